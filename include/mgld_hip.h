@@ -1,0 +1,210 @@
+/*
+ * mgld_hip.h — C ABI of libmgld_hip.so, the gfx950 (MI355X / CDNA4) kernel library behind the
+ * MGLD-VSR per-segment inference hot path.
+ *
+ * The reference is pure Python: its "FFI" for this path is the set of vendor kernels it reaches through
+ * PyTorch / xformers.  Each entry point below replaces one of those call sites (cited per function as
+ * reference file:line, paths relative to the reference tree).  Conventions:
+ *   - plain pointers + sizes only; no torch types.  All pointers are DEVICE pointers borrowed for the call.
+ *   - every launcher takes the hipStream_t (as void*) to enqueue on; no host sync, no allocation inside,
+ *     so every call is hipGraph-capturable.
+ *   - return 0 on success, negative MGLD_E_* on error (host side raises RuntimeError).
+ *   - activations are NHWC ("tokens x channels") fp16 matrices with an explicit leading dimension `ld`
+ *     (elements), so channel-concatenation is done by producers writing into slices of a wider buffer.
+ *   - accumulation, normalisation statistics, softmax and the DDPM/guidance arithmetic are fp32.
+ */
+#ifndef MGLD_HIP_H
+#define MGLD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGLD_OK 0
+#define MGLD_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
+#define MGLD_E_LAUNCH (-2)   /* hipLaunch / runtime error */
+#define MGLD_E_UNSUPPORTED (-3)
+
+/* ---- runtime ------------------------------------------------------------------------------------------- */
+int mgld_version(void);
+/* last HIP error string seen by the library (static storage) */
+const char* mgld_last_error(void);
+/* device properties: out[0]=CU count, out[1]=LDS bytes/CU, out[2]=clock kHz, out[3]=gcn arch number (950) */
+int mgld_device_info(int device, int64_t* out4);
+/* stream-capture helpers (hipStreamBeginCapture / EndCapture / GraphInstantiate / GraphLaunch) */
+int mgld_graph_begin(void* stream);
+int mgld_graph_end(void* stream, void** graph_exec_out);
+int mgld_graph_launch(void* graph_exec, void* stream);
+int mgld_graph_destroy(void* graph_exec);
+/* hipEvent timing on an arbitrary stream (bench.py: roofline.achieved is measured with these) */
+int mgld_event_create(void** ev_out);
+int mgld_event_record(void* ev, void* stream);
+int mgld_event_sync(void* ev);
+int mgld_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);
+int mgld_event_destroy(void* ev);
+
+/* ---- K1/K2/K4/K8/K13: implicit-GEMM on MFMA ---------------------------------------------------------------
+ * C[M,N] = epilogue( A_gather[M,K] * W[N,K]^T ), fp16 operands, fp32 accumulate (v_mfma_f32_32x32x16_f16).
+ * Replaces: nn.Conv2d 3x3 / 1x1 (openaimodel.py:176,221,271-304,401-436; spade.py:83-88; model.py:84-183;
+ * rrdbnet_arch.py:9-38), nn.Linear (attention.py:51,64,71,323-330,510,524; openaimodel.py:2021-2025),
+ * nn.Conv1d 1x1 (openaimodel.py:515-519), nn.Conv3d (3,1,1) (diffusionmodules/util.py:298).
+ */
+enum {
+  MGLD_MODE_LINEAR = 0,  /* A row m = A + m*lda                                             */
+  MGLD_MODE_CONV3X3 = 1, /* m=(n,oy,ox); K = 9*Cin; tap (ky,kx) reads pixel (oy*s+ky-pad_t, ox*s+kx-pad_l);
+                            zero outside; optional nearest-2x upsample folded into the gather */
+  MGLD_MODE_TCONV3 = 2   /* m=(clip,t,p); K = 3*Cin; tap dt reads frame t+dt-1 (zero outside [0,T)) */
+};
+enum {
+  MGLD_ACT_NONE = 0,
+  MGLD_ACT_RELU = 1,
+  MGLD_ACT_LRELU02 = 2,
+  MGLD_ACT_SILU = 3,
+  MGLD_ACT_GEGLU = 4 /* W rows packed [32 value | 32 gate] per 64; output has N/2 columns: v*gelu(g) */
+};
+
+typedef struct MgldIGemm {
+  const void* A;      /* fp16 activations                                                   */
+  const void* W;      /* fp16 weights [N, ldw], K contiguous ([Cout][tap][Cin] for conv)    */
+  void* C;            /* fp16 (or fp32 if out_f32) output [M, ldc]                          */
+  const float* bias;  /* [N] or NULL                                                        */
+  const float* bias_m;/* [M] per-row bias or NULL (transposed projections)                  */
+  const float* rowvec;/* [M / rows_per_frame, ld_rowvec] per-frame per-channel add, or NULL (time-embedding add) */
+  const void* R;      /* fp16 residual [M, ldr] or NULL                                     */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldc, ldr, ld_rowvec;
+  int32_t mode;
+  int32_t Cin;            /* channels per tap (K = taps*Cin); Cin % 8 == 0                  */
+  int32_t Hin, Win;       /* stored input image size                                        */
+  int32_t Hout, Wout;     /* output image size                                              */
+  int32_t stride;         /* 1 or 2                                                         */
+  int32_t pad_t, pad_l;   /* top/left zero padding (bottom/right implied by Hout/Wout)      */
+  int32_t up2;            /* 1: gather from a virtual nearest-2x-upsampled input            */
+  int32_t T, HW;          /* TCONV3: frames per clip, pixels per frame                      */
+  int32_t rows_per_frame; /* for rowvec                                                     */
+  int32_t act;
+  int32_t out_f32;
+  float alpha, beta;      /* out = alpha*act(acc+bias+rowvec) + beta*R                      */
+  int32_t batch;          /* grid.z batches (>=1)                                           */
+  int64_t strideA, strideW, strideC, strideR; /* element strides between batches            */
+} MgldIGemm;
+
+int mgld_igemm(const MgldIGemm* p, void* stream);
+
+/* ---- K3: GroupNorm (32 groups) on NHWC fp16, fp32 statistics -----------------------------------------------
+ * Replaces nn.GroupNorm / GroupNorm32 (diffusionmodules/util.py:214-216, model.py:80-81, attention.py:87-88).
+ * stats: two-stage (per-chunk per-channel partial sums -> fp64 combine) -> mean/rstd [frames, groups, 2].
+ * `partials` workspace: frames * chunks(=mgld_gn_chunks(rows)) * C * 2 floats.
+ */
+int mgld_gn_chunks(int rows_per_frame);
+int mgld_gn_stats(const void* x, int frames, int rows_per_frame, int C, int ld, int groups, float eps,
+                  float* partials, float* stats_out, void* stream);
+/* y = [silu]((x-mean)*rstd*gamma+beta); x,y fp16 NHWC */
+int mgld_gn_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                  void* y, int ldy, int frames, int rows_per_frame, int C, int groups, int silu, void* stream);
+/* SPADE modulation + residual (spade.py:93-111, openaimodel.py:481-482):
+ * y = skip + ((h-mean)*rstd*gamma+beta) * (1+gb[:, 0:C]) + gb[:, C:2C]          */
+int mgld_spade_apply(const void* h, int ldh, const float* stats, const float* gamma, const float* beta,
+                     const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
+                     int frames, int rows_per_frame, int C, int groups, void* stream);
+/* LayerNorm over C per token (attention.py:125,427-429), eps 1e-5 */
+int mgld_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                   int rows, int C, float eps, void* stream);
+
+/* ---- K5/K6/K7/K9: attention ----------------------------------------------------------------------------------
+ * Flash attention, fp16 q/k/v, fp32 online softmax, exact softmax(q k^T * scale) v.
+ * Replaces xformers.ops.memory_efficient_attention (attention.py:298,371; openaimodel.py:582).
+ * Element (b, row i, head h, dim d):  q: Q + b*q_sb + i*q_si + h*q_sh + d   (same for k, o)
+ * V is consumed TRANSPOSED: vt element (b, h, d, key j) at Vt + b*vt_sb + h*vt_sh + d*vt_sd + j
+ * (the V projection GEMM writes it that way; vt_sd % 4 == 0, rows zero-padded past Nkv).
+ * head_dim in {64, 128}.
+ */
+typedef struct MgldAttn {
+  const void* Q; const void* K; const void* Vt; void* O;
+  int32_t batch, heads, Nq, Nkv, head_dim;
+  int64_t q_sb, q_si, q_sh;
+  int64_t k_sb, k_si, k_sh;
+  int64_t vt_sb, vt_sh, vt_sd;
+  int64_t o_sb, o_si, o_sh;
+  float scale;
+} MgldAttn;
+int mgld_attention(const MgldAttn* p, void* stream);
+/* TemporalAttention core (attention.py:124-143 -> 262-308): per pixel and head, softmax over the T frames.
+ * q,k,v,o: frame-major token matrices [T*HW, ld] fp16 (row = t*HW + pixel), head h at columns h*head_dim.. ;
+ * T <= 16, head_dim in {64,128}. One wave per (pixel, head). */
+int mgld_temporal_attention(const void* q, const void* k, const void* v, int ld, void* o, int ldo, int T, int HW,
+                            int heads, int head_dim, float scale, void* stream);
+/* row softmax fp32 [rows, ld_s] -> fp16 [rows, ld_p] (VAE mid attention d=512, model.py:220-244) */
+int mgld_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, void* stream);
+
+/* ---- small dense ops -----------------------------------------------------------------------------------------
+ * y[m,n] = act_out( sum_k act_in(a[m,k]) * w[n,k] + b[n] ), M <= 16, fp32 a/y, fp16 w: weight-streaming GEMV
+ * for the time-embedding MLPs (openaimodel.py:2020-2025, 289-295; diffusionmodules/util.py:151-171). */
+int mgld_linear_small(const float* a, int lda, const void* w, int ldw, const float* b, float* y, int ldy,
+                      int M, int N, int K, int silu_in, int silu_out, void* stream);
+/* sinusoidal embedding: out[m, :dim] = [cos(t*f), sin(t*f)], t = tvals[m*t_stride] (float) */
+int mgld_timestep_embedding(const float* tvals, int t_stride, float* out, int M, int dim, void* stream);
+
+/* ---- layout / copies -------------------------------------------------------------------------------------- */
+/* fp32 NCHW [n,c,h,w] -> fp16 NHWC [n*h*w, ld] (channels >= c zero-filled up to cpad) */
+int mgld_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int cpad, int ld, void* stream);
+/* fp16/fp32 NHWC [n*h*w, ld] (first c channels) -> fp32 NCHW */
+int mgld_nhwc_to_nchw(const void* x, int in_f32, int ld, float* y, int n, int c, int h, int w, void* stream);
+/* strided fp16 2-D copy: dst[r, 0:cols] = src[r, 0:cols]; cols % 8 == 0 */
+int mgld_copy2d(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols, void* stream);
+/* y = a*x + b*y (fp16, strided) */
+int mgld_axpby(const void* x, int ldx, void* y, int ldy, int64_t rows, int cols, float a, float b, void* stream);
+
+/* ---- B2/B3/F1/K10/K15: one reverse-diffusion step + motion guidance (ddpm.py:340-353, 3538-3574, 4325-4380) ---
+ * coef table row (8 floats per schedule index i): {sqrt_recip_ac, sqrt_recipm1_ac, post_mean_coef1,
+ * post_mean_coef2, post_log_var_clipped, nonzero(i!=0), t_replace, unused}. `step_idx` is a device int. */
+/* z = mean(x, eps) + nonzero*exp(0.5*logvar)*noise ; x,noise,z fp32 NCHW [n,4,h,w]; eps fp32 NHWC [n*h*w, ld_eps] */
+int mgld_ddpm_step(const float* x, const float* eps, int ld_eps, const float* noise, const float* coef,
+                   const int32_t* step_idx, float* z, int n, int c, int h, int w, void* stream);
+/* bilinear backward warp, zeros padding, align_corners=True (arch_util.py:156-194): out[n,c,y,x] =
+ * bilinear(in[n,c], x+flow[n,0,y,x], y+flow[n,1,y,x]); flow fp32 [n,2,h,w] */
+int mgld_flow_warp(const float* in, const float* flow, float* out, int n, int c, int h, int w, void* stream);
+/* guidance: given z [T,c,h,w], flows fwd_prop/bwd_prop [T-1,2,h,w], occlusion masks fwd_occ/bwd_occ [T-1,h,w]:
+ * x_out = z - guidance_scale*logvar(step)*grad(L)(z), L = compute_temporal_condition_v4.
+ * work: >= (2*T*c*h*w) floats + (T*c*h*w) int64 (scatter accumulators), caller-provided. */
+int mgld_guidance(const float* z, const float* flow_fwd_prop, const float* flow_bwd_prop,
+                  const float* fwd_occ, const float* bwd_occ, const float* coef, const int32_t* step_idx,
+                  float guidance_scale, float* x_out, void* work, int T, int c, int h, int w, void* stream);
+/* scalar loss value of compute_temporal_condition_v4 (tests) -> loss_out[0] (device) */
+int mgld_guidance_loss(const float* z, const float* flow_fwd_prop, const float* flow_bwd_prop,
+                       const float* fwd_occ, const float* bwd_occ, float* loss_out, void* work,
+                       int T, int c, int h, int w, void* stream);
+/* step_idx[0] += delta */
+int mgld_step_advance(int32_t* step_idx, int delta, void* stream);
+/* tvals[m] = coef[step][6] (t_replace) for m < n  (feeds mgld_timestep_embedding) */
+int mgld_step_timestep(const float* coef, const int32_t* step_idx, float* tvals, int n, void* stream);
+
+/* ---- F3/F4: flow utilities (util_flow.py:114-136, arch_util.py:235-270) --------------------------------- */
+int mgld_fb_consistency(const float* fwd_flow, const float* bwd_flow, float alpha, float beta,
+                        float* fwd_occ, float* bwd_occ, int n, int h, int w, void* stream);
+/* bilinear resize (align_corners=False) of [n,2,h,w] flow to [n,2,oh,ow] with u,v rescaled */
+int mgld_resize_flow(const float* flow, float* out, int n, int h, int w, int oh, int ow, void* stream);
+
+/* ---- H1/H2: colour fix (wavelet_color_fix.py:44-119) --------------------------------------------------- */
+/* out = (x-mean_x)/sqrt(var_x+eps)*sqrt(var_s+eps)+mean_s per (n,c) plane; unbiased variance; fp32 NCHW */
+int mgld_adain(const float* content, const float* style, float* out, int planes, int64_t hw, float eps,
+               float* work, void* stream);
+/* 5-level a-trous wavelet: out = high(content) + low(style); work >= 4*planes*h*w floats */
+int mgld_wavelet_reconstruction(const float* content, const float* style, float* out, int planes, int h, int w,
+                                float* work, void* stream);
+
+/* ---- C1: aggregation-sampling tile ops (ddpm.py:4191-4322, 4601-4616) ---------------------------------- */
+/* crop fp32 NCHW src[n,c,H,W] window (y0,x0,th,tw) -> dst[n,c,th,tw] */
+int mgld_crop(const float* src, float* dst, int n, int c, int H, int W, int y0, int x0, int th, int tw, void* stream);
+/* acc[n,c,y0+y,x0+x] += tile[n,c,y,x]*wgt[y,x]; cnt[.. same ..] += wgt[y,x]   (tile fp32 NCHW) */
+int mgld_tile_accumulate(const float* tile, const float* wgt, float* acc, float* cnt, int n, int c, int H, int W,
+                         int y0, int x0, int th, int tw, void* stream);
+/* out = acc / cnt */
+int mgld_tile_normalize(const float* acc, const float* cnt, float* out, int64_t numel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGLD_HIP_H */

@@ -1,0 +1,246 @@
+// attention.hip — flash attention on CDNA4 matrix cores + a plain row-softmax.
+//
+// Replaces xformers.ops.memory_efficient_attention on the hot path (attention.py:298,371;
+// openaimodel.py:582; SURVEY.md §2.2 K5,K6,K7,K9): exact softmax(q k^T * scale) v, no mask, fp32 softmax.
+//
+// Design (64-wide wavefronts, v_mfma_f32_32x32x16_f16):
+//  * one block = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.
+//  * scores are computed TRANSPOSED, S^T = K Q^T, so a lane holds 16 keys of ONE query row per 32-key tile:
+//    the online-softmax row max / row sum are 31 lane-local ops + one exchange with lane^32 (wave shuffle),
+//    no LDS round trip.
+//  * the probabilities feed the second MFMA directly from registers: O^T = V^T P^T.  The key->k-slot
+//    assignment of that MFMA is chosen to be exactly the order in which the lane already holds P
+//    (any permutation of the contraction index is legal as long as both operands agree), so P never
+//    moves between lanes.  V arrives already transposed ([head][d][key], written so by the V projection
+//    GEMM), so V^T fragments are two 8-byte LDS reads.
+//  * K and V^T tiles (64 keys) are staged global->registers->LDS; the next tile's global loads are issued
+//    before the current tile's MFMAs (issue-early / write-late).
+#include "common.h"
+
+namespace {
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const MgldAttn p) {
+  constexpr int KT = 64;             // keys per tile
+  constexpr int KS = D + 8;          // K LDS row stride (halves): conflict-free ds_read_b128
+  constexpr int VS = KT + 4;         // V^T LDS row stride (halves): 34 banks -> conflict-free ds_read_b64
+  constexpr int DK = D / 16;         // k-steps of the QK^T contraction
+  constexpr int DT = D / 32;         // 32-row tiles of O^T
+  constexpr int NKV = KT * D / 8 / 256;  // staging vectors per thread for K (and for V^T)
+
+  __shared__ __attribute__((aligned(16))) f16 sK[KT * KS];
+  __shared__ __attribute__((aligned(16))) f16 sV[D * VS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int Nq = p.Nq, Nkv = p.Nkv;
+
+  const f16* __restrict__ Qp = (const f16*)p.Q + b * p.q_sb + h * p.q_sh;
+  const f16* __restrict__ Kp = (const f16*)p.K + b * p.k_sb + h * p.k_sh;
+  const f16* __restrict__ Vp = (const f16*)p.Vt + b * p.vt_sb + h * p.vt_sh;
+
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0+l31][ks*16 + lhi*8 .. +8]
+  f16x8 qf[DK];
+  {
+    const int q = q0 + l31;
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks)
+      qf[ks] = (q < Nq) ? *(const f16x8*)(Qp + (int64_t)q * p.q_si + ks * 16 + lhi * 8) : zero8;
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = p.scale * 1.44269504088896340736f;  // fold log2(e): softmax via exp2
+
+  f16x8 rk[NKV], rv[NKV];
+  auto load_tile = [&](int kbase) {
+#pragma unroll
+    for (int i = 0; i < NKV; ++i) {
+      const int v = tid + i * 256;
+      {  // K: 64 rows x D/8 vectors
+        const int row = v / (D / 8), cv = v - row * (D / 8);
+        const int key = kbase + row;
+        rk[i] = (key < Nkv) ? *(const f16x8*)(Kp + (int64_t)key * p.k_si + cv * 8) : zero8;
+      }
+      {  // V^T: D rows x 8 vectors of 8 keys
+        const int d = v >> 3, kv = v & 7;
+        const int key0 = kbase + kv * 8;
+        f16x8 t = zero8;
+        if (key0 < Nkv) {
+          t = *(const f16x8*)(Vp + (int64_t)d * p.vt_sd + key0);
+          if (key0 + 8 > Nkv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (key0 + j >= Nkv) t[j] = (f16)0.f;
+          }
+        }
+        rv[i] = t;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NKV; ++i) {
+      const int v = tid + i * 256;
+      const int row = v / (D / 8), cv = v - row * (D / 8);
+      *(f16x8*)(sK + row * KS + cv * 8) = rk[i];
+      const int d = v >> 3, kv = v & 7;
+      f16* dst = sV + d * VS + kv * 8;
+      *(f16x4*)(dst) = f16x4{rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
+      *(f16x4*)(dst + 4) = f16x4{rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
+    }
+  };
+
+  const int ntiles = (Nkv + KT - 1) / KT;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kbase = t * KT;
+    if (t + 1 < ntiles) load_tile(kbase + KT);  // in flight under the MFMAs below
+
+    // ---- S^T = K Q^T for 2 key tiles of 32 ----
+    f32x16 st[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[k2][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        const f16x8 kf = *(const f16x8*)(sK + (k2 * 32 + l31) * KS + ks * 16 + lhi * 8);
+        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[k2], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (lane: query q0+l31; keys (r&3)+8*(r>>2)+4*lhi of each 32-key tile) ----
+    float mx = -1e30f;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + k2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float s = (key < Nkv) ? st[k2][r] * sc : -1e30f;
+        st[k2][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[k2][r] - m_new);
+        st[k2][r] = e;
+        rs += e;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- O^T += V^T P^T : 4 chunks of 16 keys; slot jj of chunk c <-> register 8*(c&1)+jj of tile c>>1 ----
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k2 = c >> 1, c2 = c & 1;
+      f16x8 pf;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) pf[jj] = (f16)st[k2][c2 * 8 + jj];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const f16* vrow = sV + (dt * 32 + l31) * VS + k2 * 32 + c2 * 16 + lhi * 4;
+        const f16x4 v0 = *(const f16x4*)(vrow);
+        const f16x4 v1 = *(const f16x4*)(vrow + 8);
+        const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // everyone done reading this tile
+    if (t + 1 < ntiles) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l ----
+  const int q = q0 + l31;
+  if (q < Nq) {
+    const float inv = 1.f / l_run;
+    f16* Op = (f16*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_si;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = dt * 32 + rg * 8 + lhi * 4;
+        *(f16x4*)(Op + d) = f16x4{(f16)(o[dt][rg * 4 + 0] * inv), (f16)(o[dt][rg * 4 + 1] * inv),
+                                  (f16)(o[dt][rg * 4 + 2] * inv), (f16)(o[dt][rg * 4 + 3] * inv)};
+      }
+  }
+}
+
+// one block per row: fp32 logits -> fp16 probabilities
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t ld_s, f16* __restrict__ P,
+                                                           int64_t ld_p, int cols) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const float* s = S + row * ld_s;
+  f16* o = P + row * ld_p;
+  const int tid = threadIdx.x;
+  float mx = -1e30f;
+  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, s[c]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += 256) sum += __expf(s[c] - mx);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.f / sum;
+  for (int c = tid; c < cols; c += 256) o[c] = (f16)(__expf(s[c] - mx) * inv);
+}
+
+}  // namespace
+
+extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
+  MGLD_REQUIRE(p && p->Q && p->K && p->Vt && p->O, "attention: null pointer");
+  MGLD_REQUIRE(p->batch > 0 && p->heads > 0 && p->Nq > 0 && p->Nkv > 0, "attention: empty");
+  MGLD_REQUIRE(p->head_dim == 64 || p->head_dim == 128, "attention: head_dim must be 64 or 128");
+  MGLD_REQUIRE((p->q_sb & 7) == 0 && (p->q_si & 7) == 0 && (p->q_sh & 7) == 0, "attention: q strides % 8");
+  MGLD_REQUIRE((p->k_sb & 7) == 0 && (p->k_si & 7) == 0 && (p->k_sh & 7) == 0, "attention: k strides % 8");
+  MGLD_REQUIRE((p->vt_sb & 7) == 0 && (p->vt_sh & 7) == 0 && (p->vt_sd & 7) == 0, "attention: vt strides % 8");
+  MGLD_REQUIRE((p->o_sb & 3) == 0 && (p->o_si & 3) == 0 && (p->o_sh & 3) == 0, "attention: o strides % 4");
+  MGLD_REQUIRE((((uintptr_t)p->Q | (uintptr_t)p->K | (uintptr_t)p->Vt) & 15) == 0 && ((uintptr_t)p->O & 7) == 0,
+               "attention: pointer alignment");
+  MGLD_REQUIRE(p->vt_sd >= ((p->Nkv + 7) & ~7), "attention: vt rows must be padded to a multiple of 8 keys");
+  dim3 grid(cdiv(p->Nq, 128), p->heads, p->batch);
+  if (p->head_dim == 64)
+    hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, *p);
+  else
+    hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, *p);
+  return mgld_check_launch("attention");
+}
+
+extern "C" int mgld_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols,
+                                 void* stream) {
+  MGLD_REQUIRE(S && P && rows > 0 && cols > 0, "softmax_rows: bad args");
+  MGLD_REQUIRE(rows < (1ll << 31), "softmax_rows: too many rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, ld_s, (f16*)P, ld_p,
+                     cols);
+  return mgld_check_launch("softmax_rows");
+}

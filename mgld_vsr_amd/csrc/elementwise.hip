@@ -1,0 +1,738 @@
+// elementwise.hip — small dense ops, layout conversion, flow utilities, colour fix and tile stitching.
+// All are HBM- or latency-bound (SURVEY.md §2.2 K9,K11,K14,K15): coalesced / 16-byte accesses, fp32 math.
+#include "common.h"
+
+namespace {
+
+inline int egrid(int64_t total, int per_block = 256) {
+  int64_t b = (total + per_block - 1) / per_block;
+  if (b > 256 * 32) b = 256 * 32;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- weight-streaming small-M linear: one wave per output feature ---------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ a, int lda, const f16* __restrict__ w,
+                                                           int ldw, const float* __restrict__ bias, float* __restrict__ y,
+                                                           int ldy, int M, int N, int K, int silu_in, int silu_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  const f16* wr = w + (int64_t)n * ldw;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    const f16x8 wv = *(const f16x8*)(wr + k);
+    float wf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[j] = (float)wv[j];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < M) {
+        const f32x4 a0 = *(const f32x4*)(a + (int64_t)m * lda + k);
+        const f32x4 a1 = *(const f32x4*)(a + (int64_t)m * lda + k + 4);
+        float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = silu_in ? silu_f(av[j]) : av[j];
+          acc[m] += x * wf[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float s = wave_sum(acc[m]);
+    if (lane == 0 && m < M) {
+      float v = s + (bias ? bias[n] : 0.f);
+      if (silu_out) v = silu_f(v);
+      y[(int64_t)m * ldy + n] = v;
+    }
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ tvals, int t_stride, float* __restrict__ out, int M,
+                                          int dim) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * dim) return;
+  const int m = idx / dim, j = idx - m * dim;
+  float v = 0.f;
+  if (j < 2 * half) {
+    const int jj = j < half ? j : j - half;
+    // reference: freqs = exp(-log(10000) * arange(half, fp32) / half) ; args = t * freqs   (util.py:163-167)
+    const float freq = expf(-9.210340371976184f * (float)jj / (float)half);
+    const float arg = tvals[m * t_stride] * freq;
+    v = j < half ? cosf(arg) : sinf(arg);
+  }
+  out[idx] = v;
+}
+
+// ---- layout ------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, f16* __restrict__ y, int n, int c, int hw, int cpad,
+                                    int ld) {
+  const int64_t total = (int64_t)n * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = idx / hw;
+    const int64_t pix = idx - f * hw;
+    for (int c0 = 0; c0 < cpad; c0 += 8) {
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = c0 + j;
+        o[j] = ch < c ? (f16)x[(f * c + ch) * hw + pix] : (f16)0.f;
+      }
+      *(f16x8*)(y + idx * ld + c0) = o;
+    }
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, int in_f32, int ld, float* __restrict__ y, int n, int c,
+                                    int hw) {
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx % hw;
+    const int64_t fc = idx / hw;
+    const int ch = (int)(fc % c);
+    const int64_t f = fc / c;
+    const int64_t src = (f * hw + pix) * ld + ch;
+    y[idx] = in_f32 ? ((const float*)x)[src] : (float)((const f16*)x)[src];
+  }
+}
+
+__global__ void copy2d_kernel(const f16* __restrict__ src, int lds_, f16* __restrict__ dst, int ldd, int64_t rows, int nv) {
+  const int64_t total = rows * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / nv;
+    const int v = (int)(idx - r * nv);
+    *(f16x8*)(dst + r * ldd + v * 8) = *(const f16x8*)(src + r * lds_ + v * 8);
+  }
+}
+
+__global__ void axpby_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy, int64_t rows, int nv, float a,
+                             float b) {
+  const int64_t total = rows * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / nv;
+    const int v = (int)(idx - r * nv);
+    const f16x8 xv = *(const f16x8*)(x + r * ldx + v * 8);
+    f16x8 yv = *(const f16x8*)(y + r * ldy + v * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yv[j] = (f16)(a * (float)xv[j] + b * (float)yv[j]);
+    *(f16x8*)(y + r * ldy + v * 8) = yv;
+  }
+}
+
+// ---- temporal attention (attention.py:124-143): tokens (pixel) x T frames, tiny ------------------------------
+// one wave per (pixel, head); lanes span the head dim.  q,k,v: [T*HW, ld] fp16 (frame-major), out same layout.
+template <int DH>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                            const f16* __restrict__ v, int ld, f16* __restrict__ o,
+                                                            int ldo, int T, int HW, int heads, float scale) {
+  constexpr int E = DH / 64;  // elements per lane
+  constexpr int TMAX = 16;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= HW * heads) return;
+  const int pix = item / heads, h = item - pix * heads;
+  float kk[TMAX][E], vv[TMAX][E];
+#pragma unroll
+  for (int j = 0; j < TMAX; ++j)
+    if (j < T) {
+      const int64_t off = ((int64_t)j * HW + pix) * ld + h * DH;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { kk[j][e] = (float)k[off + lane + e * 64]; vv[j][e] = (float)v[off + lane + e * 64]; }
+    }
+  for (int i = 0; i < T; ++i) {
+    const int64_t off = ((int64_t)i * HW + pix) * ld + h * DH;
+    float qq[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) qq[e] = (float)q[off + lane + e * 64];
+    float s[TMAX];
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j)
+      if (j < T) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) d += qq[e] * kk[j][e];
+        s[j] = wave_sum(d) * scale;
+        mx = fmaxf(mx, s[j]);
+      }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j)
+      if (j < T) { s[j] = __expf(s[j] - mx); den += s[j]; }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < TMAX; ++j)
+        if (j < T) acc += s[j] * vv[j][e];
+      o[((int64_t)i * HW + pix) * ldo + h * DH + lane + e * 64] = (f16)(acc * inv);
+    }
+  }
+}
+
+// ---- DDPM reverse step (ddpm.py:340-353, 4344-4357) -----------------------------------------------------------
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, int ld_eps,
+                                 const float* __restrict__ noise, const float* __restrict__ coef,
+                                 const int32_t* __restrict__ step_idx, float* __restrict__ z, int n, int c, int hw) {
+  const float* cf = coef + (int64_t)step_idx[0] * 8;
+  const float c_recip = cf[0], c_recipm1 = cf[1], pm1 = cf[2], pm2 = cf[3], logvar = cf[4], nonzero = cf[5];
+  const float sigma = nonzero * expf(0.5f * logvar);
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx % hw;
+    const int64_t fc = idx / hw;
+    const int ch = (int)(fc % c);
+    const int64_t f = fc / c;
+    const float e = eps[(f * hw + pix) * ld_eps + ch];
+    const float xv = x[idx];
+    const float x0 = c_recip * xv - c_recipm1 * e;
+    const float mean = pm1 * x0 + pm2 * xv;
+    z[idx] = mean + sigma * noise[idx];
+  }
+}
+
+// bilinear tap helper: zeros padding, align_corners=True (pixel coordinates)
+struct Taps {
+  int x0, y0;
+  float w00, w01, w10, w11;  // (y0,x0) (y0,x1) (y1,x0) (y1,x1), already zeroed when out of range
+};
+__device__ __forceinline__ Taps make_taps(float sx, float sy, int h, int w) {
+  Taps t;
+  const float fx = floorf(sx), fy = floorf(sy);
+  // guard against non-finite / huge coordinates before the int conversion
+  const float cx = fminf(fmaxf(fx, -2.f), (float)w + 1.f), cy = fminf(fmaxf(fy, -2.f), (float)h + 1.f);
+  t.x0 = (int)cx; t.y0 = (int)cy;
+  const float ax = sx - fx, ay = sy - fy;
+  const bool inx0 = (fx == cx) && t.x0 >= 0 && t.x0 < w, inx1 = (fx == cx) && t.x0 + 1 >= 0 && t.x0 + 1 < w;
+  const bool iny0 = (fy == cy) && t.y0 >= 0 && t.y0 < h, iny1 = (fy == cy) && t.y0 + 1 >= 0 && t.y0 + 1 < h;
+  t.w00 = (iny0 && inx0) ? (1.f - ay) * (1.f - ax) : 0.f;
+  t.w01 = (iny0 && inx1) ? (1.f - ay) * ax : 0.f;
+  t.w10 = (iny1 && inx0) ? ay * (1.f - ax) : 0.f;
+  t.w11 = (iny1 && inx1) ? ay * ax : 0.f;
+  return t;
+}
+__device__ __forceinline__ float sample_taps(const float* __restrict__ img, const Taps& t, int w) {
+  float v = 0.f;
+  if (t.w00 != 0.f) v += t.w00 * img[t.y0 * w + t.x0];
+  if (t.w01 != 0.f) v += t.w01 * img[t.y0 * w + t.x0 + 1];
+  if (t.w10 != 0.f) v += t.w10 * img[(t.y0 + 1) * w + t.x0];
+  if (t.w11 != 0.f) v += t.w11 * img[(t.y0 + 1) * w + t.x0 + 1];
+  return v;
+}
+
+__global__ void flow_warp_kernel(const float* __restrict__ in, const float* __restrict__ flow, float* __restrict__ out, int n,
+                                 int c, int h, int w) {
+  const int hw = h * w;
+  const int64_t total = (int64_t)n * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(idx / hw);
+    const int pix = (int)(idx - (int64_t)f * hw);
+    const int y = pix / w, x = pix - y * w;
+    const float sx = (float)x + flow[((int64_t)f * 2 + 0) * hw + pix];
+    const float sy = (float)y + flow[((int64_t)f * 2 + 1) * hw + pix];
+    const Taps t = make_taps(sx, sy, h, w);
+    for (int ch = 0; ch < c; ++ch) out[((int64_t)f * c + ch) * hw + pix] = sample_taps(in + ((int64_t)f * c + ch) * hw, t, w);
+  }
+}
+
+// ---- motion guidance (ddpm.py:3538-3574 + autograd at 4367-4373), closed form ----------------------------------
+// P_j = warp(z_j, flow_bwd_prop[j]) (j<=T-2; P_{T-1}=0) ; Q_j = warp(z_j, flow_fwd_prop[j-1]) (j>=1; Q_0=0)
+__global__ void guid_warp_kernel(const float* __restrict__ z, const float* __restrict__ ff, const float* __restrict__ fb,
+                                 float* __restrict__ P, float* __restrict__ Q, long long* __restrict__ G, int T, int c, int h,
+                                 int w) {
+  const int hw = h * w;
+  const int64_t total = (int64_t)T * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(idx / hw);
+    const int pix = (int)(idx - (int64_t)j * hw);
+    const int y = pix / w, x = pix - y * w;
+    Taps tp, tq;
+    const bool hasP = j <= T - 2, hasQ = j >= 1;
+    if (hasP) tp = make_taps((float)x + fb[((int64_t)j * 2) * hw + pix], (float)y + fb[((int64_t)j * 2 + 1) * hw + pix], h, w);
+    if (hasQ)
+      tq = make_taps((float)x + ff[((int64_t)(j - 1) * 2) * hw + pix], (float)y + ff[((int64_t)(j - 1) * 2 + 1) * hw + pix], h, w);
+    for (int ch = 0; ch < c; ++ch) {
+      const int64_t o = ((int64_t)j * c + ch) * hw + pix;
+      const float* img = z + ((int64_t)j * c + ch) * hw;
+      P[o] = hasP ? sample_taps(img, tp, w) : 0.f;
+      Q[o] = hasQ ? sample_taps(img, tq, w) : 0.f;
+      G[o] = 0;
+    }
+  }
+}
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__device__ __forceinline__ void splat(long long* __restrict__ g, const Taps& t, int w, float val) {
+  // deterministic fixed-point (2^32) accumulation of the bilinear adjoint
+  const double sc = 4294967296.0;
+  if (t.w00 != 0.f) atomicAdd((unsigned long long*)(g + t.y0 * w + t.x0), (unsigned long long)(long long)llrint((double)(t.w00 * val) * sc));
+  if (t.w01 != 0.f) atomicAdd((unsigned long long*)(g + t.y0 * w + t.x0 + 1), (unsigned long long)(long long)llrint((double)(t.w01 * val) * sc));
+  if (t.w10 != 0.f) atomicAdd((unsigned long long*)(g + (t.y0 + 1) * w + t.x0), (unsigned long long)(long long)llrint((double)(t.w10 * val) * sc));
+  if (t.w11 != 0.f) atomicAdd((unsigned long long*)(g + (t.y0 + 1) * w + t.x0 + 1), (unsigned long long)(long long)llrint((double)(t.w11 * val) * sc));
+}
+
+// scatter: for j in 1..T-2, the upstream gradients of P_j (used by frame j-1) and Q_j (used by frame j+1)
+__global__ void guid_scatter_kernel(const float* __restrict__ z, const float* __restrict__ ff, const float* __restrict__ fb,
+                                    const float* __restrict__ focc, const float* __restrict__ bocc,
+                                    const float* __restrict__ P, const float* __restrict__ Q, long long* __restrict__ G, int T,
+                                    int c, int h, int w) {
+  const int hw = h * w;
+  const int64_t total = (int64_t)(T - 2) * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = 1 + (int)(idx / hw);
+    const int pix = (int)(idx % hw);
+    const int y = pix / w, x = pix - y * w;
+    const Taps tp = make_taps((float)x + fb[((int64_t)j * 2) * hw + pix], (float)y + fb[((int64_t)j * 2 + 1) * hw + pix], h, w);
+    const Taps tq =
+        make_taps((float)x + ff[((int64_t)(j - 1) * 2) * hw + pix], (float)y + ff[((int64_t)(j - 1) * 2 + 1) * hw + pix], h, w);
+    const float mf = 1.f - focc[(int64_t)(j - 1) * hw + pix];  // mask of term_b(j-1)
+    const float mb = 1.f - bocc[(int64_t)j * hw + pix];        // mask of term_f(j+1)
+    for (int ch = 0; ch < c; ++ch) {
+      const int64_t o = ((int64_t)j * c + ch) * hw + pix;
+      const float zp = z[((int64_t)(j - 1) * c + ch) * hw + pix];
+      const float zn = z[((int64_t)(j + 1) * c + ch) * hw + pix];
+      const float gP = mf * sgn(mf * P[o] - mf * zp);
+      const float gQ = mb * sgn(mb * Q[o] - mb * zn);
+      long long* gplane = G + ((int64_t)j * c + ch) * hw;
+      if (gP != 0.f) splat(gplane, tp, w, gP);
+      if (gQ != 0.f) splat(gplane, tq, w, gQ);
+    }
+  }
+}
+
+__global__ void guid_apply_kernel(const float* __restrict__ z, const float* __restrict__ focc, const float* __restrict__ bocc,
+                                  const float* __restrict__ P, const float* __restrict__ Q, const long long* __restrict__ G,
+                                  const float* __restrict__ coef, const int32_t* __restrict__ step_idx, float gscale,
+                                  float* __restrict__ xout, int T, int c, int h, int w) {
+  const int hw = h * w;
+  const float logvar = coef[(int64_t)step_idx[0] * 8 + 4];
+  const float inv_cnt = 1.f / (float)((int64_t)c * hw);
+  const int64_t total = (int64_t)T * c * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int pix = (int)(idx % hw);
+    const int64_t fc = idx / hw;
+    const int ch = (int)(fc % c);
+    const int j = (int)(fc / c);
+    const float zv = z[idx];
+    float g = 0.f;
+    if (j <= T - 2) {
+      const float m = 1.f - focc[(int64_t)j * hw + pix];
+      g -= m * sgn(m * P[((int64_t)(j + 1) * c + ch) * hw + pix] - m * zv);
+    }
+    if (j >= 1) {
+      const float m = 1.f - bocc[(int64_t)(j - 1) * hw + pix];
+      g -= m * sgn(m * Q[((int64_t)(j - 1) * c + ch) * hw + pix] - m * zv);
+    }
+    g += (float)((double)G[idx] * (1.0 / 4294967296.0));
+    xout[idx] = zv - gscale * logvar * (g * inv_cnt);
+  }
+}
+
+__global__ __launch_bounds__(256) void guid_loss_kernel(const float* __restrict__ z, const float* __restrict__ focc,
+                                                        const float* __restrict__ bocc, const float* __restrict__ P,
+                                                        const float* __restrict__ Q, double* __restrict__ acc, int T, int c,
+                                                        int h, int w) {
+  __shared__ double red[4];
+  const int hw = h * w;
+  const int64_t total = (int64_t)T * c * hw;
+  double s = 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int pix = (int)(idx % hw);
+    const int64_t fc = idx / hw;
+    const int ch = (int)(fc % c);
+    const int j = (int)(fc / c);
+    const float zv = z[idx];
+    if (j <= T - 2) {
+      const float m = 1.f - focc[(int64_t)j * hw + pix];
+      s += (double)fabsf(m * P[((int64_t)(j + 1) * c + ch) * hw + pix] - m * zv);
+    }
+    if (j >= 1) {
+      const float m = 1.f - bocc[(int64_t)(j - 1) * hw + pix];
+      s += (double)fabsf(m * Q[((int64_t)(j - 1) * c + ch) * hw + pix] - m * zv);
+    }
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void guid_loss_final_kernel(const double* __restrict__ acc, float* __restrict__ out, double inv_cnt) {
+  out[0] = (float)(acc[0] * inv_cnt);
+}
+__global__ void zero_double_kernel(double* p) { p[0] = 0.0; }
+
+__global__ void step_advance_kernel(int32_t* s, int d) { s[0] += d; }
+__global__ void step_timestep_kernel(const float* coef, const int32_t* s, float* tv, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tv[i] = coef[(int64_t)s[0] * 8 + 6];
+}
+
+// ---- forward/backward consistency (util_flow.py:114-136) ---------------------------------------------------------
+__global__ void fb_consistency_kernel(const float* __restrict__ fwd, const float* __restrict__ bwd, float alpha, float beta,
+                                      float* __restrict__ focc, float* __restrict__ bocc, int n, int h, int w) {
+  const int hw = h * w;
+  const int64_t total = (int64_t)n * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(idx / hw);
+    const int pix = (int)(idx - (int64_t)f * hw);
+    const int y = pix / w, x = pix - y * w;
+    const float* fx = fwd + ((int64_t)f * 2) * hw;
+    const float* fy = fx + hw;
+    const float* bx = bwd + ((int64_t)f * 2) * hw;
+    const float* by = bx + hw;
+    const float fu = fx[pix], fv = fy[pix], bu = bx[pix], bv = by[pix];
+    const float mag = sqrtf(fu * fu + fv * fv) + sqrtf(bu * bu + bv * bv);
+    const Taps tf = make_taps((float)x + fu, (float)y + fv, h, w);  // warp bwd by fwd
+    const Taps tb = make_taps((float)x + bu, (float)y + bv, h, w);  // warp fwd by bwd
+    const float wbu = sample_taps(bx, tf, w), wbv = sample_taps(by, tf, w);
+    const float wfu = sample_taps(fx, tb, w), wfv = sample_taps(fy, tb, w);
+    const float d_f = sqrtf((fu + wbu) * (fu + wbu) + (fv + wbv) * (fv + wbv));
+    const float d_b = sqrtf((bu + wfu) * (bu + wfu) + (bv + wfv) * (bv + wfv));
+    const float thr = alpha * mag + beta;
+    focc[idx] = d_f > thr ? 1.f : 0.f;
+    bocc[idx] = d_b > thr ? 1.f : 0.f;
+  }
+}
+
+// bilinear interpolate, align_corners=False (PyTorch area_pixel_compute_source_index semantics), flow rescaled
+__global__ void resize_flow_kernel(const float* __restrict__ flow, float* __restrict__ out, int n, int h, int w, int oh, int ow) {
+  const float sh = (float)h / (float)oh, sw = (float)w / (float)ow;
+  const float rh = (float)oh / (float)h, rw = (float)ow / (float)w;
+  const int64_t total = (int64_t)n * 2 * oh * ow;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % ow);
+    const int oy = (int)((idx / ow) % oh);
+    const int64_t pl = idx / ((int64_t)oh * ow);
+    const int ch = (int)(pl & 1);
+    float sy = ((float)oy + 0.5f) * sh - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = ((float)ox + 0.5f) * sw - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float* p = flow + pl * h * w;
+    const float scale = ch == 0 ? rw : rh;
+    const float v = (1.f - ly) * ((1.f - lx) * p[y0 * w + x0] * scale + lx * p[y0 * w + x1] * scale) +
+                    ly * ((1.f - lx) * p[y1 * w + x0] * scale + lx * p[y1 * w + x1] * scale);
+    out[idx] = v;
+  }
+}
+
+// ---- AdaIN (wavelet_color_fix.py:44-71): per-plane mean / unbiased var via fp64 two-level reduction ----------------
+// work: [2 tensors][planes][2] doubles
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ x, int64_t hw, double* __restrict__ st) {
+  __shared__ double rs[4], rq[4];
+  const int plane = blockIdx.x;
+  const float* p = x + (int64_t)plane * hw;
+  double s = 0.0, q = 0.0;
+  for (int64_t i = threadIdx.x; i < hw; i += 256) { const double v = p[i]; s += v; q += v * v; }
+  s = wave_sum_d(s); q = wave_sum_d(q);
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = rs[0] + rs[1] + rs[2] + rs[3]; q = rq[0] + rq[1] + rq[2] + rq[3];
+    const double mean = s / (double)hw;
+    const double var = (q - s * mean) / (double)(hw - 1);  // unbiased (Tensor.var default)
+    st[plane * 2] = mean; st[plane * 2 + 1] = var;
+  }
+}
+__global__ void adain_apply_kernel(const float* __restrict__ content, const double* __restrict__ cst,
+                                   const double* __restrict__ sst, float* __restrict__ out, int planes, int64_t hw, float eps) {
+  const int64_t total = (int64_t)planes * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int pl = (int)(idx / hw);
+    const float cm = (float)cst[pl * 2], cs = sqrtf((float)cst[pl * 2 + 1] + eps);
+    const float sm = (float)sst[pl * 2], ss = sqrtf((float)sst[pl * 2 + 1] + eps);
+    out[idx] = (content[idx] - cm) / cs * ss + sm;
+  }
+}
+
+// ---- a-trous wavelet blur (wavelet_color_fix.py:73-119): 3x3 [1 2 1]^2/16, dilation r, replicate padding ---------
+__global__ void wavelet_blur_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int r) {
+  const int64_t total = (int64_t)planes * h * w;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % w);
+    const int y = (int)((idx / w) % h);
+    const float* p = in + (idx / ((int64_t)h * w)) * h * w;
+    const int ym = max(y - r, 0), yp = min(y + r, h - 1), xm = max(x - r, 0), xp = min(x + r, w - 1);
+    // same accumulation order as a 3x3 cross-correlation (row-major taps)
+    float v = 0.0625f * p[ym * w + xm] + 0.125f * p[ym * w + x] + 0.0625f * p[ym * w + xp];
+    v += 0.125f * p[y * w + xm] + 0.25f * p[y * w + x] + 0.125f * p[y * w + xp];
+    v += 0.0625f * p[yp * w + xm] + 0.125f * p[yp * w + x] + 0.0625f * p[yp * w + xp];
+    out[idx] = v;
+  }
+}
+// hi += (img - low)
+__global__ void wavelet_acc_kernel(const float* __restrict__ img, const float* __restrict__ low, float* __restrict__ hi,
+                                   int64_t total, int first) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const float d = img[idx] - low[idx];
+    hi[idx] = first ? d : hi[idx] + d;
+  }
+}
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    o[idx] = a[idx] + b[idx];
+}
+
+// ---- aggregation-sampling tiles -------------------------------------------------------------------------------
+__global__ void crop_kernel(const float* __restrict__ src, float* __restrict__ dst, int nc, int H, int W, int y0, int x0, int th,
+                            int tw) {
+  const int64_t total = (int64_t)nc * th * tw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % tw);
+    const int y = (int)((idx / tw) % th);
+    const int64_t pl = idx / ((int64_t)th * tw);
+    dst[idx] = src[(pl * H + y0 + y) * W + x0 + x];
+  }
+}
+__global__ void tile_acc_kernel(const float* __restrict__ tile, const float* __restrict__ wgt, float* __restrict__ acc,
+                                float* __restrict__ cnt, int nc, int H, int W, int y0, int x0, int th, int tw) {
+  const int64_t total = (int64_t)nc * th * tw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % tw);
+    const int y = (int)((idx / tw) % th);
+    const int64_t pl = idx / ((int64_t)th * tw);
+    const float wv = wgt[y * tw + x];
+    const int64_t o = (pl * H + y0 + y) * W + x0 + x;
+    acc[o] += tile[idx] * wv;
+    cnt[o] += wv;
+  }
+}
+__global__ void tile_norm_kernel(const float* __restrict__ acc, const float* __restrict__ cnt, float* __restrict__ out,
+                                 int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    out[idx] = acc[idx] / cnt[idx];
+}
+
+}  // namespace
+
+#define S_(s) ((hipStream_t)(s))
+
+extern "C" int mgld_linear_small(const float* a, int lda, const void* w, int ldw, const float* b, float* y, int ldy, int M,
+                                 int N, int K, int silu_in, int silu_out, void* stream) {
+  MGLD_REQUIRE(a && w && y, "linear_small: null pointer");
+  MGLD_REQUIRE(M > 0 && M <= 16 && N > 0 && K > 0, "linear_small: M must be in 1..16");
+  MGLD_REQUIRE((K & 7) == 0 && (ldw & 7) == 0 && (lda & 3) == 0, "linear_small: K%8, ldw%8, lda%4");
+  MGLD_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, "linear_small: alignment");
+  dim3 grid(cdiv(N, 4));
+#define LS(MT)                                                                                                         \
+  hipLaunchKernelGGL((linear_small_kernel<MT>), grid, dim3(256), 0, S_(stream), a, lda, (const f16*)w, ldw, b, y, ldy, M, \
+                     N, K, silu_in, silu_out)
+  if (M <= 1) LS(1);
+  else if (M <= 2) LS(2);
+  else if (M <= 4) LS(4);
+  else if (M <= 8) LS(8);
+  else LS(16);
+#undef LS
+  return mgld_check_launch("linear_small");
+}
+
+extern "C" int mgld_timestep_embedding(const float* tvals, int t_stride, float* out, int M, int dim, void* stream) {
+  MGLD_REQUIRE(tvals && out && M > 0 && dim > 0, "timestep_embedding: bad args");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv((int64_t)M * dim, 256)), dim3(256), 0, S_(stream), tvals, t_stride,
+                     out, M, dim);
+  return mgld_check_launch("timestep_embedding");
+}
+
+extern "C" int mgld_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int cpad, int ld, void* stream) {
+  MGLD_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc: bad args");
+  MGLD_REQUIRE((cpad & 7) == 0 && cpad >= c && (ld & 7) == 0 && ld >= cpad, "nchw_to_nhwc: cpad/ld");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(egrid((int64_t)n * h * w)), dim3(256), 0, S_(stream), x, (f16*)y, n, c, h * w,
+                     cpad, ld);
+  return mgld_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int mgld_nhwc_to_nchw(const void* x, int in_f32, int ld, float* y, int n, int c, int h, int w, void* stream) {
+  MGLD_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && ld >= c, "nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(egrid((int64_t)n * c * h * w)), dim3(256), 0, S_(stream), x, in_f32, ld, y, n, c,
+                     h * w);
+  return mgld_check_launch("nhwc_to_nchw");
+}
+
+extern "C" int mgld_copy2d(const void* src, int lds_, void* dst, int ldd, int64_t rows, int cols, void* stream) {
+  MGLD_REQUIRE(src && dst && rows > 0 && cols > 0, "copy2d: bad args");
+  MGLD_REQUIRE((cols & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0, "copy2d: cols/ld % 8");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(egrid(rows * (cols >> 3))), dim3(256), 0, S_(stream), (const f16*)src, lds_, (f16*)dst,
+                     ldd, rows, cols >> 3);
+  return mgld_check_launch("copy2d");
+}
+
+extern "C" int mgld_axpby(const void* x, int ldx, void* y, int ldy, int64_t rows, int cols, float a, float b, void* stream) {
+  MGLD_REQUIRE(x && y && rows > 0 && cols > 0, "axpby: bad args");
+  MGLD_REQUIRE((cols & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0, "axpby: cols/ld % 8");
+  hipLaunchKernelGGL(axpby_kernel, dim3(egrid(rows * (cols >> 3))), dim3(256), 0, S_(stream), (const f16*)x, ldx, (f16*)y, ldy,
+                     rows, cols >> 3, a, b);
+  return mgld_check_launch("axpby");
+}
+
+extern "C" int mgld_temporal_attention(const void* q, const void* k, const void* v, int ld, void* o, int ldo, int T, int HW,
+                                       int heads, int head_dim, float scale, void* stream) {
+  MGLD_REQUIRE(q && k && v && o, "temporal_attention: null pointer");
+  MGLD_REQUIRE(T > 0 && T <= 16 && HW > 0 && heads > 0, "temporal_attention: T must be in 1..16");
+  MGLD_REQUIRE(head_dim == 64 || head_dim == 128, "temporal_attention: head_dim 64 or 128");
+  dim3 grid(cdiv((int64_t)HW * heads, 4));
+  if (head_dim == 64)
+    hipLaunchKernelGGL((temporal_attn_kernel<64>), grid, dim3(256), 0, S_(stream), (const f16*)q, (const f16*)k, (const f16*)v,
+                       ld, (f16*)o, ldo, T, HW, heads, scale);
+  else
+    hipLaunchKernelGGL((temporal_attn_kernel<128>), grid, dim3(256), 0, S_(stream), (const f16*)q, (const f16*)k,
+                       (const f16*)v, ld, (f16*)o, ldo, T, HW, heads, scale);
+  return mgld_check_launch("temporal_attention");
+}
+
+extern "C" int mgld_ddpm_step(const float* x, const float* eps, int ld_eps, const float* noise, const float* coef,
+                              const int32_t* step_idx, float* z, int n, int c, int h, int w, void* stream) {
+  MGLD_REQUIRE(x && eps && noise && coef && step_idx && z, "ddpm_step: null pointer");
+  MGLD_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && ld_eps >= c, "ddpm_step: shape");
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(egrid((int64_t)n * c * h * w)), dim3(256), 0, S_(stream), x, eps, ld_eps, noise,
+                     coef, step_idx, z, n, c, h * w);
+  return mgld_check_launch("ddpm_step");
+}
+
+extern "C" int mgld_flow_warp(const float* in, const float* flow, float* out, int n, int c, int h, int w, void* stream) {
+  MGLD_REQUIRE(in && flow && out && n > 0 && c > 0 && h > 0 && w > 0, "flow_warp: bad args");
+  hipLaunchKernelGGL(flow_warp_kernel, dim3(egrid((int64_t)n * h * w)), dim3(256), 0, S_(stream), in, flow, out, n, c, h, w);
+  return mgld_check_launch("flow_warp");
+}
+
+static int guidance_common(const float* z, const float* ff, const float* fb, void* work, int T, int c, int h, int w,
+                           float** P, float** Q, long long** G, void* stream) {
+  const int64_t n = (int64_t)T * c * h * w;
+  *G = (long long*)work;  // 8-byte aligned region first
+  *P = (float*)(*G + n);
+  *Q = *P + n;
+  hipLaunchKernelGGL(guid_warp_kernel, dim3(egrid((int64_t)T * h * w)), dim3(256), 0, S_(stream), z, ff, fb, *P, *Q, *G, T, c, h,
+                     w);
+  return MGLD_OK;
+}
+
+extern "C" int mgld_guidance(const float* z, const float* ff, const float* fb, const float* focc, const float* bocc,
+                             const float* coef, const int32_t* step_idx, float gscale, float* x_out, void* work, int T, int c,
+                             int h, int w, void* stream) {
+  MGLD_REQUIRE(z && ff && fb && focc && bocc && coef && step_idx && x_out && work, "guidance: null pointer");
+  MGLD_REQUIRE(T >= 2 && c > 0 && h > 0 && w > 0, "guidance: needs T >= 2");
+  MGLD_REQUIRE(((uintptr_t)work & 7) == 0, "guidance: work must be 8-byte aligned");
+  float *P, *Q;
+  long long* G;
+  guidance_common(z, ff, fb, work, T, c, h, w, &P, &Q, &G, stream);
+  if (T > 2)
+    hipLaunchKernelGGL(guid_scatter_kernel, dim3(egrid((int64_t)(T - 2) * h * w)), dim3(256), 0, S_(stream), z, ff, fb, focc,
+                       bocc, P, Q, G, T, c, h, w);
+  hipLaunchKernelGGL(guid_apply_kernel, dim3(egrid((int64_t)T * c * h * w)), dim3(256), 0, S_(stream), z, focc, bocc, P, Q, G,
+                     coef, step_idx, gscale, x_out, T, c, h, w);
+  return mgld_check_launch("guidance");
+}
+
+extern "C" int mgld_guidance_loss(const float* z, const float* ff, const float* fb, const float* focc, const float* bocc,
+                                  float* loss_out, void* work, int T, int c, int h, int w, void* stream) {
+  MGLD_REQUIRE(z && ff && fb && focc && bocc && loss_out && work, "guidance_loss: null pointer");
+  MGLD_REQUIRE(T >= 2 && c > 0 && h > 0 && w > 0, "guidance_loss: needs T >= 2");
+  MGLD_REQUIRE(((uintptr_t)work & 7) == 0, "guidance_loss: work must be 8-byte aligned");
+  float *P, *Q;
+  long long* G;
+  guidance_common(z, ff, fb, work, T, c, h, w, &P, &Q, &G, stream);
+  double* acc = (double*)G;  // G is zeroed by the warp kernel and unused by the loss path
+  hipLaunchKernelGGL(zero_double_kernel, dim3(1), dim3(1), 0, S_(stream), acc);
+  hipLaunchKernelGGL(guid_loss_kernel, dim3(egrid((int64_t)T * c * h * w)), dim3(256), 0, S_(stream), z, focc, bocc, P, Q, acc, T,
+                     c, h, w);
+  hipLaunchKernelGGL(guid_loss_final_kernel, dim3(1), dim3(1), 0, S_(stream), acc, loss_out, 1.0 / ((double)c * h * w));
+  return mgld_check_launch("guidance_loss");
+}
+
+extern "C" int mgld_step_advance(int32_t* step_idx, int delta, void* stream) {
+  MGLD_REQUIRE(step_idx, "step_advance: null");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, S_(stream), step_idx, delta);
+  return mgld_check_launch("step_advance");
+}
+
+extern "C" int mgld_step_timestep(const float* coef, const int32_t* step_idx, float* tvals, int n, void* stream) {
+  MGLD_REQUIRE(coef && step_idx && tvals && n > 0, "step_timestep: bad args");
+  hipLaunchKernelGGL(step_timestep_kernel, dim3(cdiv(n, 64)), dim3(64), 0, S_(stream), coef, step_idx, tvals, n);
+  return mgld_check_launch("step_timestep");
+}
+
+extern "C" int mgld_fb_consistency(const float* fwd, const float* bwd, float alpha, float beta, float* focc, float* bocc, int n,
+                                   int h, int w, void* stream) {
+  MGLD_REQUIRE(fwd && bwd && focc && bocc && n > 0 && h > 0 && w > 0, "fb_consistency: bad args");
+  hipLaunchKernelGGL(fb_consistency_kernel, dim3(egrid((int64_t)n * h * w)), dim3(256), 0, S_(stream), fwd, bwd, alpha, beta,
+                     focc, bocc, n, h, w);
+  return mgld_check_launch("fb_consistency");
+}
+
+extern "C" int mgld_resize_flow(const float* flow, float* out, int n, int h, int w, int oh, int ow, void* stream) {
+  MGLD_REQUIRE(flow && out && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "resize_flow: bad args");
+  hipLaunchKernelGGL(resize_flow_kernel, dim3(egrid((int64_t)n * 2 * oh * ow)), dim3(256), 0, S_(stream), flow, out, n, h, w, oh,
+                     ow);
+  return mgld_check_launch("resize_flow");
+}
+
+extern "C" int mgld_adain(const float* content, const float* style, float* out, int planes, int64_t hw, float eps, float* work,
+                          void* stream) {
+  MGLD_REQUIRE(content && style && out && work && planes > 0 && hw > 1, "adain: bad args");
+  MGLD_REQUIRE(((uintptr_t)work & 7) == 0, "adain: work alignment");
+  double* cst = (double*)work;
+  double* sst = cst + (int64_t)planes * 2;
+  hipLaunchKernelGGL(plane_stats_kernel, dim3(planes), dim3(256), 0, S_(stream), content, hw, cst);
+  hipLaunchKernelGGL(plane_stats_kernel, dim3(planes), dim3(256), 0, S_(stream), style, hw, sst);
+  hipLaunchKernelGGL(adain_apply_kernel, dim3(egrid((int64_t)planes * hw)), dim3(256), 0, S_(stream), content, cst, sst, out,
+                     planes, hw, eps);
+  return mgld_check_launch("adain");
+}
+
+extern "C" int mgld_wavelet_reconstruction(const float* content, const float* style, float* out, int planes, int h, int w,
+                                           float* work, void* stream) {
+  MGLD_REQUIRE(content && style && out && work && planes > 0 && h > 0 && w > 0, "wavelet: bad args");
+  const int64_t n = (int64_t)planes * h * w;
+  float* a = work;          // ping
+  float* b = work + n;      // pong
+  float* hi = work + 2 * n; // content high-frequency accumulator
+  const int g = egrid(n);
+  // content: high frequency
+  const float* cur = content;
+  for (int i = 0; i < 5; ++i) {
+    float* low = (i & 1) ? b : a;
+    hipLaunchKernelGGL(wavelet_blur_kernel, dim3(g), dim3(256), 0, S_(stream), cur, low, planes, h, w, 1 << i);
+    hipLaunchKernelGGL(wavelet_acc_kernel, dim3(g), dim3(256), 0, S_(stream), cur, low, hi, n, i == 0);
+    cur = low;
+  }
+  // style: low frequency
+  cur = style;
+  for (int i = 0; i < 5; ++i) {
+    float* low = (i & 1) ? b : a;
+    hipLaunchKernelGGL(wavelet_blur_kernel, dim3(g), dim3(256), 0, S_(stream), cur, low, planes, h, w, 1 << i);
+    cur = low;
+  }
+  hipLaunchKernelGGL(add2_kernel, dim3(g), dim3(256), 0, S_(stream), hi, cur, out, n);
+  return mgld_check_launch("wavelet_reconstruction");
+}
+
+extern "C" int mgld_crop(const float* src, float* dst, int n, int c, int H, int W, int y0, int x0, int th, int tw, void* stream) {
+  MGLD_REQUIRE(src && dst && n > 0 && c > 0, "crop: bad args");
+  MGLD_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + th <= H && x0 + tw <= W && th > 0 && tw > 0, "crop: window out of range");
+  hipLaunchKernelGGL(crop_kernel, dim3(egrid((int64_t)n * c * th * tw)), dim3(256), 0, S_(stream), src, dst, n * c, H, W, y0, x0,
+                     th, tw);
+  return mgld_check_launch("crop");
+}
+
+extern "C" int mgld_tile_accumulate(const float* tile, const float* wgt, float* acc, float* cnt, int n, int c, int H, int W,
+                                    int y0, int x0, int th, int tw, void* stream) {
+  MGLD_REQUIRE(tile && wgt && acc && cnt && n > 0 && c > 0, "tile_accumulate: bad args");
+  MGLD_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + th <= H && x0 + tw <= W && th > 0 && tw > 0, "tile_accumulate: window out of range");
+  hipLaunchKernelGGL(tile_acc_kernel, dim3(egrid((int64_t)n * c * th * tw)), dim3(256), 0, S_(stream), tile, wgt, acc, cnt, n * c,
+                     H, W, y0, x0, th, tw);
+  return mgld_check_launch("tile_accumulate");
+}
+
+extern "C" int mgld_tile_normalize(const float* acc, const float* cnt, float* out, int64_t numel, void* stream) {
+  MGLD_REQUIRE(acc && cnt && out && numel > 0, "tile_normalize: bad args");
+  hipLaunchKernelGGL(tile_norm_kernel, dim3(egrid(numel)), dim3(256), 0, S_(stream), acc, cnt, out, numel);
+  return mgld_check_launch("tile_normalize");
+}

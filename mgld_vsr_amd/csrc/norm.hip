@@ -1,0 +1,247 @@
+// norm.hip — GroupNorm(32) / SPADE modulation / LayerNorm on token-major (NHWC) fp16 activations.
+// HBM-bound kernels (SURVEY.md §2.2 K2,K3): 16-byte vector loads along channels, fp32 partial sums per channel,
+// fp64 combine, statistics kept in fp32 exactly as the reference does (diffusionmodules/util.py:214-216).
+#include "common.h"
+
+namespace {
+
+// ---- stage 1: per-(frame, chunk) per-channel partial sums -------------------------------------------------
+// grid (chunks, frames), 256 threads.  partials layout: [frame][chunk][C][2] (sum, sumsq).
+__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x, int rows, int C, int ld,
+                                                         int rows_per_chunk, float* __restrict__ partials) {
+  extern __shared__ float sred[];  // [rpi][C][2] when rpi > 1
+  const int NV = C >> 3;
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, frame = blockIdx.y, chunks = gridDim.x;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  const f16* xf = x + (int64_t)frame * rows * ld;
+  float* pout = partials + ((int64_t)(frame * chunks + chunk) * C) * 2;
+
+  if (NV >= 256) {
+    // wide rows: each thread owns vector columns tid, tid+256, ... ; one row at a time
+    for (int v = tid; v < NV; v += 256) {
+      float s[8], q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+      for (int r = r0; r < r1; ++r) {
+        const f16x8 d = *(const f16x8*)(xf + (int64_t)r * ld + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)d[j]; s[j] += f; q[j] += f * f; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pout[(v * 8 + j) * 2] = s[j]; pout[(v * 8 + j) * 2 + 1] = q[j]; }
+    }
+    return;
+  }
+  const int rpi = 256 / NV;  // rows handled per iteration
+  const int rr = tid / NV, v = tid - rr * NV;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (rr < rpi) {
+    for (int r = r0 + rr; r < r1; r += rpi) {
+      const f16x8 d = *(const f16x8*)(xf + (int64_t)r * ld + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)d[j]; s[j] += f; q[j] += f * f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sred[((rr * C) + v * 8 + j) * 2] = s[j];
+      sred[((rr * C) + v * 8 + j) * 2 + 1] = q[j];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float ss = 0.f, qq = 0.f;
+    for (int r = 0; r < rpi; ++r) { ss += sred[(r * C + c) * 2]; qq += sred[(r * C + c) * 2 + 1]; }
+    pout[c * 2] = ss; pout[c * 2 + 1] = qq;
+  }
+}
+
+// ---- stage 2: combine in fp64 -> (mean, rstd) per (frame, group).  grid (groups, frames), 64 threads.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partials, int chunks, int C,
+                                                        int groups, int rows, float eps, float* __restrict__ stats) {
+  const int g = blockIdx.x, frame = blockIdx.y;
+  const int cg = C / groups;
+  const float* p = partials + (int64_t)frame * chunks * C * 2;
+  double s = 0.0, q = 0.0;
+  const int items = chunks * cg;
+  for (int i = threadIdx.x; i < items; i += 64) {
+    const int ch = i / cg, cc = i - ch * cg;
+    const float* e = p + ((int64_t)ch * C + g * cg + cc) * 2;
+    s += (double)e[0]; q += (double)e[1];
+  }
+  s = wave_sum_d(s); q = wave_sum_d(q);
+  if (threadIdx.x == 0) {
+    const double n = (double)rows * cg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(frame * groups + g) * 2] = (float)mean;
+    stats[(frame * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// ---- apply: y = [silu]((x-mean)*rstd*gamma+beta) ----------------------------------------------------------------
+template <bool SPADE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int ldx, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const f16* __restrict__ gb, int ldgb, const f16* __restrict__ skip,
+                                                       int ldskip, f16* __restrict__ y, int ldy, int64_t total_rows,
+                                                       int rows_per_frame, int C, int groups, int silu) {
+  const int NV = C >> 3;
+  const int cg = C / groups;
+  const int64_t total = total_rows * NV;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / NV;
+    const int v = (int)(idx - row * NV);
+    const int frame = (int)(row / rows_per_frame);
+    const int c0 = v * 8;
+    const f16x8 d = *(const f16x8*)(x + row * ldx + c0);
+    f16x8 gm, bt, sk;
+    if (SPADE) {
+      gm = *(const f16x8*)(gb + row * ldgb + c0);
+      bt = *(const f16x8*)(gb + row * ldgb + C + c0);
+      sk = *(const f16x8*)(skip + row * ldskip + c0);
+    }
+    const float* st = stats + (int64_t)frame * groups * 2;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      const int g = c / cg;
+      float f = ((float)d[j] - st[g * 2]) * st[g * 2 + 1] * gamma[c] + beta[c];
+      if (SPADE) {
+        f = f * (1.f + (float)gm[j]) + (float)bt[j] + (float)sk[j];
+      } else if (silu) {
+        f = silu_f(f);
+      }
+      o[j] = (f16)f;
+    }
+    *(f16x8*)(y + row * ldy + c0) = o;
+  }
+}
+
+// ---- LayerNorm: one wave per token row ---------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, f16* __restrict__ y, int ldy,
+                                                        int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int NV = C >> 3;
+  f16x8 d[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < NV) {
+      d[i] = *(const f16x8*)(x + (int64_t)row * ldx + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)d[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < NV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float t = (float)d[i][j] - mean; q += t * t; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < NV) {
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        o[j] = (f16)(((float)d[i][j] - mean) * rstd * gamma[c] + beta[c]);
+      }
+      *(f16x8*)(y + (int64_t)row * ldy + v * 8) = o;
+    }
+  }
+}
+
+inline int rows_per_chunk_for(int rows) { return rows <= 64 ? rows : (cdiv(rows, 256) > 64 ? cdiv(rows, 256) : 64); }
+
+}  // namespace
+
+extern "C" int mgld_gn_chunks(int rows_per_frame) {
+  if (rows_per_frame <= 0) return 0;
+  return cdiv(rows_per_frame, rows_per_chunk_for(rows_per_frame));
+}
+
+extern "C" int mgld_gn_stats(const void* x, int frames, int rows, int C, int ld, int groups, float eps,
+                             float* partials, float* stats_out, void* stream) {
+  MGLD_REQUIRE(x && partials && stats_out, "gn_stats: null pointer");
+  MGLD_REQUIRE(frames > 0 && rows > 0 && C > 0 && groups > 0, "gn_stats: empty");
+  MGLD_REQUIRE((C & 7) == 0 && (ld & 7) == 0 && C % groups == 0, "gn_stats: C%8, ld%8, C%groups");
+  MGLD_REQUIRE(((uintptr_t)x & 15) == 0, "gn_stats: alignment");
+  const int rpc = rows_per_chunk_for(rows);
+  const int chunks = cdiv(rows, rpc);
+  const int NV = C >> 3;
+  const int rpi = NV >= 256 ? 1 : 256 / NV;
+  const size_t shm = NV >= 256 ? 0 : (size_t)rpi * C * 2 * sizeof(float);
+  MGLD_REQUIRE(shm <= 64 * 1024, "gn_stats: LDS budget");
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, frames), dim3(256), shm, (hipStream_t)stream, (const f16*)x, rows, C,
+                     ld, rpc, partials);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, frames), dim3(64), 0, (hipStream_t)stream, partials, chunks, C,
+                     groups, rows, eps, stats_out);
+  return mgld_check_launch("gn_stats");
+}
+
+static int elem_grid(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int mgld_gn_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta, void* y,
+                             int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
+  MGLD_REQUIRE(x && stats && gamma && beta && y, "gn_apply: null pointer");
+  MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C % groups == 0, "gn_apply: alignment");
+  const int64_t total_rows = (int64_t)frames * rows;
+  hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(elem_grid(total_rows * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)x, ldx, stats, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, total_rows, rows, C,
+                     groups, silu);
+  return mgld_check_launch("gn_apply");
+}
+
+extern "C" int mgld_spade_apply(const void* h, int ldh, const float* stats, const float* gamma, const float* beta,
+                                const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy, int frames,
+                                int rows, int C, int groups, void* stream) {
+  MGLD_REQUIRE(h && stats && gamma && beta && gb && skip && y, "spade_apply: null pointer");
+  MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0,
+               "spade_apply: alignment");
+  const int64_t total_rows = (int64_t)frames * rows;
+  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(elem_grid(total_rows * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)h, ldh, stats, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy,
+                     total_rows, rows, C, groups, 0);
+  return mgld_check_launch("spade_apply");
+}
+
+extern "C" int mgld_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int rows,
+                              int C, float eps, void* stream) {
+  MGLD_REQUIRE(x && gamma && beta && y, "layernorm: null pointer");
+  MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C <= 2048 && rows > 0, "layernorm: shape");
+  const int NV = C >> 3;
+  dim3 grid(cdiv(rows, 4));
+  if (NV <= 64)
+    hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, gamma, beta,
+                       (f16*)y, ldy, rows, C, eps);
+  else if (NV <= 128)
+    hipLaunchKernelGGL((layernorm_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, gamma, beta,
+                       (f16*)y, ldy, rows, C, eps);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, gamma, beta,
+                       (f16*)y, ldy, rows, C, eps);
+  return mgld_check_launch("layernorm");
+}

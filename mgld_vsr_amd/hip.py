@@ -1,0 +1,387 @@
+"""ctypes binding of libmgld_hip.so (include/mgld_hip.h) + thin tensor-level wrappers.
+
+PyTorch is used here only as plumbing: device memory (torch tensors own the buffers), the current HIP stream,
+and dtype bookkeeping.  Every compute call goes through the C ABI; if the library is missing the import of
+this module's `lib()` fails loudly — there is no eager/CPU fallback on the product path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmgld_hip.so")
+_lib = None
+
+MODE_LINEAR, MODE_CONV3X3, MODE_TCONV3 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
+
+
+class MgldIGemm(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
+        ("bias", C.c_void_p), ("bias_m", C.c_void_p), ("rowvec", C.c_void_p), ("R", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("ld_rowvec", C.c_int32),
+        ("mode", C.c_int32), ("Cin", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("up2", C.c_int32),
+        ("T", C.c_int32), ("HW", C.c_int32), ("rows_per_frame", C.c_int32),
+        ("act", C.c_int32), ("out_f32", C.c_int32),
+        ("alpha", C.c_float), ("beta", C.c_float),
+        ("batch", C.c_int32),
+        ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
+    ]
+
+
+class MgldAttn(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nkv", C.c_int32), ("head_dim", C.c_int32),
+        ("q_sb", C.c_int64), ("q_si", C.c_int64), ("q_sh", C.c_int64),
+        ("k_sb", C.c_int64), ("k_si", C.c_int64), ("k_sh", C.c_int64),
+        ("vt_sb", C.c_int64), ("vt_sh", C.c_int64), ("vt_sd", C.c_int64),
+        ("o_sb", C.c_int64), ("o_si", C.c_int64), ("o_sh", C.c_int64),
+        ("scale", C.c_float),
+    ]
+
+
+# every symbol include/mgld_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "mgld_version", "mgld_last_error", "mgld_device_info",
+    "mgld_graph_begin", "mgld_graph_end", "mgld_graph_launch", "mgld_graph_destroy",
+    "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
+    "mgld_igemm", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_layernorm",
+    "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows",
+    "mgld_linear_small", "mgld_timestep_embedding",
+    "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
+    "mgld_ddpm_step", "mgld_flow_warp", "mgld_guidance", "mgld_guidance_loss", "mgld_step_advance",
+    "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
+    "mgld_adain", "mgld_wavelet_reconstruction",
+    "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize",
+]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load libmgld_hip.so; raise if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: the MGLD-VSR hot path has no CPU/eager fallback. "
+                "Build it with `python -m mgld_vsr_amd.build` (hipcc --offload-arch=gfx950).")
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.mgld_last_error.restype = C.c_char_p
+        _lib.mgld_gn_chunks.restype = C.c_int
+    return _lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        msg = lib().mgld_last_error().decode(errors="replace")
+        raise RuntimeError(f"libmgld_hip {what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libmgld_hip ops need device tensors (no CPU fallback on the product path)")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# tensor-level wrappers.  "Token matrices" are 2-D views [rows, C] with stride (ld, 1) — fp16 unless noted.
+# --------------------------------------------------------------------------------------------------------------
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, f"expected a [rows, C] view with unit channel stride, got {t.shape} {t.stride()}"
+    return t.stride(0)
+
+
+def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None,
+          act=ACT_NONE, alpha=1.0, beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0,
+          M=None, N=None, K=None):
+    """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h)."""
+    _req_cuda(a, w, out)
+    p = MgldIGemm()
+    p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.bias_m = bias_m.data_ptr() if bias_m is not None else None
+    p.rowvec = rowvec.data_ptr() if rowvec is not None else None
+    p.R = resid.data_ptr() if resid is not None else None
+    p.M = M if M is not None else out.shape[0]
+    p.N = N if N is not None else w.shape[0]
+    p.K = K if K is not None else w.shape[1]
+    p.lda, p.ldw, p.ldc = _ld(a), _ld(w), _ld(out)
+    p.ldr = _ld(resid) if resid is not None else 0
+    p.ld_rowvec = _ld(rowvec) if rowvec is not None else 0
+    p.mode = mode
+    p.rows_per_frame = rows_per_frame
+    p.act = act
+    p.out_f32 = 1 if out.dtype == torch.float32 else 0
+    p.alpha, p.beta = alpha, beta
+    p.batch = batch
+    p.strideA, p.strideW, p.strideC, p.strideR = strideA, strideW, strideC, strideR
+    if mode == MODE_CONV3X3:
+        p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = conv
+    elif mode == MODE_TCONV3:
+        p.Cin, p.T, p.HW = tconv
+    _chk(lib().mgld_igemm(C.byref(p), stream_ptr()), "igemm")
+    return out
+
+
+def gn_chunks(rows):
+    return lib().mgld_gn_chunks(int(rows))
+
+
+def gn_stats(x, frames, rows, groups, eps, partials, stats):
+    _req_cuda(x, partials, stats)
+    _chk(lib().mgld_gn_stats(_p(x), frames, rows, x.shape[1], _ld(x), groups, C.c_float(eps), _p(partials), _p(stats),
+                             stream_ptr()), "gn_stats")
+    return stats
+
+
+def gn_apply(x, stats, gamma, beta, y, frames, rows, groups, silu):
+    _req_cuda(x, stats, gamma, beta, y)
+    _chk(lib().mgld_gn_apply(_p(x), _ld(x), _p(stats), _p(gamma), _p(beta), _p(y), _ld(y), frames, rows, x.shape[1], groups,
+                             1 if silu else 0, stream_ptr()), "gn_apply")
+    return y
+
+
+def spade_apply(h, stats, gamma, beta, gb, skip, y, frames, rows, groups):
+    _req_cuda(h, stats, gamma, beta, gb, skip, y)
+    _chk(lib().mgld_spade_apply(_p(h), _ld(h), _p(stats), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip), _ld(skip), _p(y),
+                                _ld(y), frames, rows, h.shape[1], groups, stream_ptr()), "spade_apply")
+    return y
+
+
+def layernorm(x, gamma, beta, y, eps=1e-5):
+    _req_cuda(x, gamma, beta, y)
+    _chk(lib().mgld_layernorm(_p(x), _ld(x), _p(gamma), _p(beta), _p(y), _ld(y), x.shape[0], x.shape[1], C.c_float(eps),
+                              stream_ptr()), "layernorm")
+    return y
+
+
+def attention(q, k, vt, o, *, batch, heads, Nq, Nkv, head_dim, q_strides, k_strides, vt_strides, o_strides, scale):
+    _req_cuda(q, k, vt, o)
+    p = MgldAttn()
+    p.Q, p.K, p.Vt, p.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
+    p.batch, p.heads, p.Nq, p.Nkv, p.head_dim = batch, heads, Nq, Nkv, head_dim
+    p.q_sb, p.q_si, p.q_sh = q_strides
+    p.k_sb, p.k_si, p.k_sh = k_strides
+    p.vt_sb, p.vt_sh, p.vt_sd = vt_strides
+    p.o_sb, p.o_si, p.o_sh = o_strides
+    p.scale = scale
+    _chk(lib().mgld_attention(C.byref(p), stream_ptr()), "attention")
+    return o
+
+
+def temporal_attention(q, k, v, o, T, HW, heads, head_dim, scale):
+    _req_cuda(q, k, v, o)
+    assert _ld(q) == _ld(k) == _ld(v)
+    _chk(lib().mgld_temporal_attention(_p(q), _p(k), _p(v), _ld(q), _p(o), _ld(o), T, HW, heads, head_dim, C.c_float(scale),
+                                       stream_ptr()), "temporal_attention")
+    return o
+
+
+def softmax_rows(S, P, rows, cols):
+    _req_cuda(S, P)
+    _chk(lib().mgld_softmax_rows(_p(S), C.c_int64(S.stride(0)), _p(P), C.c_int64(P.stride(0)), C.c_int64(rows), cols,
+                                 stream_ptr()), "softmax_rows")
+    return P
+
+
+def linear_small(a, w, b, y, silu_in=False, silu_out=False):
+    _req_cuda(a, w, y)
+    _chk(lib().mgld_linear_small(_p(a), _ld(a), _p(w), _ld(w), _p(b), _p(y), _ld(y), a.shape[0], w.shape[0], w.shape[1],
+                                 int(silu_in), int(silu_out), stream_ptr()), "linear_small")
+    return y
+
+
+def timestep_embedding(tvals, out, t_stride=1):
+    _req_cuda(tvals, out)
+    _chk(lib().mgld_timestep_embedding(_p(tvals), t_stride, _p(out), out.shape[0], out.shape[1], stream_ptr()),
+         "timestep_embedding")
+    return out
+
+
+def nchw_to_nhwc(x, y, cpad):
+    """x fp32 [n,c,h,w] -> y fp16 [n*h*w, ld] (channels c..cpad-1 zero)."""
+    _req_cuda(x, y)
+    n, c, h, w = x.shape
+    _chk(lib().mgld_nchw_to_nhwc(_p(x), _p(y), n, c, h, w, cpad, _ld(y), stream_ptr()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, y):
+    """x fp16/fp32 [n*h*w, ld] -> y fp32 [n,c,h,w]."""
+    _req_cuda(x, y)
+    n, c, h, w = y.shape
+    _chk(lib().mgld_nhwc_to_nchw(_p(x), 1 if x.dtype == torch.float32 else 0, _ld(x), _p(y), n, c, h, w, stream_ptr()),
+         "nhwc_to_nchw")
+    return y
+
+
+def copy2d(src, dst):
+    _req_cuda(src, dst)
+    _chk(lib().mgld_copy2d(_p(src), _ld(src), _p(dst), _ld(dst), C.c_int64(src.shape[0]), src.shape[1], stream_ptr()), "copy2d")
+    return dst
+
+
+def axpby(x, y, a, b):
+    _req_cuda(x, y)
+    _chk(lib().mgld_axpby(_p(x), _ld(x), _p(y), _ld(y), C.c_int64(x.shape[0]), x.shape[1], C.c_float(a), C.c_float(b),
+                          stream_ptr()), "axpby")
+    return y
+
+
+def ddpm_step(x, eps, noise, coef, step_idx, z):
+    _req_cuda(x, eps, noise, coef, step_idx, z)
+    n, c, h, w = x.shape
+    _chk(lib().mgld_ddpm_step(_p(x), _p(eps), _ld(eps), _p(noise), _p(coef), _p(step_idx), _p(z), n, c, h, w, stream_ptr()),
+         "ddpm_step")
+    return z
+
+
+def flow_warp(x, flow, out):
+    """x [n,c,h,w] fp32, flow [n,2,h,w] fp32 (dx,dy)."""
+    _req_cuda(x, flow, out)
+    n, c, h, w = x.shape
+    _chk(lib().mgld_flow_warp(_p(x), _p(flow), _p(out), n, c, h, w, stream_ptr()), "flow_warp")
+    return out
+
+
+def guidance_work_bytes(T, c, h, w):
+    return T * c * h * w * (8 + 4 + 4)
+
+
+def guidance(z, ff, fb, focc, bocc, coef, step_idx, gscale, x_out, work):
+    _req_cuda(z, ff, fb, focc, bocc, coef, step_idx, x_out, work)
+    T, c, h, w = z.shape
+    _chk(lib().mgld_guidance(_p(z), _p(ff), _p(fb), _p(focc), _p(bocc), _p(coef), _p(step_idx), C.c_float(gscale), _p(x_out),
+                             _p(work), T, c, h, w, stream_ptr()), "guidance")
+    return x_out
+
+
+def guidance_loss(z, ff, fb, focc, bocc, loss_out, work):
+    _req_cuda(z, ff, fb, focc, bocc, loss_out, work)
+    T, c, h, w = z.shape
+    _chk(lib().mgld_guidance_loss(_p(z), _p(ff), _p(fb), _p(focc), _p(bocc), _p(loss_out), _p(work), T, c, h, w, stream_ptr()),
+         "guidance_loss")
+    return loss_out
+
+
+def step_advance(step_idx, delta):
+    _chk(lib().mgld_step_advance(_p(step_idx), delta, stream_ptr()), "step_advance")
+
+
+def step_timestep(coef, step_idx, tvals):
+    _chk(lib().mgld_step_timestep(_p(coef), _p(step_idx), _p(tvals), tvals.numel(), stream_ptr()), "step_timestep")
+    return tvals
+
+
+def fb_consistency(fwd, bwd, alpha, beta, focc, bocc):
+    _req_cuda(fwd, bwd, focc, bocc)
+    n, _, h, w = fwd.shape
+    _chk(lib().mgld_fb_consistency(_p(fwd), _p(bwd), C.c_float(alpha), C.c_float(beta), _p(focc), _p(bocc), n, h, w,
+                                   stream_ptr()), "fb_consistency")
+    return focc, bocc
+
+
+def resize_flow(flow, out):
+    _req_cuda(flow, out)
+    n, _, h, w = flow.shape
+    _chk(lib().mgld_resize_flow(_p(flow), _p(out), n, h, w, out.shape[2], out.shape[3], stream_ptr()), "resize_flow")
+    return out
+
+
+def adain(content, style, out, work):
+    _req_cuda(content, style, out, work)
+    n, c, h, w = content.shape
+    _chk(lib().mgld_adain(_p(content), _p(style), _p(out), n * c, C.c_int64(h * w), C.c_float(1e-5), _p(work), stream_ptr()),
+         "adain")
+    return out
+
+
+def wavelet_reconstruction(content, style, out, work):
+    _req_cuda(content, style, out, work)
+    n, c, h, w = content.shape
+    _chk(lib().mgld_wavelet_reconstruction(_p(content), _p(style), _p(out), n * c, h, w, _p(work), stream_ptr()), "wavelet")
+    return out
+
+
+def crop(src, dst, y0, x0):
+    _req_cuda(src, dst)
+    n, c, H, W = src.shape
+    _chk(lib().mgld_crop(_p(src), _p(dst), n, c, H, W, y0, x0, dst.shape[2], dst.shape[3], stream_ptr()), "crop")
+    return dst
+
+
+def tile_accumulate(tile, wgt, acc, cnt, y0, x0):
+    _req_cuda(tile, wgt, acc, cnt)
+    n, c, H, W = acc.shape
+    _chk(lib().mgld_tile_accumulate(_p(tile), _p(wgt), _p(acc), _p(cnt), n, c, H, W, y0, x0, tile.shape[2], tile.shape[3],
+                                    stream_ptr()), "tile_accumulate")
+
+
+def tile_normalize(acc, cnt, out):
+    _req_cuda(acc, cnt, out)
+    _chk(lib().mgld_tile_normalize(_p(acc), _p(cnt), _p(out), C.c_int64(acc.numel()), stream_ptr()), "tile_normalize")
+    return out
+
+
+# ---- graph / events ---------------------------------------------------------------------------------------------
+class Graph:
+    """hipGraph captured from launches enqueued on the current torch stream between begin() and end()."""
+
+    def __init__(self):
+        self.exec = C.c_void_p(0)
+
+    def begin(self):
+        _chk(lib().mgld_graph_begin(stream_ptr()), "graph_begin")
+
+    def end(self):
+        _chk(lib().mgld_graph_end(stream_ptr(), C.byref(self.exec)), "graph_end")
+
+    def launch(self):
+        _chk(lib().mgld_graph_launch(self.exec, stream_ptr()), "graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec and self.exec.value:
+                lib().mgld_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.ev = C.c_void_p(0)
+        _chk(lib().mgld_event_create(C.byref(self.ev)), "event_create")
+
+    def record(self):
+        _chk(lib().mgld_event_record(self.ev, stream_ptr()), "event_record")
+
+    def sync(self):
+        _chk(lib().mgld_event_sync(self.ev), "event_sync")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        _chk(lib().mgld_event_elapsed_ms(self.ev, stop.ev, C.byref(ms)), "event_elapsed")
+        return ms.value
+
+
+def device_info(device=0):
+    out = (C.c_int64 * 4)()
+    _chk(lib().mgld_device_info(device, out), "device_info")
+    return {"cus": out[0], "lds_per_cu": out[1], "clock_khz": out[2], "gfx": out[3]}

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The ctypes binding with the library loaded; GPU tests call the product path through the C ABI only."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from mgld_vsr_amd import hip as _hip
+    _hip.lib()
+    return _hip

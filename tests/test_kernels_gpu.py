@@ -1,0 +1,321 @@
+"""Per-kernel parity tests: every libmgld_hip entry point (called through the C ABI) vs a plain fp32 torch-CPU
+statement of the same op.  Tolerances are relative-L2; fp16-operand kernels are compared against the fp32 result of
+the SAME fp16-rounded operands, so the tolerance only has to cover fp32-accumulation order + the fp16 output rounding.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def h16(t):
+    return t.half()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# igemm
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (100, 72, 40), (4096, 1280, 320), (512, 1280, 1280),
+                                   (77, 640, 1024), (33, 4, 320), (300, 32, 544), (64, 64, 8)])
+def test_igemm_linear(hip, M, N, K):
+    a, w, b = h16(rnd(M, K, seed=1)), h16(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
+    ref = a.float() @ w.float().t() + b
+    out = torch.empty(M, N, dtype=torch.half, device=DEV)
+    hip.igemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+
+
+def test_igemm_transpose_detect(hip):
+    # A = I-like with asymmetric W catches row/col swaps of the MFMA output mapping
+    M = N = K = 64
+    a = torch.eye(M, K).half()
+    w = (torch.arange(N * K).reshape(N, K).float() / (N * K)).half()
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    hip.igemm(a.to(DEV), w.to(DEV), out)
+    assert torch.allclose(out.cpu(), w.float().t(), atol=1e-6)
+
+
+def test_igemm_strided_epilogues(hip):
+    # lda/ldc/ldr strides (concat-by-slices), residual with alpha/beta, SiLU, fp32 out, bias_m
+    M, N, K = 200, 96, 128
+    abig = h16(rnd(M, K + 64, seed=4)).to(DEV)
+    a = abig[:, 32:32 + K]
+    w = h16(rnd(N, K, seed=5, scale=K ** -0.5)).to(DEV)
+    rbig = h16(rnd(M, N + 16, seed=6)).to(DEV)
+    r = rbig[:, 8:8 + N]
+    bm = rnd(M, seed=7).to(DEV)
+    obig = torch.zeros(M, N + 40, dtype=torch.half, device=DEV)
+    out = obig[:, 16:16 + N]
+    hip.igemm(a, w, out, bias_m=bm, resid=r, act=hip.ACT_SILU, alpha=0.3, beta=0.7)
+    ref = 0.3 * F.silu(a.cpu().float() @ w.cpu().float().t() + bm.cpu()[:, None]) + 0.7 * r.cpu().float()
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+    assert float(obig[:, :16].abs().max()) == 0 and float(obig[:, 16 + N:].abs().max()) == 0
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    hip.igemm(a, w, o32, act=hip.ACT_RELU)
+    assert rel_l2(o32.cpu(), F.relu(a.cpu().float() @ w.cpu().float().t())) < 1e-5
+
+
+def test_igemm_batched_nt(hip):
+    # V^T projection: per-frame out[C, tokens] = Wv[C, Cin] @ x_f[tokens, Cin]^T  (A shared, W strided)
+    Fr, tokens, Cin, Cc = 3, 200, 64, 128
+    x = h16(rnd(Fr * tokens, Cin, seed=8)).to(DEV)
+    wv = h16(rnd(Cc, Cin, seed=9, scale=Cin ** -0.5)).to(DEV)
+    tp = 208
+    out = torch.zeros(Fr * Cc, tp, dtype=torch.half, device=DEV)
+    hip.igemm(wv, x, out, M=Cc, N=tokens, K=Cin, batch=Fr, strideA=0, strideW=tokens * Cin, strideC=Cc * tp)
+    ref = torch.einsum("ck,ftk->fct", wv.cpu().float(), x.cpu().float().reshape(Fr, tokens, Cin))
+    assert rel_l2(out.cpu().float().reshape(Fr, Cc, tp)[:, :, :tokens], ref) < 1e-3
+
+
+def test_igemm_geglu(hip):
+    M, dim, inner = 300, 64, 256
+    a = h16(rnd(M, dim, seed=10)).to(DEV)
+    w = h16(rnd(2 * inner, dim, seed=11, scale=dim ** -0.5))
+    b = rnd(2 * inner, seed=12)
+    from mgld_vsr_amd.engine import pack_geglu
+    wp, bp = pack_geglu(w, b)
+    out = torch.empty(M, inner, dtype=torch.half, device=DEV)
+    hip.igemm(a, wp.to(DEV), out, bias=bp.to(DEV), act=hip.ACT_GEGLU)
+    y = a.cpu().float() @ w.float().t() + b
+    ref = y[:, :inner] * F.gelu(y[:, inner:])
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+
+
+def _conv_ref(x_nchw, w, b, stride, pad):
+    return F.conv2d(F.pad(x_nchw, pad), w, b, stride=stride)
+
+
+def _to_tok(x_nchw):
+    n, c, h, w = x_nchw.shape
+    return x_nchw.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
+
+
+def _from_tok(t, n, h, w):
+    return t.reshape(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,stride,pads,up2", [
+    (2, 32, 64, 16, 16, 1, (1, 1, 1, 1), 0),
+    (1, 8, 320, 12, 20, 1, (1, 1, 1, 1), 0),
+    (2, 64, 64, 16, 16, 2, (1, 1, 1, 1), 0),     # UNet Downsample: stride 2, pad 1
+    (2, 64, 32, 16, 16, 2, (0, 1, 0, 1), 0),     # VAE Downsample: pad (0,1,0,1), stride 2
+    (2, 64, 48, 8, 8, 1, (1, 1, 1, 1), 1),       # nearest-2x upsample folded into the gather
+    (1, 544, 32, 10, 10, 1, (1, 1, 1, 1), 0),    # RDB growth conv
+    (3, 320, 4, 8, 8, 1, (1, 1, 1, 1), 0),       # out conv
+])
+def test_igemm_conv3x3(hip, n, cin, cout, h, w, stride, pads, up2):
+    x = h16(rnd(n, cin, h, w, seed=20))
+    wt = h16(rnd(cout, cin, 3, 3, seed=21, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=22)
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if up2 else x.float()
+    ref = _conv_ref(xin, wt.float(), b, stride, pads)
+    ho, wo = ref.shape[2], ref.shape[3]
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    out = torch.empty(n * ho * wo, cout, dtype=torch.half, device=DEV)
+    hip.igemm(_to_tok(x).to(DEV), wk, out, mode=hip.MODE_CONV3X3, bias=b.to(DEV),
+              conv=(cin, h, w, ho, wo, stride, pads[2], pads[0], up2))
+    assert rel_l2(_from_tok(out.cpu().float(), n, ho, wo), ref) < 1e-3
+
+
+def test_igemm_conv_rowvec(hip):
+    n, cin, cout, h, w = 3, 32, 64, 8, 8
+    x = h16(rnd(n, cin, h, w, seed=23))
+    wt = h16(rnd(cout, cin, 3, 3, seed=24, scale=(9 * cin) ** -0.5))
+    b, emb = rnd(cout, seed=25), rnd(n, cout, seed=26)
+    ref = F.conv2d(x.float(), wt.float(), b, padding=1) + emb[:, :, None, None]
+    out = torch.empty(n * h * w, cout, dtype=torch.half, device=DEV)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    hip.igemm(_to_tok(x).to(DEV), wk, out, mode=hip.MODE_CONV3X3, bias=b.to(DEV), rowvec=emb.to(DEV), rows_per_frame=h * w,
+              conv=(cin, h, w, h, w, 1, 1, 1, 0))
+    assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
+
+
+@pytest.mark.parametrize("clips,T", [(1, 5), (2, 3), (1, 1)])
+def test_igemm_tconv(hip, clips, T):
+    c, h, w = 64, 6, 6
+    x = h16(rnd(clips * T, c, h, w, seed=27))
+    wt = h16(rnd(c, c, 3, 1, 1, seed=28, scale=(3 * c) ** -0.5))
+    b = rnd(c, seed=29)
+    alpha = 0.37
+    x5 = x.float().reshape(clips, T, c, h, w).permute(0, 2, 1, 3, 4)
+    res = F.conv3d(x5, wt.float(), b, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(clips * T, c, h, w)
+    ref = alpha * res + (1 - alpha) * x.float()
+    xt = _to_tok(x).to(DEV)
+    wk = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, 3 * c).contiguous().to(DEV)
+    out = torch.empty_like(xt)
+    hip.igemm(xt, wk, out, mode=hip.MODE_TCONV3, bias=b.to(DEV), resid=xt, alpha=alpha, beta=1 - alpha, tconv=(c, T, h * w))
+    assert rel_l2(_from_tok(out.cpu().float(), clips * T, h, w), ref) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("frames,C,h,w,eps", [(2, 320, 16, 16, 1e-5), (1, 1920, 8, 8, 1e-5), (3, 128, 24, 24, 1e-6),
+                                              (1, 2560, 8, 8, 1e-5), (2, 64, 4, 4, 1e-6)])
+def test_groupnorm(hip, frames, C, h, w, eps):
+    x = h16(rnd(frames, C, h, w, seed=30) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=31), 0.1 * rnd(C, seed=32)
+    ld = C + 24
+    xt = torch.zeros(frames * h * w, ld, dtype=torch.half, device=DEV)
+    xt[:, 8:8 + C] = _to_tok(x).to(DEV)
+    xv = xt[:, 8:8 + C]
+    rows = h * w
+    partials = torch.empty(frames * hip.gn_chunks(rows) * C * 2, dtype=torch.float32, device=DEV)
+    stats = torch.empty(frames, 32, 2, dtype=torch.float32, device=DEV)
+    hip.gn_stats(xv, frames, rows, 32, eps, partials, stats)
+    y = torch.empty(frames * rows, C, dtype=torch.half, device=DEV)
+    hip.gn_apply(xv, stats, gamma.to(DEV), beta.to(DEV), y, frames, rows, 32, True)
+    ref = F.silu(F.group_norm(x.float(), 32, gamma, beta, eps))
+    xg = x.float().reshape(frames, 32, -1)
+    assert torch.allclose(stats[:, :, 0].cpu(), xg.mean(-1), atol=2e-5)
+    assert rel_l2(stats[:, :, 1].cpu(), 1 / torch.sqrt(xg.var(-1, unbiased=False) + eps)) < 1e-5
+    assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
+
+
+def test_spade_apply(hip):
+    frames, C, h, w = 2, 320, 8, 8
+    rows = h * w
+    hh, skip = h16(rnd(frames * rows, C, seed=33)), h16(rnd(frames * rows, C, seed=34))
+    gb = h16(rnd(frames * rows, 2 * C, seed=35, scale=0.5))
+    gamma, beta = 1 + 0.1 * rnd(C, seed=36), 0.1 * rnd(C, seed=37)
+    partials = torch.empty(frames * hip.gn_chunks(rows) * C * 2, dtype=torch.float32, device=DEV)
+    stats = torch.empty(frames, 32, 2, dtype=torch.float32, device=DEV)
+    hd = hh.to(DEV)
+    hip.gn_stats(hd, frames, rows, 32, 1e-5, partials, stats)
+    y = torch.empty(frames * rows, C, dtype=torch.half, device=DEV)
+    hip.spade_apply(hd, stats, gamma.to(DEV), beta.to(DEV), gb.to(DEV), skip.to(DEV), y, frames, rows, 32)
+    hn = F.group_norm(_from_tok(hh.float(), frames, h, w), 32, gamma, beta, 1e-5)
+    ref = _from_tok(skip.float(), frames, h, w) + hn * (1 + _from_tok(gb.float()[:, :C], frames, h, w)) + _from_tok(
+        gb.float()[:, C:], frames, h, w)
+    assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
+
+
+@pytest.mark.parametrize("rows,C", [(130, 320), (64, 640), (37, 1280), (9, 64)])
+def test_layernorm(hip, rows, C):
+    x = h16(rnd(rows, C, seed=38) * 2 + 0.5)
+    g, b = 1 + 0.1 * rnd(C, seed=39), 0.1 * rnd(C, seed=40)
+    y = torch.empty(rows, C, dtype=torch.half, device=DEV)
+    hip.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), y)
+    assert rel_l2(y.cpu().float(), F.layer_norm(x.float(), (C,), g, b, 1e-5)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, scale):
+    s = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    return torch.einsum("bhij,bhjd->bhid", s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nkv,D", [(2, 5, 256, 256, 64), (1, 2, 200, 77, 64), (2, 4, 130, 130, 128), (1, 1, 64, 64, 64),
+                                          (1, 3, 1024, 1024, 64), (3, 2, 64, 5, 64)])
+def test_flash_attention(hip, B, H, Nq, Nkv, D):
+    q, k, v = h16(rnd(B, H, Nq, D, seed=41)), h16(rnd(B, H, Nkv, D, seed=42)), h16(rnd(B, H, Nkv, D, seed=43))
+    scale = D ** -0.5
+    ref = _attn_ref(q.float(), k.float(), v.float(), scale)
+    C_ = H * D
+    qt = q.permute(0, 2, 1, 3).reshape(B * Nq, C_).contiguous().to(DEV)      # token-major [B*Nq, H*D]
+    kt = k.permute(0, 2, 1, 3).reshape(B * Nkv, C_).contiguous().to(DEV)
+    nkp = (Nkv + 7) // 8 * 8
+    vt = torch.zeros(B, H, D, nkp, dtype=torch.half)
+    vt[..., :Nkv] = v.permute(0, 1, 3, 2)
+    vt = vt.to(DEV)
+    o = torch.empty(B * Nq, C_, dtype=torch.half, device=DEV)
+    hip.attention(qt, kt, vt, o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D,
+                  q_strides=(Nq * C_, C_, D), k_strides=(Nkv * C_, C_, D), vt_strides=(H * D * nkp, D * nkp, nkp),
+                  o_strides=(Nq * C_, C_, D), scale=scale)
+    got = o.cpu().float().reshape(B, Nq, H, D).permute(0, 2, 1, 3)
+    assert rel_l2(got, ref) < 2e-3
+
+
+def test_flash_attention_spike(hip):
+    # force a large running-max jump in a late key tile (online-softmax rescale path)
+    B, H, N, D = 1, 1, 192, 64
+    q, k, v = h16(rnd(B, H, N, D, seed=44)), h16(rnd(B, H, N, D, seed=45)), h16(rnd(B, H, N, D, seed=46))
+    k[0, 0, 150] = q[0, 0, 7] * 4
+    scale = D ** -0.5
+    ref = _attn_ref(q.float(), k.float(), v.float(), scale)
+    vt = v.permute(0, 1, 3, 2).contiguous().to(DEV)
+    qt, kt = q.reshape(N, D).to(DEV), k.reshape(N, D).to(DEV)
+    o = torch.empty(N, D, dtype=torch.half, device=DEV)
+    hip.attention(qt, kt, vt, o, batch=1, heads=1, Nq=N, Nkv=N, head_dim=D, q_strides=(N * D, D, D), k_strides=(N * D, D, D),
+                  vt_strides=(D * N, D * N, N), o_strides=(N * D, D, D), scale=scale)
+    assert rel_l2(o.cpu().float().reshape(1, 1, N, D), ref) < 2e-3
+
+
+@pytest.mark.parametrize("T,HW,heads,D", [(5, 64, 20, 64), (8, 16, 2, 64), (3, 9, 1, 128)])
+def test_temporal_attention(hip, T, HW, heads, D):
+    C_ = heads * D
+    q, k, v = h16(rnd(T * HW, C_, seed=47)), h16(rnd(T * HW, C_, seed=48)), h16(rnd(T * HW, C_, seed=49))
+    o = torch.empty(T * HW, C_, dtype=torch.half, device=DEV)
+    hip.temporal_attention(q.to(DEV), k.to(DEV), v.to(DEV), o, T, HW, heads, D, D ** -0.5)
+
+    def sh(t):  # [T*HW, C] -> [HW, heads, T, D]
+        return t.float().reshape(T, HW, heads, D).permute(1, 2, 0, 3)
+    ref = _attn_ref(sh(q), sh(k), sh(v), D ** -0.5).permute(2, 0, 1, 3).reshape(T * HW, C_)
+    assert rel_l2(o.cpu().float(), ref) < 1e-3
+
+
+def test_softmax_rows(hip):
+    rows, cols = 300, 1000
+    s = rnd(rows, cols, seed=50) * 3
+    p = torch.empty(rows, cols + 8, dtype=torch.half, device=DEV)
+    hip.softmax_rows(s.to(DEV), p, rows, cols)
+    assert rel_l2(p[:, :cols].cpu().float(), s.softmax(-1)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# small dense + embedding + layout
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(5, 1280, 320), (8, 20000, 1280), (1, 64, 8), (16, 100, 256)])
+def test_linear_small(hip, M, N, K):
+    a, w, b = rnd(M, K, seed=51), h16(rnd(N, K, seed=52, scale=K ** -0.5)), rnd(N, seed=53)
+    y = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    hip.linear_small(a.to(DEV), w.to(DEV), b.to(DEV), y, silu_in=True, silu_out=True)
+    ref = F.silu(F.silu(a) @ w.float().t() + b)
+    assert rel_l2(y.cpu(), ref) < 1e-5
+
+
+def test_timestep_embedding(hip):
+    t = torch.tensor([0., 20., 41., 999., 500.])
+    dim = 320
+    out = torch.empty(5, dim, dtype=torch.float32, device=DEV)
+    hip.timestep_embedding(t.to(DEV), out)
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert float((out.cpu() - ref).abs().max()) < 2e-4   # fp32 sin/cos of arguments up to 999
+
+
+def test_layout_roundtrip(hip):
+    x = rnd(3, 4, 10, 12, seed=54)
+    y = torch.empty(3 * 10 * 12, 16, dtype=torch.half, device=DEV)
+    hip.nchw_to_nhwc(x.to(DEV), y, 8)
+    assert float(y[:, 4:8].abs().max()) == 0
+    back = torch.empty(3, 4, 10, 12, dtype=torch.float32, device=DEV)
+    hip.nhwc_to_nchw(y, back)
+    assert torch.equal(back.cpu(), x.half().float())
+    z = torch.zeros(3 * 10 * 12, 24, dtype=torch.half, device=DEV)
+    hip.copy2d(y[:, :8], z[:, 16:24])
+    assert torch.equal(z[:, 16:24], y[:, :8])
+    hip.axpby(y[:, :8], z[:, 16:24], 2.0, 0.5)
+    assert torch.allclose(z[:, 16:24].float(), y[:, :8].float() * 2.5, atol=2e-3, rtol=2e-3)
