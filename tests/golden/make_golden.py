@@ -1,0 +1,287 @@
+"""Generate the golden fixtures under tests/golden/*.npz by running the REFERENCE's own Python
+(/root/reference, read-only) in the build container.  Fixtures hold inputs + expected outputs (+ the reference's
+parameter names/shapes); weights are never stored — both sides regenerate them from mgld_vsr_amd.synth.
+
+    python tests/golden/make_golden.py            # (re)writes every fixture
+
+Never runs on the GPU box (the reference does not travel); the committed .npz files do.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL  # noqa: E402
+from mgld_vsr_amd import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def names_shapes(module):
+    return json.dumps([[k, list(v.shape)] for k, v in module.state_dict().items() if v.is_floating_point()])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def gen_flow():
+    au = ref_import.ref("basicsr.archs.arch_util")
+    uf = ref_import.ref("scripts.util_flow")
+    n, c, h, w = 3, 4, 20, 24
+    x = synth.synth_tensor("flow/x", (n, c, h, w))
+    flow = synth.smooth_flow("flow/f", n, h, w, amp=3.0)
+    flow[0, :, :3] += 40.0  # far out of range
+    flow[1, :, :, -2:] += 1.7  # straddles the right border
+    with torch.enable_grad():
+        xg = x.clone().requires_grad_(True)
+        out = au.flow_warp(xg, flow.permute(0, 2, 3, 1))
+        up = synth.synth_tensor("flow/up", (n, c, h, w))
+        grad = torch.autograd.grad((out * up).sum(), xg)[0]
+    out2 = uf.flow_warp(x, flow)
+    fwd, bwd = synth.smooth_flow("flow/fw", n, h, w, 2.0), synth.smooth_flow("flow/bw", n, h, w, 2.0)
+    bwd = -fwd + 0.3 * bwd
+    focc, bocc = uf.forward_backward_consistency_check(fwd, bwd, alpha=0.01, beta=0.5)
+    rs = au.resize_flow(fwd, "shape", [h // 2, w // 2])
+    rs2 = au.resize_flow(fwd, "ratio", [0.5, 0.5])
+    save("g_flow", x=x, flow=flow, warp=out.detach(), up=up, grad=grad, warp_n2hw=out2, fwd=fwd, bwd=bwd, focc=focc, bocc=bocc,
+         resized=rs, resized_ratio=rs2)
+
+
+def gen_guidance():
+    ddpm = ref_import.ref("ldm.models.diffusion.ddpm")
+    uf = ref_import.ref("scripts.util_flow")
+    out = {}
+    for Tn, h, w in [(3, 12, 16), (5, 16, 16)]:
+        z = synth.synth_tensor(f"guid/z{Tn}", (Tn, 4, h, w), 0.8)
+        ff = synth.smooth_flow(f"guid/ff{Tn}", Tn - 1, h, w)
+        fb = synth.smooth_flow(f"guid/fb{Tn}", Tn - 1, h, w)
+        focc, bocc = uf.forward_backward_consistency_check(fb, ff)
+        focc[:, :2] = 1.0
+        self_ = types.SimpleNamespace(num_frames=Tn)
+        with torch.enable_grad():
+            zg = z.clone().requires_grad_(True)
+            loss = ddpm.LatentDiffusionVSRTextWT.compute_temporal_condition_v4(
+                self_, (ff[None], fb[None]), zg, (focc[None, :, None], bocc[None, :, None]))
+            grad = torch.autograd.grad(loss, zg)[0]
+        out.update({f"z{Tn}": z, f"ff{Tn}": ff, f"fb{Tn}": fb, f"focc{Tn}": focc, f"bocc{Tn}": bocc,
+                    f"loss{Tn}": loss.detach().reshape(1), f"grad{Tn}": grad})
+    save("g_guidance", **out)
+
+
+# ---- reduced full model ---------------------------------------------------------------------------------------------
+class _StubCond(torch.nn.Module):
+    def __init__(self, ctx_dim=64, **kw):
+        super().__init__()
+        self.ctx_dim = ctx_dim
+        self.device = "cpu"
+
+    def forward(self, text):
+        return synth.synth_tensor("ctx", (1, 77, self.ctx_dim)).repeat(len(text), 1, 1)
+
+    def encode(self, text):
+        return self(text)
+
+
+class _StubFlow(torch.nn.Module):
+    def __init__(self, **kw):
+        super().__init__()
+
+
+def build_ref_model():
+    stubs = types.ModuleType("golden_stubs")
+    stubs.StubCond, stubs.StubFlow = _StubCond, _StubFlow
+    sys.modules["golden_stubs"] = stubs
+    ddpm = ref_import.ref("ldm.models.diffusion.ddpm")
+    fs_dd = dict(VAE_DD_SMALL)
+    fs_dd.pop("num_frames")
+    model = ddpm.LatentDiffusionVSRTextWT(
+        first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                            "params": {"embed_dim": 4, "ddconfig": fs_dd, "lossconfig": {"target": "torch.nn.Identity"}}},
+        cond_stage_config={"target": "golden_stubs.StubCond", "params": {"ctx_dim": UNET_SMALL["context_dim"]}},
+        structcond_stage_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedEncoderUNetModelWT",
+                                 "params": dict(STRUCT_SMALL)},
+        flownet_config={"target": "golden_stubs.StubFlow", "params": {}},
+        num_frames=T, linear_start=0.00085, linear_end=0.0120, num_timesteps_cond=1, log_every_t=200, timesteps=1000,
+        first_stage_key="image", cond_stage_key="caption", image_size=128, channels=4, cond_stage_trainable=False,
+        conditioning_key="crossattn", scale_factor=0.18215, use_ema=False, time_replace=1000, use_usm=True,
+        unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedUNetModelDualcondV2",
+                     "params": dict(UNET_SMALL)})
+    model.eval()
+    synth.fill_module_(model.model.diffusion_model, "unet")
+    synth.fill_module_(model.structcond_stage_model, "structcond")
+    synth.fill_module_(model.first_stage_model, "first_stage")
+    model.configs = types.SimpleNamespace(model=types.SimpleNamespace(params=types.SimpleNamespace(channels=4)))
+    return model, ddpm
+
+
+def respace(model, steps):
+    """scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py:308-329, verbatim procedure."""
+    import copy
+    ddpm = ref_import.ref("ldm.models.diffusion.ddpm")
+    model.register_schedule(given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=0.00085,
+                            linear_end=0.0120, cosine_s=8e-3)
+    model.num_timesteps = 1000
+    sac = copy.deepcopy(model.sqrt_alphas_cumprod)
+    somac = copy.deepcopy(model.sqrt_one_minus_alphas_cumprod)
+    use_timesteps = set(ddpm.space_timesteps(1000, [steps]))
+    last = 1.0
+    new_betas = []
+    for i, ac in enumerate(model.alphas_cumprod):
+        if i in use_timesteps:
+            new_betas.append(1 - ac / last)
+            last = ac
+    new_betas = [b.data.cpu().numpy() for b in new_betas]
+    model.register_schedule(given_betas=np.array(new_betas), timesteps=len(new_betas))
+    model.num_timesteps = 1000
+    model.ori_timesteps = sorted(list(use_timesteps))
+    return sac, somac
+
+
+SCHED_KEYS = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+              "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]
+
+
+def gen_schedule(model):
+    out = {}
+    for S in (4, 50):
+        sac, somac = respace(model, S)
+        for k in SCHED_KEYS:
+            out[f"S{S}_{k}"] = getattr(model, k).clone()
+        out[f"S{S}_ori_timesteps"] = np.array(model.ori_timesteps, dtype=np.int64)
+        out[f"S{S}_full_sqrt_alphas_cumprod"] = sac
+        out[f"S{S}_full_sqrt_one_minus_alphas_cumprod"] = somac
+    x0 = synth.synth_tensor("sched/x0", (T, 4, 8, 8))
+    nz = synth.synth_tensor("sched/noise", (T, 4, 8, 8))
+    t = torch.tensor([999] * T).long()
+    out["qs_x0"], out["qs_noise"] = x0, nz
+    out["qs_out"] = model.q_sample_respace(x_start=x0, t=t, sqrt_alphas_cumprod=sac, sqrt_one_minus_alphas_cumprod=somac, noise=nz)
+    save("g_schedule", **out)
+
+
+def gen_unet(model):
+    unet = model.model.diffusion_model
+    sc = model.structcond_stage_model
+    h = w = 16
+    x = synth.synth_tensor("unet/x", (T, 4, h, w))
+    lat = synth.synth_tensor("unet/lat", (T, 4, h, w), 0.5)
+    t = torch.tensor([541] * T).long()
+    ctx = synth.synth_tensor("ctx", (1, 77, UNET_SMALL["context_dim"]))
+    scd = sc(lat, t)
+    eps = unet(x, t, context=ctx, struct_cond=scd)
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+    temb = timestep_embedding(torch.tensor([0, 20, 541, 999]).long(), 64)
+    save("g_unet", x=x, lat=lat, t=t.numpy(), ctx=ctx, eps=eps, temb=temb, unet_params=names_shapes(unet),
+         struct_params=names_shapes(sc), **{f"sc_{k}": v for k, v in scd.items()})
+
+
+def gen_vae():
+    ae = ref_import.ref("ldm.models.autoencoder")
+    cf = ref_import.ref("scripts.wavelet_color_fix")
+    vq = ae.VideoAutoencoderKLResi(ddconfig=dict(VAE_DD_SMALL), lossconfig={"target": "torch.nn.Identity"}, embed_dim=4,
+                                   fusion_w=1.0, freeze_dec=True, version=1)
+    vq.eval()
+    synth.fill_module_(vq, "vae")
+    x = synth.synth_tensor("vae/x", (T, 3, 64, 64), 0.5)
+    post, fea = vq.encode(x)
+    z = synth.synth_tensor("vae/z", (T, 4, 8, 8))
+    dec = vq.decode(z, fea)
+    vq.decoder.fusion_w = 0.5
+    dec_w05 = vq.decode(z, fea)
+    style = synth.synth_tensor("vae/style", (T, 3, 64, 64), 0.3) + 0.1
+    adain = cf.adaptive_instance_normalization(dec, style)
+    wav = cf.wavelet_reconstruction(dec, style)
+    save("g_vae", x=x, mean=post.mean, logvar=post.logvar, fea0=fea[0], fea1=fea[1], z=z, dec=dec, dec_w05=dec_w05,
+         style=style, adain=adain, wavelet=wav, vae_params=names_shapes(vq))
+
+
+def gen_first_stage(model):
+    """AutoencoderKL.encode (first_stage_model) moments for the init latent path (ddpm.py:3906-3943, 3382-3389)."""
+    x = synth.synth_tensor("vae/x", (T, 3, 64, 64), 0.5)
+    post = model.first_stage_model.encode(x)
+    save("g_first_stage", x=x, mean=post.mean, logvar=post.logvar, params=names_shapes(model.first_stage_model))
+
+
+def gen_sample(model, ddpm):
+    S = 4
+    uf = ref_import.ref("scripts.util_flow")
+    out = {}
+    for tag, (h, w), canvas in [("plain", (16, 16), False), ("canvas", (24, 24), True)]:
+        respace(model, S)
+        ctx = model.cond_stage_model([""])
+        lat = synth.synth_tensor(f"sample/{tag}/lat", (T, 4, h, w), 0.5)
+        xT = synth.synth_tensor(f"sample/{tag}/xT", (T, 4, h, w))
+        noises = [synth.synth_tensor(f"sample/{tag}/noise{i}", (T, 4, h, w)) for i in range(S)]
+        ff = synth.smooth_flow(f"sample/{tag}/ff", T - 1, h, w)
+        fb = synth.smooth_flow(f"sample/{tag}/fb", T - 1, h, w)
+        focc, bocc = uf.forward_backward_consistency_check(fb, ff)
+        queue = list(noises)
+        orig = ddpm.noise_like
+        ddpm.noise_like = lambda shape, device, repeat=False: queue.pop(0)
+        try:
+            kw = dict(cond=ctx, struct_cond=lat, guidance_scale=-10.0, lr_images=None, flows=(ff[None], fb[None]),
+                      masks=(focc[None, :, None], bocc[None, :, None]), batch_size=1, timesteps=S, time_replace=S, x_T=xT,
+                      return_intermediates=True, verbose=False)
+            if canvas:
+                x0, inter = model.sample_canvas(tile_size=16, tile_overlap=8, batch_size_sample=1, **kw)
+            else:
+                x0, inter = model.sample(**kw)
+            # and once more without guidance
+            queue[:] = list(noises)
+            kw["flows"], kw["masks"] = None, None
+            if canvas:
+                x0_ng, _ = model.sample_canvas(tile_size=16, tile_overlap=8, batch_size_sample=1, **kw)
+            else:
+                x0_ng, _ = model.sample(**kw)
+        finally:
+            ddpm.noise_like = orig
+        out.update({f"{tag}_ctx": ctx, f"{tag}_lat": lat, f"{tag}_xT": xT, f"{tag}_noise": torch.stack(noises),
+                    f"{tag}_ff": ff, f"{tag}_fb": fb, f"{tag}_focc": focc, f"{tag}_bocc": bocc, f"{tag}_x0": x0,
+                    f"{tag}_x0_noguid": x0_ng})
+    out["gauss16"] = model._gaussian_weights(16, 16, 1)[0, 0]
+    out["gauss64"] = model._gaussian_weights(64, 64, 1)[0, 0]
+    save("g_sample", **out)
+
+
+def gen_spliter():
+    ui = ref_import.ref("scripts.util_image")
+    out = {}
+    for L, size, stride in [(1024, 960, 750), (512, 960, 750), (2000, 960, 750), (100, 64, 32)]:
+        sp = ui.ImageSpliterTh(torch.zeros(1, 1, L, L + 8), size, stride, sf=1)
+        out[f"h_{L}_{size}_{stride}"] = np.array(sp.height_starts_list)
+        out[f"w_{L}_{size}_{stride}"] = np.array(sp.width_starts_list)
+    save("g_spliter", **out)
+
+
+if __name__ == "__main__":
+    gen_flow()
+    gen_guidance()
+    try:
+        gen_spliter()
+    except Exception as e:  # util_image imports optional deps
+        print("spliter fixture skipped:", repr(e))
+    gen_vae()
+    model, ddpm = build_ref_model()
+    gen_schedule(model)
+    gen_unet(model)
+    gen_first_stage(model)
+    gen_sample(model, ddpm)

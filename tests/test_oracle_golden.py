@@ -1,0 +1,134 @@
+"""Pin the oracle (oracle/, torch-CPU restatement) against golden vectors produced by the reference's own Python
+(tests/golden/make_golden.py, run in the build container against /root/reference).  CPU-only."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL  # noqa: E402
+from mgld_vsr_amd import synth  # noqa: E402
+from oracle import colorfix as ocf  # noqa: E402
+from oracle import flow as oflow  # noqa: E402
+from oracle import nets  # noqa: E402
+from oracle import sampler as osamp  # noqa: E402
+from oracle import schedule as osched  # noqa: E402
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+
+
+def G(name):
+    d = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    return {k: (torch.from_numpy(d[k]) if d[k].dtype.kind in "fiu" else d[k]) for k in d.files}
+
+
+def sd_from(fix, key, salt):
+    return synth.synth_state_dict(json.loads(str(fix[key])), salt)
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_flow_golden():
+    g = G("g_flow")
+    x = g["x"].clone().requires_grad_(True)
+    out = oflow.flow_warp(x, g["flow"].permute(0, 2, 3, 1))
+    grad = torch.autograd.grad((out * g["up"]).sum(), x)[0]
+    assert torch.equal(out.detach(), g["warp"])
+    assert torch.equal(grad, g["grad"])
+    assert torch.equal(oflow.flow_warp_n2hw(g["x"], g["flow"]), g["warp_n2hw"])
+    fo, bo = oflow.forward_backward_consistency_check(g["fwd"], g["bwd"])
+    assert torch.equal(fo, g["focc"]) and torch.equal(bo, g["bocc"])
+    h, w = g["fwd"].shape[2:]
+    assert torch.equal(oflow.resize_flow(g["fwd"], h // 2, w // 2), g["resized"])
+    assert torch.equal(g["resized"], g["resized_ratio"])
+
+
+@pytest.mark.parametrize("Tn", [3, 5])
+def test_guidance_golden(Tn):
+    g = G("g_guidance")
+    z = g[f"z{Tn}"].clone().requires_grad_(True)
+    flows = (g[f"ff{Tn}"][None], g[f"fb{Tn}"][None])
+    masks = (g[f"focc{Tn}"][None, :, None], g[f"bocc{Tn}"][None, :, None])
+    loss = oflow.temporal_condition_v4(flows, z, masks, Tn)
+    grad = torch.autograd.grad(loss, z)[0]
+    assert abs(float(loss) - float(g[f"loss{Tn}"])) < 1e-7
+    assert torch.allclose(grad, g[f"grad{Tn}"], atol=1e-9)
+
+
+@pytest.mark.parametrize("S", [4, 50])
+def test_schedule_golden(S):
+    g = G("g_schedule")
+    full, resp, ori = osched.respaced_schedule(S)
+    assert ori == g[f"S{S}_ori_timesteps"].tolist()
+    for k in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+              "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]:
+        assert torch.equal(resp[k], g[f"S{S}_{k}"]), k
+    assert torch.equal(full["sqrt_alphas_cumprod"], g[f"S{S}_full_sqrt_alphas_cumprod"])
+    t = torch.tensor([999] * g["qs_x0"].shape[0]).long()
+    out = osched.q_sample_respace(g["qs_x0"], t, full["sqrt_alphas_cumprod"], full["sqrt_one_minus_alphas_cumprod"], g["qs_noise"])
+    assert torch.equal(out, g["qs_out"])
+
+
+def test_unet_structcond_golden():
+    g = G("g_unet")
+    usd, ssd = sd_from(g, "unet_params", "unet"), sd_from(g, "struct_params", "structcond")
+    t = g["t"].long()
+    assert torch.allclose(nets.timestep_embedding(torch.tensor([0, 20, 541, 999]), 64), g["temb"], atol=1e-6)
+    sc = nets.structcond_forward(ssd, STRUCT_SMALL, g["lat"], t)
+    for k, v in sc.items():
+        assert rel_l2(v, g[f"sc_{k}"]) < 1e-5, k
+    eps = nets.unet_forward(usd, UNET_SMALL, g["x"], t, g["ctx"], sc)
+    assert rel_l2(eps, g["eps"]) < 1e-5
+
+
+def test_vae_golden():
+    g = G("g_vae")
+    sd = sd_from(g, "vae_params", "vae")
+    mean, logvar, fea = nets.vae_moments(sd, VAE_DD_SMALL, g["x"])
+    assert rel_l2(mean, g["mean"]) < 1e-5 and rel_l2(logvar, g["logvar"]) < 1e-5
+    assert rel_l2(fea[0], g["fea0"]) < 1e-5 and rel_l2(fea[1], g["fea1"]) < 1e-5
+    dec = nets.vae_decode(sd, VAE_DD_SMALL, g["z"], [g["fea0"], g["fea1"]], fusion_w=1.0)
+    assert rel_l2(dec, g["dec"]) < 1e-5
+    dec05 = nets.vae_decode(sd, VAE_DD_SMALL, g["z"], [g["fea0"], g["fea1"]], fusion_w=0.5)
+    assert rel_l2(dec05, g["dec_w05"]) < 1e-5
+    assert rel_l2(ocf.adaptive_instance_normalization(g["dec"], g["style"]), g["adain"]) < 1e-6
+    assert rel_l2(ocf.wavelet_reconstruction(g["dec"], g["style"]), g["wavelet"]) < 1e-6
+
+
+def test_first_stage_golden():
+    g = G("g_first_stage")
+    sd = sd_from(g, "params", "first_stage")
+    dd = dict(VAE_DD_SMALL)
+    mean, logvar, _ = nets.vae_moments(sd, dd, g["x"])
+    assert rel_l2(mean, g["mean"]) < 1e-5 and rel_l2(logvar, g["logvar"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,tile", [("plain", None), ("canvas", (16, 8))])
+def test_sample_golden(tag, tile):
+    g, gu = G("g_sample"), G("g_unet")
+    usd, ssd = sd_from(gu, "unet_params", "unet"), sd_from(gu, "struct_params", "structcond")
+    noises = list(g[f"{tag}_noise"])
+    flows = (g[f"{tag}_ff"][None], g[f"{tag}_fb"][None])
+    masks = (g[f"{tag}_focc"][None, :, None], g[f"{tag}_bocc"][None, :, None])
+    kw = dict(tile=tile)
+    x0_ng = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, g[f"{tag}_ctx"], g[f"{tag}_lat"], g[f"{tag}_xT"], noises, 4, **kw)
+    assert rel_l2(x0_ng, g[f"{tag}_x0_noguid"]) < 1e-5
+    x0 = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, g[f"{tag}_ctx"], g[f"{tag}_lat"], g[f"{tag}_xT"], noises, 4,
+                      guidance_scale=-10.0, flows=flows, masks=masks, **kw)
+    assert rel_l2(x0, g[f"{tag}_x0"]) < 1e-4
+
+
+def test_gaussian_weights_golden():
+    g = G("g_sample")
+    assert torch.equal(osamp.gaussian_weights(16, 16), g["gauss16"])
+    assert torch.equal(osamp.gaussian_weights(64, 64), g["gauss64"])
+    assert osamp.tile_origins(128, 128, 64, 32) == [(y, x) for x in (0, 32, 64) for y in (0, 32, 64)]
