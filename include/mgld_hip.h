@@ -160,9 +160,12 @@ int mgld_axpby(const void* x, int ldx, void* y, int ldy, int64_t rows, int cols,
 /* ---- B2/B3/F1/K10/K15: one reverse-diffusion step + motion guidance (ddpm.py:340-353, 3538-3574, 4325-4380) ---
  * coef table row (8 floats per schedule index i): {sqrt_recip_ac, sqrt_recipm1_ac, post_mean_coef1,
  * post_mean_coef2, post_log_var_clipped, nonzero(i!=0), t_replace, unused}. `step_idx` is a device int. */
-/* z = mean(x, eps) + nonzero*exp(0.5*logvar)*noise ; x,noise,z fp32 NCHW [n,4,h,w]; eps fp32 NHWC [n*h*w, ld_eps] */
-int mgld_ddpm_step(const float* x, const float* eps, int ld_eps, const float* noise, const float* coef,
-                   const int32_t* step_idx, float* z, int n, int c, int h, int w, void* stream);
+/* z = mean(x, eps) + nonzero*exp(0.5*logvar)*noise ; x,noise,z fp32 NCHW [n,4,h,w]; eps fp32 NHWC [n*h*w, ld_eps]
+ * (ld_eps <= 0: eps is NCHW like x — the stitched aggregation-sampling canvas);
+ * the noise of schedule index i is read at noise + i*noise_step_stride (stride 0: one tensor) so that a captured
+ * hipGraph of the step can be replayed for every i without host involvement. */
+int mgld_ddpm_step(const float* x, const float* eps, int ld_eps, const float* noise, int64_t noise_step_stride,
+                   const float* coef, const int32_t* step_idx, float* z, int n, int c, int h, int w, void* stream);
 /* bilinear backward warp, zeros padding, align_corners=True (arch_util.py:156-194): out[n,c,y,x] =
  * bilinear(in[n,c], x+flow[n,0,y,x], y+flow[n,1,y,x]); flow fp32 [n,2,h,w] */
 int mgld_flow_warp(const float* in, const float* flow, float* out, int n, int c, int h, int w, void* stream);

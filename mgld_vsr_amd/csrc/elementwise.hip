@@ -179,9 +179,11 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const f16* __restric
 
 // ---- DDPM reverse step (ddpm.py:340-353, 4344-4357) -----------------------------------------------------------
 __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, int ld_eps,
-                                 const float* __restrict__ noise, const float* __restrict__ coef,
-                                 const int32_t* __restrict__ step_idx, float* __restrict__ z, int n, int c, int hw) {
+                                 const float* __restrict__ noise_base, int64_t noise_step_stride,
+                                 const float* __restrict__ coef, const int32_t* __restrict__ step_idx,
+                                 float* __restrict__ z, int n, int c, int hw) {
   const float* cf = coef + (int64_t)step_idx[0] * 8;
+  const float* noise = noise_base + (int64_t)step_idx[0] * noise_step_stride;
   const float c_recip = cf[0], c_recipm1 = cf[1], pm1 = cf[2], pm2 = cf[3], logvar = cf[4], nonzero = cf[5];
   const float sigma = nonzero * expf(0.5f * logvar);
   const int64_t total = (int64_t)n * c * hw;
@@ -190,7 +192,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
     const int64_t fc = idx / hw;
     const int ch = (int)(fc % c);
     const int64_t f = fc / c;
-    const float e = eps[(f * hw + pix) * ld_eps + ch];
+    const float e = ld_eps > 0 ? eps[(f * hw + pix) * ld_eps + ch] : eps[idx];  // ld_eps<=0: eps is NCHW like x
     const float xv = x[idx];
     const float x0 = c_recip * xv - c_recipm1 * e;
     const float mean = pm1 * x0 + pm2 * xv;
@@ -588,12 +590,13 @@ extern "C" int mgld_temporal_attention(const void* q, const void* k, const void*
   return mgld_check_launch("temporal_attention");
 }
 
-extern "C" int mgld_ddpm_step(const float* x, const float* eps, int ld_eps, const float* noise, const float* coef,
-                              const int32_t* step_idx, float* z, int n, int c, int h, int w, void* stream) {
+extern "C" int mgld_ddpm_step(const float* x, const float* eps, int ld_eps, const float* noise, int64_t noise_step_stride,
+                              const float* coef, const int32_t* step_idx, float* z, int n, int c, int h, int w,
+                              void* stream) {
   MGLD_REQUIRE(x && eps && noise && coef && step_idx && z, "ddpm_step: null pointer");
-  MGLD_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && ld_eps >= c, "ddpm_step: shape");
+  MGLD_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && (ld_eps <= 0 || ld_eps >= c), "ddpm_step: shape");
   hipLaunchKernelGGL(ddpm_step_kernel, dim3(egrid((int64_t)n * c * h * w)), dim3(256), 0, S_(stream), x, eps, ld_eps, noise,
-                     coef, step_idx, z, n, c, h * w);
+                     noise_step_stride, coef, step_idx, z, n, c, h * w);
   return mgld_check_launch("ddpm_step");
 }
 

@@ -1,0 +1,434 @@
+"""LatentDiffusionVSRTextWT: the respaced DDPM sampling loop with motion guidance, on the HIP engine.
+
+Interface mirror of ldm/models/diffusion/ddpm.py: DDPM.register_schedule (:237-292), q_sample_respace (:403-406),
+LatentDiffusionVSRTextWT (:3166-4909: encode_first_stage / get_first_stage_encoding :3382-3389,3906-3943,
+compute_temporal_condition_v4 :3538-3574, apply_model :3984-4085, p_sample_loop / sample :4501-4599,4696-4719,
+sample_canvas :4722-4746 with _gaussian_weights :4601-4616), DiffusionWrapper (:4911-4940).
+
+MI355X design: the whole reverse step (struct-cond encoder -> UNet -> posterior -> guidance) is a fixed launch
+sequence over a bump arena; after the first eager step it is captured into ONE hipGraph and replayed for the
+remaining steps with no host synchronisation — per-step scalars (schedule coefficients, the network timestep, the
+noise slice) are read on the device through a step index that the graph itself decrements.
+"""
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .engine import Act, Engine
+from .util import default, instantiate_from_config
+from .vae import DiagonalGaussianDistribution
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """ldm/modules/diffusionmodules/util.py:21-43 ('linear' is the only schedule the VSR path uses)."""
+    if schedule != "linear":
+        raise NotImplementedError(f"beta schedule '{schedule}' is not on the MGLD-VSR hot path")
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+
+
+def space_timesteps(num_timesteps, section_counts):
+    """ddpm.py:101-154."""
+    if isinstance(section_counts, str):
+        section_counts = [int(x) for x in section_counts.split(",")]
+    size_per, extra = num_timesteps // len(section_counts), num_timesteps % len(section_counts)
+    start_idx, all_steps = 0, []
+    for i, cnt in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < cnt:
+            raise ValueError(f"cannot divide section of {size} steps into {cnt}")
+        stride = 1 if cnt <= 1 else (size - 1) / (cnt - 1)
+        cur = 0.0
+        for _ in range(cnt):
+            all_steps.append(start_idx + round(cur))
+            cur += stride
+        start_idx += size
+    return set(all_steps)
+
+
+def extract_into_tensor(a, t, x_shape):
+    b = t.shape[0]
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+class DiffusionWrapper(nn.Module):
+    """ddpm.py:4911-4940 (crossattn conditioning)."""
+
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+        assert conditioning_key == "crossattn", "MGLD-VSR uses cross-attention conditioning"
+
+    def forward(self, x, t, c_concat=None, c_crossattn=None, struct_cond=None, seg_cond=None):
+        cc = torch.cat(c_crossattn, 1)
+        return self.diffusion_model(x, t, context=cc, struct_cond=struct_cond)
+
+
+class LatentDiffusionVSRTextWT(nn.Module):
+    """Drop-in for `ldm.models.diffusion.ddpm.LatentDiffusionVSRTextWT` on the inference path."""
+
+    def __init__(self, first_stage_config, cond_stage_config, structcond_stage_config, flownet_config, unet_config=None,
+                 num_frames=1, num_timesteps_cond=None, cond_stage_key="image", cond_stage_trainable=False, concat_mode=True,
+                 cond_stage_forward=None, conditioning_key=None, scale_factor=1.0, scale_by_std=False,
+                 train_temporal_module=True, unfrozen_diff=False, random_size=False, test_gt=False, p2_gamma=None, p2_k=None,
+                 time_replace=None, use_usm=False, mix_ratio=0.0, timesteps=1000, beta_schedule="linear",
+                 linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3, image_size=256, channels=3, log_every_t=100,
+                 clip_denoised=True, parameterization="eps", use_ema=True, first_stage_key="image", v_posterior=0.,
+                 ckpt_path=None, ignore_keys=(), **kwargs):
+        super().__init__()
+        assert parameterization == "eps" and v_posterior == 0.
+        self.num_frames, self.channels, self.image_size = num_frames, channels, image_size
+        self.scale_factor = scale_factor
+        self.log_every_t, self.time_replace = log_every_t, time_replace
+        self.clip_denoised = False  # ddpm.py:3228
+        self.use_ema = False
+        self.parameterization, self.v_posterior = parameterization, v_posterior
+        self.cond_stage_key, self.first_stage_key = cond_stage_key, first_stage_key
+        self.model = DiffusionWrapper(unet_config, conditioning_key or ("concat" if concat_mode else "crossattn"))
+        self.first_stage_model = instantiate_from_config(first_stage_config)
+        self.cond_stage_model = instantiate_from_config(cond_stage_config)
+        self.structcond_stage_model = instantiate_from_config(structcond_stage_config)
+        self.flownet_model = instantiate_from_config(flownet_config)
+        self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
+                               linear_end=linear_end, cosine_s=cosine_s)
+        # time respacing as in the reference constructor (ddpm.py:3280-3295)
+        if self.time_replace is None:
+            self.time_replace = timesteps
+        use = set(space_timesteps(timesteps, [self.time_replace]))
+        self._respace(use, linear_start, linear_end)
+        self.configs = None
+        self._engine = None
+        self._stream = None
+        self._graph = None
+        self._graph_key = None
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+
+    # ---- schedule -------------------------------------------------------------------------------------------------
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        """ddpm.py:237-292: float64 (or the dtype of given_betas) math, float32 buffers."""
+        betas = given_betas if given_betas is not None else make_beta_schedule(beta_schedule, timesteps, linear_start,
+                                                                             linear_end, cosine_s)
+        betas = np.asarray(betas)
+        alphas = 1. - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1., ac[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        t32 = lambda a: torch.tensor(a, dtype=torch.float32)
+        post_var = (1 - self.v_posterior) * betas * (1. - ac_prev) / (1. - ac) + self.v_posterior * betas
+        for name, val in [
+            ("betas", betas), ("alphas_cumprod", ac), ("alphas_cumprod_prev", ac_prev),
+            ("sqrt_alphas_cumprod", np.sqrt(ac)), ("sqrt_one_minus_alphas_cumprod", np.sqrt(1. - ac)),
+            ("log_one_minus_alphas_cumprod", np.log(1. - ac)), ("sqrt_recip_alphas_cumprod", np.sqrt(1. / ac)),
+            ("sqrt_recipm1_alphas_cumprod", np.sqrt(1. / ac - 1)), ("posterior_variance", post_var),
+            ("posterior_log_variance_clipped", np.log(np.maximum(post_var, 1e-20))),
+            ("posterior_mean_coef1", betas * np.sqrt(ac_prev) / (1. - ac)),
+            ("posterior_mean_coef2", (1. - ac_prev) * np.sqrt(alphas) / (1. - ac)),
+        ]:
+            if name in self._buffers:
+                self._buffers[name] = t32(val)
+            else:
+                self.register_buffer(name, t32(val))
+        self._graph_key = None
+
+    def _respace(self, use_timesteps, linear_start, linear_end):
+        last, new_betas = 1.0, []
+        for i, ac in enumerate(self.alphas_cumprod):
+            if i in use_timesteps:
+                new_betas.append(1 - ac / last)
+                last = ac
+        new_betas = [b.data.cpu().numpy() for b in new_betas]
+        self.register_schedule(given_betas=np.array(new_betas), timesteps=len(new_betas), linear_start=linear_start,
+                               linear_end=linear_end)
+        self.ori_timesteps = sorted(list(use_timesteps))
+
+    @contextmanager
+    def ema_scope(self, context=None):
+        yield None  # use_ema=False in the shipped config (mgldvsr_512_realbasicvsr_deg.yaml:21)
+
+    def init_from_ckpt(self, path, ignore_keys=(), only_model=False):
+        sd = torch.load(path, map_location="cpu")
+        if "state_dict" in sd:
+            sd = sd["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        return self.load_state_dict(sd, strict=False)
+
+    # ---- engine ----------------------------------------------------------------------------------------------------
+    def engine(self):
+        if self._engine is None:
+            self._engine = Engine()
+            for m in (self.model.diffusion_model, self.structcond_stage_model, self.first_stage_model):
+                if hasattr(m, "set_engine"):
+                    m.set_engine(self._engine)
+        return self._engine
+
+    @property
+    def device(self):
+        return self.engine().device
+
+    def cuda(self, device=None):  # parameters stay on the host; packed fp16 copies live in the engine cache
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # ---- first stage / conditioning ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        self.engine()
+        return self.first_stage_model.encode(x)
+
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            z = encoder_posterior.sample(noise) if noise is not None else encoder_posterior.sample()
+        elif isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        else:
+            raise NotImplementedError(type(encoder_posterior))
+        return self.scale_factor * z
+
+    def get_learned_conditioning(self, c):
+        return self.cond_stage_model(c)
+
+    def q_sample_respace(self, x_start, t, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod, noise=None):
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        dev = x_start.device
+        return (extract_into_tensor(sqrt_alphas_cumprod.to(dev), t.to(dev), x_start.shape) * x_start +
+                extract_into_tensor(sqrt_one_minus_alphas_cumprod.to(dev), t.to(dev), x_start.shape) * noise)
+
+    def compute_flow(self, lrs):
+        """ddpm.py:3404-3429 — RAFT is SURVEY.md §8(f) 'next'; flows are inputs on this path."""
+        return self.flownet_model(lrs)
+
+    @torch.no_grad()
+    def compute_temporal_condition_v4(self, flows, latents, masks):
+        """Scalar guidance loss (ddpm.py:3538-3574) evaluated by the HIP kernels."""
+        eng = self.engine()
+        ff, fb, fo, bo = self._flows_to_device(eng, flows, masks)
+        z = latents.to(eng.device, torch.float32).contiguous()
+        T, c, h, w = z.shape
+        work = torch.empty(hip.guidance_work_bytes(T, c, h, w), dtype=torch.uint8, device=eng.device)
+        loss = torch.empty(1, device=eng.device)
+        hip.guidance_loss(z, ff, fb, fo, bo, loss, work)
+        return loss[0]
+
+    @torch.no_grad()
+    def apply_model(self, x_noisy, t, cond, struct_cond, return_ids=False):
+        if not isinstance(cond, dict):
+            cond = {"c_crossattn": cond if isinstance(cond, list) else [cond]}
+        return self.model(x_noisy, t, **cond, struct_cond=struct_cond)
+
+    # ---- sampling ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _flows_to_device(eng, flows, masks):
+        ff, fb = flows
+        fo, bo = masks
+        assert ff.shape[0] == 1, "motion guidance operates on one clip (b = 1), as the reference scripts do"
+        f32 = lambda t: t.to(eng.device, torch.float32).contiguous()
+        ff, fb = f32(ff[0]), f32(fb[0])                       # [T-1, 2, h, w]
+        fo, bo = f32(fo[0].reshape(fo.shape[1], *fo.shape[-2:])), f32(bo[0].reshape(bo.shape[1], *bo.shape[-2:]))
+        return ff, fb, fo, bo
+
+    def _coef_table(self, steps_total, use_t_replace):
+        S = self.posterior_mean_coef1.shape[0]
+        t = torch.zeros(S, 8)
+        t[:, 0] = self.sqrt_recip_alphas_cumprod
+        t[:, 1] = self.sqrt_recipm1_alphas_cumprod
+        t[:, 2] = self.posterior_mean_coef1
+        t[:, 3] = self.posterior_mean_coef2
+        t[:, 4] = self.posterior_log_variance_clipped
+        t[:, 5] = 1.0
+        t[0, 5] = 0.0
+        t[:, 6] = torch.tensor(self.ori_timesteps, dtype=torch.float32) if use_t_replace else torch.arange(S).float()
+        return t
+
+    def _gaussian_weights(self, tile_width, tile_height, nbatches=1):
+        """ddpm.py:4601-4616 (float64, asymmetric midpoints)."""
+        var = 0.01
+        mid = (tile_width - 1) / 2
+        xs = [np.exp(-(x - mid) * (x - mid) / (tile_width * tile_width) / (2 * var)) / np.sqrt(2 * np.pi * var)
+              for x in range(tile_width)]
+        mid = tile_height / 2
+        ys = [np.exp(-(y - mid) * (y - mid) / (tile_height * tile_height) / (2 * var)) / np.sqrt(2 * np.pi * var)
+              for y in range(tile_height)]
+        w = torch.tensor(np.outer(ys, xs))
+        return torch.tile(w, (nbatches, self.channels, 1, 1))
+
+    @staticmethod
+    def _tile_origins(h, w, tile_size, tile_overlap):
+        """tile enumeration of p_mean_variance_canvas (ddpm.py:4205-4236), reference order."""
+        def count(L):
+            n, cur = 0, 0
+            while cur < L:
+                cur = max(n * tile_size - tile_overlap * n, 0) + tile_size
+                n += 1
+            return n
+        rows, cols = count(w), count(h)
+        out, ofs_x, ofs_y = [], 0, 0
+        for row in range(rows):
+            for col in range(cols):
+                if col < cols - 1 or row < rows - 1:
+                    ofs_x = max(row * tile_size - tile_overlap * row, 0)
+                    ofs_y = max(col * tile_size - tile_overlap * col, 0)
+                if row == rows - 1:
+                    ofs_x = w - tile_size
+                if col == cols - 1:
+                    ofs_y = h - tile_size
+                out.append((ofs_y, ofs_x))
+        return out
+
+    def _step_body(self, eng, st):
+        """One reverse step as a pure launch sequence (graph-capturable)."""
+        unet, sc_net = self.model.diffusion_model, self.structcond_stage_model
+        eng.reset()
+        hip.step_timestep(st["coef"], st["step_idx"], st["tvals"])
+        x = st["x"]
+        if st["tiles"] is None:
+            xa = eng.from_nchw(x)
+            sc = sc_net.run(eng, st["lat_act"], st["tvals"], None)
+            eps = unet.run(eng, xa, st["tvals"], None, st["ctx"], sc).v
+        else:
+            ts = st["tile_size"]
+            nt = len(st["tiles"])
+            T, c = x.shape[0], x.shape[1]
+            xt = eng.arena.alloc((nt * T, c, ts, ts), torch.float32)
+            for k, (y0, x0) in enumerate(st["tiles"]):
+                hip.crop(x, xt[k * T:(k + 1) * T], y0, x0)
+            xa = eng.from_nchw(xt)
+            sc = sc_net.run(eng, st["lat_tiles"], st["tvals"], None)
+            e = unet.run(eng, xa, st["tvals"], None, st["ctx"], sc)
+            et = eng.arena.alloc((nt * T, c, ts, ts), torch.float32)
+            hip.nhwc_to_nchw(e.v, et)
+            acc, cnt = st["acc"], st["cnt"]
+            acc.zero_()
+            cnt.zero_()
+            for k, (y0, x0) in enumerate(st["tiles"]):
+                hip.tile_accumulate(et[k * T:(k + 1) * T], st["wgt"], acc, cnt, y0, x0)
+            eps = st["eps_canvas"]
+            hip.tile_normalize(acc, cnt, eps)
+        if st["guided"]:
+            hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], st["z"], st["noise_stride"])
+            hip.guidance(st["z"], st["ff"], st["fb"], st["fo"], st["bo"], st["coef"], st["step_idx"], st["gscale"], x, st["work"])
+        else:
+            hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], x, st["noise_stride"])
+        hip.step_advance(st["step_idx"], -1)
+
+    @torch.no_grad()
+    def _sample_loop(self, cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
+                     return_intermediates, log_every_t, noise, tile, use_graph=True):
+        eng = self.engine()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=eng.device)
+        S = timesteps if timesteps is not None else self.num_timesteps
+        if S > self.posterior_mean_coef1.shape[0]:
+            raise ValueError("timesteps exceeds the registered (respaced) schedule length")
+        use_t_replace = not (time_replace is None or time_replace == 1000)
+        if not log_every_t:
+            log_every_t = self.log_every_t
+        dev = eng.device
+        T_total, c, h, w = shape
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            x = (torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)).contiguous().clone()
+            if noise is None:
+                noise = torch.randn((S,) + tuple(shape), device=dev)
+            else:
+                noise = noise.to(dev, torch.float32).contiguous()
+                assert noise.shape == (S,) + tuple(shape), "noise must be [steps, T, C, h, w], indexed by schedule index i"
+            lat = struct_cond.to(dev, torch.float32).contiguous()
+            ctx = cond["c_crossattn"][0] if isinstance(cond, dict) else (cond[0] if isinstance(cond, list) else cond)
+            ctx = ctx.to(dev, torch.float32)[:1].contiguous()
+            st = {
+                "x": x, "coef": self._coef_table(S, use_t_replace).to(dev), "noise": noise, "noise_stride": x.numel(),
+                "step_idx": torch.tensor([S - 1], dtype=torch.int32, device=dev), "tvals": torch.zeros(1, device=dev),
+                "ctx": self.model.diffusion_model.context_cache(eng, ctx), "guided": flows is not None,
+                "gscale": float(guidance_scale), "tiles": None,
+            }
+            if flows is not None:
+                assert T_total == self.num_frames, "guidance expects one clip of num_frames frames"
+                st["ff"], st["fb"], st["fo"], st["bo"] = self._flows_to_device(eng, flows, masks)
+                st["z"] = torch.empty_like(x)
+                st["work"] = torch.empty(hip.guidance_work_bytes(T_total, c, h, w), dtype=torch.uint8, device=dev)
+            # persistent (non-arena) conditioning buffers
+            if tile is None:
+                la = torch.empty(T_total * h * w, 8, dtype=torch.float16, device=dev)
+                hip.nchw_to_nhwc(lat, la, 8)
+                st["lat_act"] = Act(la, T_total, h, w)
+            else:
+                ts, ov = tile
+                tiles = self._tile_origins(h, w, ts, ov)
+                st["tiles"], st["tile_size"] = tiles, ts
+                lt = torch.empty(len(tiles) * T_total, c, ts, ts, device=dev)
+                for k, (y0, x0) in enumerate(tiles):
+                    hip.crop(lat, lt[k * T_total:(k + 1) * T_total], y0, x0)
+                la = torch.empty(len(tiles) * T_total * ts * ts, 8, dtype=torch.float16, device=dev)
+                hip.nchw_to_nhwc(lt, la, 8)
+                st["lat_tiles"] = Act(la, len(tiles) * T_total, ts, ts)
+                st["wgt"] = self._gaussian_weights(ts, ts, 1)[0, 0].to(dev, torch.float32).contiguous()
+                st["acc"], st["cnt"], st["eps_canvas"] = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            intermediates = [x.clone()]
+            graph = None
+            for k, i in enumerate(reversed(range(S))):
+                if k == 0 or not use_graph:
+                    self._step_body(eng, st)
+                else:
+                    if graph is None:
+                        eng.arena.frozen = True
+                        graph = hip.Graph()
+                        graph.begin()
+                        try:
+                            self._step_body(eng, st)
+                        finally:
+                            graph.end()
+                            eng.arena.frozen = False
+                    graph.launch()
+                if return_intermediates and (i % log_every_t == 0 or i == S - 1):
+                    intermediates.append(x.clone())
+            self.last_launches_per_step = eng.launches
+            out = x
+        cur.wait_stream(self._stream)
+        if return_intermediates:
+            return out, intermediates
+        return out
+
+    def _check_unsupported(self, **kw):
+        for k, v in kw.items():
+            if v is not None:
+                raise NotImplementedError(f"option '{k}' is not used by the MGLD-VSR inference scripts and is not implemented")
+
+    @torch.no_grad()
+    def sample(self, cond, struct_cond, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, batch_size=16,
+               return_intermediates=False, x_T=None, verbose=True, timesteps=None, quantize_denoised=False, mask=None,
+               x0=None, shape=None, time_replace=None, adain_fea=None, interfea_path=None, start_T=None, noise=None,
+               use_graph=True, **kwargs):
+        """ddpm.py:4696-4719 -> p_sample_loop.  Extra kwargs: `noise` [steps,T,C,h,w] (injected noise indexed by
+        the schedule index; the reference draws randn per step) and `use_graph`."""
+        self._check_unsupported(lr_images=lr_images, mask=mask, x0=x0, adain_fea=adain_fea, interfea_path=interfea_path,
+                                start_T=start_T)
+        if shape is None:
+            shape = tuple(struct_cond.shape) if x_T is None else tuple(x_T.shape)
+        if cond is not None and not isinstance(cond, (dict, list)):
+            cond = cond[:batch_size]
+        return self._sample_loop(cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
+                                 return_intermediates, None, noise, None, use_graph)
+
+    @torch.no_grad()
+    def sample_canvas(self, cond, struct_cond, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, batch_size=16,
+                      return_intermediates=False, x_T=None, verbose=True, timesteps=None, quantize_denoised=False,
+                      mask=None, x0=None, shape=None, time_replace=None, adain_fea=None, interfea_path=None, tile_size=64,
+                      tile_overlap=32, batch_size_sample=4, log_every_t=None, noise=None, use_graph=True, **kwargs):
+        """ddpm.py:4722-4746 -> p_sample_loop_canvas: aggregation sampling over overlapping latent tiles.  All tiles
+        of a step are batched into one struct-cond + UNet pass (each tile is an independent clip)."""
+        self._check_unsupported(lr_images=lr_images, mask=mask, x0=x0, adain_fea=adain_fea, interfea_path=interfea_path)
+        if shape is None:
+            shape = tuple(struct_cond.shape) if x_T is None else tuple(x_T.shape)
+        return self._sample_loop(cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
+                                 return_intermediates, log_every_t, noise, (tile_size, tile_overlap), use_graph)

@@ -51,3 +51,205 @@ def pack_geglu(w, b):
     if b is not None:
         bp = torch.stack([b[:inner].reshape(g, 32), b[inner:].reshape(g, 32)], 1).reshape(two_inner).contiguous()
     return wp, bp
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# activations + arena
+# ------------------------------------------------------------------------------------------------------------------
+class Act:
+    """Token-major (NHWC) activation: `v` is a 2-D fp16 view [n*h*w, C] with row stride ld >= C."""
+    __slots__ = ("v", "n", "h", "w")
+
+    def __init__(self, v, n, h, w):
+        assert v.dim() == 2 and v.shape[0] == n * h * w, (v.shape, n, h, w)
+        self.v, self.n, self.h, self.w = v, n, h, w
+
+    @property
+    def C(self):
+        return self.v.shape[1]
+
+    @property
+    def rows(self):
+        return self.v.shape[0]
+
+    @property
+    def hw(self):
+        return self.h * self.w
+
+    def cols(self, c0, c1):
+        return Act(self.v[:, c0:c1], self.n, self.h, self.w)
+
+
+class Arena:
+    """Bump allocator over large device chunks.  reset() rewinds; identical call sequences therefore return
+    identical pointers, which is what makes a captured hipGraph of the launch sequence replayable."""
+
+    def __init__(self, device, chunk_bytes=1 << 30):
+        self.device = device
+        self.chunk_bytes = chunk_bytes
+        self.chunks = []
+        self.ci = 0
+        self.off = 0
+        self.frozen = False
+
+    def reset(self):
+        self.ci, self.off = 0, 0
+
+    def alloc(self, shape, dtype):
+        nbytes = int(torch.tensor([], dtype=dtype).element_size())
+        for s in shape:
+            nbytes *= int(s)
+        nbytes = (nbytes + 255) & ~255
+        while True:
+            if self.ci >= len(self.chunks):
+                if self.frozen:
+                    raise RuntimeError("arena grew after a graph was captured")
+                self.chunks.append(torch.empty(max(self.chunk_bytes, nbytes), dtype=torch.uint8, device=self.device))
+                self.off = 0
+            ch = self.chunks[self.ci]
+            if self.off + nbytes <= ch.numel():
+                t = ch[self.off:self.off + nbytes].view(dtype)
+                self.off += nbytes
+                n = 1
+                for s in shape:
+                    n *= int(s)
+                return t[:n].view(*shape)
+            self.ci += 1
+            self.off = 0
+
+    def bytes_reserved(self):
+        return sum(c.numel() for c in self.chunks)
+
+
+class Engine:
+    """Owns the arena, the packed-weight cache and the op helpers every network forward is written in."""
+
+    GROUPS = 32
+
+    def __init__(self, device="cuda", chunk_bytes=1 << 30):
+        hip.lib()  # fail loudly if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("mgld_vsr_amd needs a HIP device: the hot path has no CPU fallback")
+        self.device = torch.device(device)
+        self.arena = Arena(self.device, chunk_bytes)
+        self._wcache = {}
+        self.launches = 0
+
+    # ---- memory ----
+    def reset(self):
+        self.arena.reset()
+
+    def empty(self, rows, C, dtype=torch.float16):
+        return self.arena.alloc((rows, C), dtype)
+
+    def act(self, n, h, w, C, dtype=torch.float16):
+        return Act(self.arena.alloc((n * h * w, C), dtype), n, h, w)
+
+    # ---- packed weights (cached per (tag, parameter identity, version)) ----
+    def weight(self, tag, params, fn, dtype=torch.float16):
+        """params: tuple of parameters/tensors; fn(*cpu fp32 tensors) -> tensor (or tuple of tensors)."""
+        key = (tag,) + tuple((id(p), p._version) for p in params if p is not None)
+        hit = self._wcache.get(key)
+        if hit is not None:
+            return hit
+        with torch.no_grad():
+            out = fn(*[None if p is None else p.detach().float().cpu() for p in params])
+        if isinstance(out, (tuple, list)):
+            dev = tuple(None if o is None else o.to(self.device, dtype if o.dtype.is_floating_point and i == 0 else torch.float32).contiguous()
+                        for i, o in enumerate(out))
+        else:
+            dev = out.to(self.device, dtype).contiguous()
+        self._wcache[key] = dev
+        return dev
+
+    def f32(self, tag, p):
+        return self.weight(tag, (p,), lambda t: t, torch.float32)
+
+    # ---- ops ----
+    def conv3x3(self, x, wp, bias, cout, out=None, stride=1, pad=(1, 1), up2=False, hw_out=None, rowvec=None,
+                rows_per_frame=0, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16):
+        hin, win = x.h, x.w
+        if hw_out is None:
+            hv, wv = (2 * hin, 2 * win) if up2 else (hin, win)
+            hw_out = (hv, wv) if stride == 1 else (hv // 2, wv // 2)
+        ho, wo = hw_out
+        if out is None:
+            out = Act(self.arena.alloc((x.n * ho * wo, cout), out_dtype), x.n, ho, wo)
+        cin = x.C
+        assert wp.shape[1] == 9 * cin, (wp.shape, cin)
+        hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec,
+                  rows_per_frame=rows_per_frame or ho * wo, resid=None if resid is None else resid.v, act=act, alpha=alpha,
+                  beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0))
+        self.launches += 1
+        return out
+
+    def linear(self, x, w, bias, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, n_out=None):
+        """x: Act or 2-D view; w [N, K] fp16 packed."""
+        xv = x.v if isinstance(x, Act) else x
+        N = n_out if n_out is not None else (w.shape[0] // 2 if act == hip.ACT_GEGLU else w.shape[0])
+        if out is None:
+            ov = self.arena.alloc((xv.shape[0], N), out_dtype)
+            out = Act(ov, x.n, x.h, x.w) if isinstance(x, Act) else ov
+        ov = out.v if isinstance(out, Act) else out
+        rv = resid.v if isinstance(resid, Act) else resid
+        hip.igemm(xv, w, ov, bias=bias, resid=rv, act=act, alpha=alpha, beta=beta, M=xv.shape[0], N=w.shape[0], K=w.shape[1])
+        self.launches += 1
+        return out
+
+    def tconv3(self, x, wp, bias, T, alpha_blend, out=None):
+        """SpatialTemporalConv: out = a*(conv3d_t(x)+b) + (1-a)*x."""
+        if out is None:
+            out = self.act(x.n, x.h, x.w, x.C)
+        hip.igemm(x.v, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
+                  tconv=(x.C, T, x.hw))
+        self.launches += 1
+        return out
+
+    def gn_stats(self, x, eps, groups=None):
+        g = groups or self.GROUPS
+        partials = self.arena.alloc((x.n * hip.gn_chunks(x.hw) * x.C * 2,), torch.float32)
+        stats = self.arena.alloc((x.n, g, 2), torch.float32)
+        hip.gn_stats(x.v, x.n, x.hw, g, eps, partials, stats)
+        self.launches += 2
+        return stats
+
+    def gn_apply(self, x, stats, gamma, beta, silu, out=None, groups=None):
+        if out is None:
+            out = self.act(x.n, x.h, x.w, x.C)
+        hip.gn_apply(x.v, stats, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
+        self.launches += 1
+        return out
+
+    def groupnorm(self, x, gamma, beta, eps, silu, out=None):
+        return self.gn_apply(x, self.gn_stats(x, eps), gamma, beta, silu, out)
+
+    def spade_apply(self, h, stats, gamma, beta, gb, skip, out=None):
+        if out is None:
+            out = self.act(h.n, h.h, h.w, h.C)
+        hip.spade_apply(h.v, stats, gamma, beta, gb.v, skip.v, out.v, h.n, h.hw, self.GROUPS)
+        self.launches += 1
+        return out
+
+    def layernorm(self, x, gamma, beta, eps=1e-5):
+        xv = x.v if isinstance(x, Act) else x
+        out = self.arena.alloc((xv.shape[0], xv.shape[1]), torch.float16)
+        hip.layernorm(xv, gamma, beta, out, eps)
+        self.launches += 1
+        return Act(out, x.n, x.h, x.w) if isinstance(x, Act) else out
+
+    def from_nchw(self, x, cpad=None):
+        """fp32 NCHW device tensor -> fp16 Act with channels zero-padded to a multiple of 8."""
+        n, c, h, w = x.shape
+        cp = cpad or ((c + 7) // 8 * 8)
+        out = self.act(n, h, w, cp)
+        hip.nchw_to_nhwc(x.contiguous().float(), out.v, cp)
+        self.launches += 1
+        return out
+
+    def to_nchw(self, a, c=None, out=None):
+        c = c or a.C
+        if out is None:
+            out = torch.empty(a.n, c, a.h, a.w, dtype=torch.float32, device=self.device)
+        hip.nhwc_to_nchw(a.v, out)
+        self.launches += 1
+        return out

@@ -245,11 +245,13 @@ def axpby(x, y, a, b):
     return y
 
 
-def ddpm_step(x, eps, noise, coef, step_idx, z):
+def ddpm_step(x, eps, noise, coef, step_idx, z, noise_step_stride=0):
+    """noise: one [n,c,h,w] tensor (stride 0) or a stack indexed by the schedule index (stride = n*c*h*w)."""
     _req_cuda(x, eps, noise, coef, step_idx, z)
     n, c, h, w = x.shape
-    _chk(lib().mgld_ddpm_step(_p(x), _p(eps), _ld(eps), _p(noise), _p(coef), _p(step_idx), _p(z), n, c, h, w, stream_ptr()),
-         "ddpm_step")
+    ld_eps = 0 if eps.dim() == 4 else _ld(eps)   # 4-D eps = NCHW canvas
+    _chk(lib().mgld_ddpm_step(_p(x), _p(eps), ld_eps, _p(noise), C.c_int64(noise_step_stride), _p(coef), _p(step_idx),
+                              _p(z), n, c, h, w, stream_ptr()), "ddpm_step")
     return z
 
 

@@ -1,0 +1,446 @@
+"""KL-VAE encoder and temporal-aware video decoder on the HIP engine.
+
+Interface mirror of ldm/modules/diffusionmodules/model.py (Encoder :473-572, VideoDecoder_Mix :926-1056, ResnetBlock
+:124-183, AttnBlock :192-244, Upsample/Downsample :84-121, ResBlock :1312-1335, Fuse_sft_block_ResidualDenseBlock
+:1354-1367), basicsr/archs/rrdbnet_arch.py:9-38 (ResidualDenseBlock), ldm/modules/distributions/distributions.py:24-40
+and ldm/models/autoencoder.py (AutoencoderKL :299, VideoAutoencoderKLResi :1564-1690): same constructor kwargs, same
+state_dict keys, same encode/decode signatures.
+
+MI355X notes: every 3x3 conv is the MFMA implicit GEMM on NHWC; the dense block's concatenations are slices of one
+growing buffer; the asymmetric (0,1,0,1) pad of the encoder downsample and the nearest-2x upsample are folded into
+the conv gather; the single-head d=512 mid attention runs as two batched GEMMs around an fp32 row softmax.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .engine import Act, Engine, pack_conv1x1, pack_conv3x3, pack_tconv3
+from .unet import SpatialTemporalConv, _meta_module
+
+
+def Normalize(in_channels, num_groups=32):
+    return nn.GroupNorm(num_groups=num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def _conv3(eng, conv, x, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, **kw):
+    w = eng.weight("c3", (conv.weight,), lambda t: pack_conv3x3(t, x.C))
+    return eng.conv3x3(x, w, eng.f32("b", conv.bias), conv.out_channels, out=out, resid=resid, act=act, alpha=alpha, beta=beta,
+                       **kw)
+
+
+def _conv1(eng, conv, x, out=None, resid=None, alpha=1.0, beta=1.0):
+    w = eng.weight("c1", (conv.weight,), lambda t: pack_conv1x1(t, x.C))
+    return eng.linear(x, w, eng.f32("b", conv.bias), out=out, resid=resid, alpha=alpha, beta=beta)
+
+
+def _gn(eng, norm, x, silu):
+    return eng.groupnorm(x, eng.f32("g", norm.weight), eng.f32("b", norm.bias), norm.eps, silu)
+
+
+class Upsample(nn.Module):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1)
+
+    def run(self, eng, x):
+        return _conv3(eng, self.conv, x, up2=True)
+
+
+class Downsample(nn.Module):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
+
+    def run(self, eng, x):
+        # F.pad (0,1,0,1) then stride-2 valid conv (model.py:114-118): pad_t = pad_l = 0, bottom/right implied
+        return _conv3(eng, self.conv, x, stride=2, pad=(0, 0), hw_out=(x.h // 2, x.w // 2))
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout, temb_channels=512):
+        super().__init__()
+        assert not conv_shortcut and temb_channels == 0
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
+
+    def run(self, eng, x, out=None):
+        h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True))
+        skip = x if self.in_channels == self.out_channels else _conv1(eng, self.nin_shortcut, x)
+        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip)
+
+
+class AttnBlock(nn.Module):
+    """single head, d = C (512 at full size): S = q k^T * C^-1/2 (fp32) -> row softmax -> P v."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = nn.Conv2d(in_channels, in_channels, 1)
+        self.k = nn.Conv2d(in_channels, in_channels, 1)
+        self.v = nn.Conv2d(in_channels, in_channels, 1)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, 1)
+
+    def run(self, eng, x):
+        C, N, F = self.in_channels, x.hw, x.n
+        hn = _gn(eng, self.norm, x, False)
+        wqk = eng.weight("qk", (self.q.weight, self.k.weight), lambda q, k: torch.cat([q.reshape(C, C), k.reshape(C, C)], 0))
+        bqk = eng.weight("bqk", (self.q.bias, self.k.bias), lambda q, k: torch.cat([q, k], 0), torch.float32)
+        qk = eng.linear(hn, wqk, bqk).v                                             # [F*N, 2C]
+        wv = eng.weight("c1", (self.v.weight,), pack_conv1x1)
+        vt = eng.arena.alloc((F * C, N), torch.float16)                             # per frame V^T [C, N]
+        hip.igemm(wv, hn.v, vt, bias_m=eng.f32("b", self.v.bias), M=C, N=N, K=C, batch=F, strideA=0,
+                  strideW=N * hn.v.stride(0), strideC=C * N)
+        S = eng.arena.alloc((F * N, N), torch.float32)
+        hip.igemm(qk, qk[:, C:], S, M=N, N=N, K=C, alpha=float(int(C) ** (-0.5)), batch=F, strideA=N * 2 * C,
+                  strideW=N * 2 * C, strideC=N * N)
+        P = eng.arena.alloc((F * N, N), torch.float16)
+        hip.softmax_rows(S, P, F * N, N)
+        o = eng.act(x.n, x.h, x.w, C)
+        hip.igemm(P, vt, o.v, M=N, N=C, K=N, batch=F, strideA=N * N, strideW=C * N, strideC=N * C)
+        eng.launches += 4
+        return _conv1(eng, self.proj_out, o, resid=x)
+
+
+def make_attn(in_channels, attn_type="vanilla"):
+    assert attn_type == "vanilla"
+    return AttnBlock(in_channels)
+
+
+class Encoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, use_linear_attn=False,
+                 attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        assert not attn_resolutions and not use_linear_attn
+        self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, 1, 1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+            down = nn.Module()
+            down.block = block
+            down.attn = nn.ModuleList()
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, 1, 1)
+
+    def run(self, eng, x, fea_out=None):
+        """x: Act (channels padded to 8). Returns (h Act [n, h/8, w/8, 2z], [fea level1, fea level2]).
+        fea_out: optional list of 2 Acts to write the encoder features into (decoder concat buffers)."""
+        h = _conv3(eng, self.conv_in, x)
+        fea = []
+        for lvl in range(self.num_resolutions):
+            nb = len(self.down[lvl].block)
+            for bi, blk in enumerate(self.down[lvl].block):
+                o = None
+                if fea_out is not None and lvl in (1, 2) and bi == nb - 1:
+                    o = fea_out[lvl - 1]
+                h = blk.run(eng, h, out=o)
+            if lvl in (1, 2):
+                fea.append(h)
+            if lvl != self.num_resolutions - 1:
+                h = self.down[lvl].downsample.run(eng, h)
+        h = self.mid.block_1.run(eng, h)
+        h = self.mid.attn_1.run(eng, h)
+        h = self.mid.block_2.run(eng, h)
+        h = _conv3(eng, self.conv_out, _gn(eng, self.norm_out, h, True))
+        return h, fea
+
+
+class ResBlock(nn.Module):
+    """model.py:1312-1335 (fusion-layer residual block: GN/swish/conv x2, 1x1 conv_out on the skip)."""
+
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = in_channels if out_channels is None else out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        if self.in_channels != self.out_channels:
+            self.conv_out = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
+
+    def run(self, eng, x, out=None, resid_extra=None):
+        h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True))
+        skip = x if self.in_channels == self.out_channels else _conv1(eng, self.conv_out, x)
+        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip)
+
+
+class ResidualDenseBlock(nn.Module):
+    """rrdbnet_arch.py:9-38: x1..x4 grow inside one [rows, C+4*32] buffer (no concatenation copies)."""
+
+    def __init__(self, num_feat=64, num_grow_ch=32):
+        super().__init__()
+        self.nf, self.gc = num_feat, num_grow_ch
+        self.conv1 = nn.Conv2d(num_feat, num_grow_ch, 3, 1, 1)
+        self.conv2 = nn.Conv2d(num_feat + num_grow_ch, num_grow_ch, 3, 1, 1)
+        self.conv3 = nn.Conv2d(num_feat + 2 * num_grow_ch, num_grow_ch, 3, 1, 1)
+        self.conv4 = nn.Conv2d(num_feat + 3 * num_grow_ch, num_grow_ch, 3, 1, 1)
+        self.conv5 = nn.Conv2d(num_feat + 4 * num_grow_ch, num_feat, 3, 1, 1)
+
+    def run(self, eng, buf, out_buf):
+        """buf: Act [rows, nf+4gc] whose first nf columns hold x; writes x5*0.2+x into out_buf[:, :nf]."""
+        nf, gc = self.nf, self.gc
+        for i, conv in enumerate([self.conv1, self.conv2, self.conv3, self.conv4]):
+            _conv3(eng, conv, buf.cols(0, nf + i * gc), out=buf.cols(nf + i * gc, nf + (i + 1) * gc), act=hip.ACT_LRELU02)
+        return _conv3(eng, self.conv5, buf, out=out_buf.cols(0, nf), resid=buf.cols(0, nf), alpha=0.2, beta=1.0)
+
+
+class Fuse_sft_block_ResidualDenseBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, num_block=1, num_grow_ch=32):
+        super().__init__()
+        self.in_ch, self.gc = in_ch, num_grow_ch
+        self.encode_enc_1 = ResBlock(2 * in_ch, in_ch)
+        self.encode_enc_2 = nn.Sequential(*[ResidualDenseBlock(num_feat=in_ch, num_grow_ch=num_grow_ch) for _ in range(num_block)])
+        self.encode_enc_3 = ResBlock(in_ch, out_ch)
+
+    def run(self, eng, cat, w):
+        """cat: Act [rows, 2*in_ch] = [enc_feat | dec_feat]; returns dec_feat + w * f(cat)."""
+        dec = cat.cols(self.in_ch, 2 * self.in_ch)
+        width = self.in_ch + 4 * self.gc
+        bufs = [eng.act(cat.n, cat.h, cat.w, width) for _ in range(len(self.encode_enc_2) + 1)]
+        self.encode_enc_1.run(eng, cat, out=bufs[0].cols(0, self.in_ch))
+        for i, blk in enumerate(self.encode_enc_2):
+            blk.run(eng, bufs[i], bufs[i + 1])
+        e = self.encode_enc_3.run(eng, bufs[-1].cols(0, self.in_ch))
+        out = eng.act(cat.n, cat.h, cat.w, self.in_ch)
+        hip.copy2d(dec.v, out.v)
+        hip.axpby(e.v, out.v, float(w), 1.0)
+        eng.launches += 2
+        return out
+
+
+class VideoDecoder_Mix(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, num_frames=1, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False,
+                 use_linear_attn=False, attn_type="vanilla", num_fuse_block=2, fusion_w=1.0, **ignorekwargs):
+        super().__init__()
+        assert not attn_resolutions and not give_pre_end and not tanh_out
+        self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels, self.num_frames, self.fusion_w = resolution, in_channels, num_frames, fusion_w
+        self.out_ch = out_ch
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, 1, 1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.temporal_mixing = SpatialTemporalConv(num_feat=block_in, num_frames=num_frames)
+        self.mid.attn_1 = make_attn(block_in, attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, temporal_mixing = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            if i_level != self.num_resolutions - 1 and i_level != 0:
+                setattr(self, f"fusion_layer_{i_level}",
+                        Fuse_sft_block_ResidualDenseBlock(in_ch=block_out, out_ch=block_out, num_block=num_fuse_block))
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+                temporal_mixing.append(SpatialTemporalConv(num_feat=block_in, num_frames=num_frames))
+            up = nn.Module()
+            up.block, up.temporal_mixing, up.attn = block, temporal_mixing, nn.ModuleList()
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+            self.up.insert(0, up)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
+
+    def run(self, eng, z, enc_fea):
+        """z: Act [n,h,w,8] (post_quant_conv output, padded); enc_fea: [Act level1 (H/2), Act level2 (H/4)].
+        Returns fp32 token-major output Act [n*H*W, out_ch]."""
+        h = _conv3(eng, self.conv_in, z)
+        h = self.mid.block_1.run(eng, h)
+        h = self.temporal_mixing.run(eng, h)
+        h = self.mid.attn_1.run(eng, h)
+        h = self.mid.block_2.run(eng, h)
+        for lvl in reversed(range(self.num_resolutions)):
+            fuse = lvl != self.num_resolutions - 1 and lvl != 0
+            nb = self.num_res_blocks + 1
+            cat = None
+            for b in range(nb):
+                h = self.up[lvl].block[b].run(eng, h)
+                o = None
+                if fuse and b == nb - 1:
+                    ef = enc_fea[lvl - 1]
+                    cat = eng.act(h.n, h.h, h.w, ef.C + h.C)
+                    hip.copy2d(ef.v, cat.v[:, :ef.C])
+                    eng.launches += 1
+                    o = cat.cols(ef.C, ef.C + h.C)
+                h = self.up[lvl].temporal_mixing[b].run(eng, h, out=o)
+            if fuse:
+                h = getattr(self, f"fusion_layer_{lvl}").run(eng, cat, self.fusion_w)
+            if lvl != 0:
+                h = self.up[lvl].upsample.run(eng, h)
+        t = _gn(eng, self.norm_out, h, True)
+        out = Act(eng.arena.alloc((h.rows, self.out_ch), torch.float32), h.n, h.h, h.w)
+        return _conv3(eng, self.conv_out, t, out=out)
+
+
+class DiagonalGaussianDistribution(object):
+    """ldm/modules/distributions/distributions.py:24-40 (device tensors, fp32)."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if self.deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, noise=None):
+        if noise is None:  # the reference draws on the CPU then moves (distributions.py:35-37)
+            noise = torch.randn(self.mean.shape)
+        return self.mean + self.std * noise.to(self.parameters.device)
+
+    def mode(self):
+        return self.mean
+
+
+class _AutoencoderBase(nn.Module):
+    def engine(self):
+        if self._engine is None:
+            self._engine = Engine()
+        return self._engine
+
+    def set_engine(self, eng):
+        self._engine = eng
+
+    def _finish_init(self):
+        self.to_empty(device="cpu")
+        for p in self.parameters():
+            p.data.zero_()
+            p.requires_grad_(False)
+        self._engine = None
+
+    def _moments(self, eng, x, fea_out=None):
+        """x: NCHW fp32 device tensor -> (moments NCHW fp32 [n, 2*embed, h/8, w/8], [fea Acts])."""
+        xa = eng.from_nchw(x)
+        h, fea = self.encoder.run(eng, xa, fea_out=fea_out)
+        m = Act(eng.arena.alloc((h.rows, 2 * self.embed_dim), torch.float32), h.n, h.h, h.w)
+        wq = eng.weight("c1", (self.quant_conv.weight,), lambda t: pack_conv1x1(t, h.C))
+        eng.linear(h, wq, eng.f32("b", self.quant_conv.bias), out=m)
+        return eng.to_nchw(m, 2 * self.embed_dim), fea
+
+    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
+        """autoencoder.py:1652-1672: accepts full-model checkpoints by stripping the `first_stage_model.` prefix."""
+        sd = torch.load(path, map_location="cpu")
+        if "state_dict" in sd:
+            sd = sd["state_dict"]
+        for k in list(sd.keys()):
+            if "first_stage_model" in k:
+                sd[k[18:]] = sd.pop(k)
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        return missing
+
+
+class AutoencoderKL(_AutoencoderBase):
+    """ldm/models/autoencoder.py:299 — only the encode path is on the VSR hot path (init latent, ddpm.py:3906-3943)."""
+
+    def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=[], image_key="image",
+                 colorize_nlabels=None, monitor=None, **kw):
+        super().__init__()
+        self.embed_dim = embed_dim
+        with _meta_module():
+            self.encoder = Encoder(**ddconfig)
+            self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+            self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self._finish_init()
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+
+    def load_state_dict(self, sd, strict=True):
+        # public SD checkpoints also hold decoder.* weights of the image decoder, unused by the VSR path
+        own = set(self.state_dict().keys())
+        return super().load_state_dict({k: v for k, v in sd.items() if k in own or not k.startswith("decoder.")}, strict=strict)
+
+    @torch.no_grad()
+    def encode(self, x):
+        eng = self.engine()
+        eng.reset()
+        m, _ = self._moments(eng, x.to(eng.device, torch.float32))
+        return DiagonalGaussianDistribution(m)
+
+
+class VideoAutoencoderKLResi(_AutoencoderBase):
+    """ldm/models/autoencoder.py:1564-1690: encode(x) -> (posterior, enc_fea); decode(z, enc_fea) -> frames."""
+
+    def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=[], image_key="image",
+                 colorize_nlabels=None, monitor=None, fusion_w=1.0, freeze_dec=True, synthesis_data=False, use_usm=False,
+                 test_gt=False, version=1):
+        super().__init__()
+        assert version == 1, "VideoDecoder_MixV2 is not on the MGLD-VSR hot path"
+        self.embed_dim = embed_dim
+        with _meta_module():
+            self.encoder = Encoder(**ddconfig)
+            self.decoder = VideoDecoder_Mix(**ddconfig)
+            self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+            self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self._finish_init()
+        self.decoder.fusion_w = fusion_w
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+
+    @torch.no_grad()
+    def encode(self, x):
+        """-> (DiagonalGaussianDistribution, [fea1, fea2]); features stay on the device as NHWC fp16 Acts."""
+        eng = self.engine()
+        eng.reset()
+        m, fea = self._moments(eng, x.to(eng.device, torch.float32))
+        # features outlive the arena pass: move them to owned storage
+        keep = []
+        for f in fea:
+            t = torch.empty(f.rows, f.C, dtype=torch.float16, device=eng.device)
+            hip.copy2d(f.v, t)
+            keep.append(Act(t, f.n, f.h, f.w))
+        return DiagonalGaussianDistribution(m), keep
+
+    @torch.no_grad()
+    def decode(self, z, enc_fea):
+        eng = self.engine()
+        eng.reset()
+        z = z.to(eng.device, torch.float32)
+        fea = [f if isinstance(f, Act) else eng.from_nchw(f.to(eng.device, torch.float32)) for f in enc_fea]
+        za = eng.from_nchw(z)
+        wq = eng.weight("c1", (self.post_quant_conv.weight,), lambda t: pack_conv1x1(t, za.C))
+        # post_quant_conv output padded to 8 channels (zero weight rows) so conv_in sees Cin % 8 == 0
+        zq = eng.act(za.n, za.h, za.w, 8)
+        zq.v.zero_()
+        eng.linear(za, wq, eng.f32("b", self.post_quant_conv.bias), out=zq.cols(0, self.post_quant_conv.out_channels))
+        out = self.decoder.run(eng, zq, fea)
+        return eng.to_nchw(out, self.decoder.out_ch)
+
+    def forward(self, input, latent, sample_posterior=True):
+        posterior, enc_fea = self.encode(input)
+        return self.decode(latent, enc_fea), posterior

@@ -1,0 +1,172 @@
+"""GPU parity of the networks and the sampler: product path (ldm.* drop-in classes -> libmgld_hip through the C ABI)
+vs the golden vectors produced by the reference and vs the oracle on the same seeded inputs.
+
+Tolerances (relative L2, stated per test): the product computes with fp16 operands / fp32 accumulation (the
+reference's GPU precision is fp16 autocast); the fp32 CPU reference is the truth.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from configs import STRUCT_FULL, STRUCT_SMALL, T, UNET_FULL, UNET_SMALL, VAE_DD_FULL, VAE_DD_SMALL  # noqa: E402
+from mgld_vsr_amd import synth  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+from oracle import sampler as osamp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+METRICS = {}
+
+
+def G(name):
+    d = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    return {k: (torch.from_numpy(d[k]) if d[k].dtype.kind in "fiu" else d[k]) for k in d.files}
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double().flatten(), b.detach().cpu().double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def record(name, val):
+    METRICS[name] = val
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_metrics.json"), "w") as fh:
+            json.dump(METRICS, fh, indent=1, sort_keys=True)
+    return val
+
+
+@pytest.fixture(scope="module")
+def small_nets(hip):
+    from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
+    unet = synth.fill_module_(InflatedUNetModelDualcondV2(**UNET_SMALL), "unet")
+    sc = synth.fill_module_(InflatedEncoderUNetModelWT(**STRUCT_SMALL), "structcond")
+    return unet, sc
+
+
+def test_structcond_small_vs_golden(hip, small_nets):
+    _, sc = small_nets
+    g = G("g_unet")
+    out = sc(g["lat"].cuda(), g["t"].cuda())
+    assert set(out.keys()) == {"16", "8", "4", "2"}
+    for k, v in out.items():
+        assert record(f"structcond_small_{k}", rel_l2(v, g[f"sc_{k}"])) < 5e-3
+
+
+def test_unet_small_vs_golden(hip, small_nets):
+    unet, _ = small_nets
+    g = G("g_unet")
+    sc = {k[3:]: v.cuda() for k, v in g.items() if k.startswith("sc_")}
+    eps = unet(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].cuda(), struct_cond=sc)
+    assert record("unet_small", rel_l2(eps, g["eps"])) < 5e-3
+    # per-frame (non-uniform) timesteps go through the M = n embedding path
+    t2 = torch.tensor([541, 20, 999])
+    usd = {k: v for k, v in unet.state_dict().items()}
+    sc_cpu = {k[3:]: v for k, v in g.items() if k.startswith("sc_")}
+    ref = onets.unet_forward(usd, UNET_SMALL, g["x"], t2, g["ctx"], sc_cpu)
+    eps2 = unet(g["x"].cuda(), t2.cuda(), context=g["ctx"].cuda(), struct_cond=sc)
+    assert record("unet_small_mixed_t", rel_l2(eps2, ref)) < 5e-3
+
+
+def test_vae_small_vs_golden(hip):
+    from ldm.models.autoencoder import AutoencoderKL, VideoAutoencoderKLResi
+    g = G("g_vae")
+    vq = synth.fill_module_(VideoAutoencoderKLResi(ddconfig=dict(VAE_DD_SMALL), lossconfig={"target": "torch.nn.Identity"},
+                                                   embed_dim=4), "vae")
+    post, fea = vq.encode(g["x"].cuda())
+    assert record("vae_small_mean", rel_l2(post.mean, g["mean"])) < 5e-3
+    assert record("vae_small_logvar", rel_l2(post.logvar, g["logvar"])) < 5e-3
+    from mgld_vsr_amd.engine import Engine
+    f0 = vq.engine().to_nchw(fea[0])
+    f1 = vq.engine().to_nchw(fea[1])
+    assert record("vae_small_fea0", rel_l2(f0, g["fea0"])) < 5e-3 and record("vae_small_fea1", rel_l2(f1, g["fea1"])) < 5e-3
+    dec = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])
+    assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 5e-3
+    vq.decoder.fusion_w = 0.5
+    dec05 = vq.decode(g["z"].cuda(), fea)
+    assert record("vae_small_dec_w05", rel_l2(dec05, g["dec_w05"])) < 5e-3
+    from scripts.wavelet_color_fix import adaptive_instance_normalization, wavelet_reconstruction
+    assert rel_l2(adaptive_instance_normalization(g["dec"], g["style"]), g["adain"]) < 1e-5
+    assert rel_l2(wavelet_reconstruction(g["dec"], g["style"]), g["wavelet"]) < 1e-5
+    # first-stage (image) encoder
+    gf = G("g_first_stage")
+    dd = dict(VAE_DD_SMALL)
+    dd.pop("num_frames")
+    fs = synth.fill_module_(AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4), "first_stage")
+    post = fs.encode(gf["x"].cuda())
+    assert record("first_stage_mean", rel_l2(post.mean, gf["mean"])) < 5e-3
+
+
+def _small_model():
+    from test_host_cpu import _small_model as mk
+    m = mk()
+    synth.fill_module_(m.model.diffusion_model, "unet")
+    synth.fill_module_(m.structcond_stage_model, "structcond")
+    synth.fill_module_(m.first_stage_model, "first_stage")
+    return m
+
+
+def _respace(model, S):
+    from ldm.models.diffusion.ddpm import space_timesteps
+    model.register_schedule(given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.0120)
+    use = set(space_timesteps(1000, [S]))
+    last, nb = 1.0, []
+    for i, ac in enumerate(model.alphas_cumprod):
+        if i in use:
+            nb.append(1 - ac / last)
+            last = ac
+    model.register_schedule(given_betas=np.array([b.data.cpu().numpy() for b in nb]), timesteps=len(nb))
+    model.num_timesteps = 1000
+    model.ori_timesteps = sorted(list(use))
+
+
+@pytest.mark.parametrize("tag", ["plain", "canvas"])
+def test_sample_small_vs_golden(hip, tag):
+    g = G("g_sample")
+    model = _small_model()
+    S = 4
+    _respace(model, S)
+    # reference noise list is in loop order (i = S-1 .. 0); the product indexes noise by schedule index i
+    noise = torch.flip(g[f"{tag}_noise"], dims=[0])
+    flows = (g[f"{tag}_ff"][None], g[f"{tag}_fb"][None])
+    masks = (g[f"{tag}_focc"][None, :, None], g[f"{tag}_bocc"][None, :, None])
+    kw = dict(cond=g[f"{tag}_ctx"], struct_cond=g[f"{tag}_lat"], guidance_scale=-10.0, batch_size=1, timesteps=S,
+              time_replace=S, x_T=g[f"{tag}_xT"], noise=noise)
+    fn = model.sample if tag == "plain" else (lambda **k: model.sample_canvas(tile_size=16, tile_overlap=8, batch_size_sample=1, **k))
+    x0_ng = fn(**kw)
+    assert record(f"sample_{tag}_noguid", rel_l2(x0_ng, g[f"{tag}_x0_noguid"])) < 1e-2
+    x0 = fn(flows=flows, masks=masks, **kw)
+    assert record(f"sample_{tag}_guided", rel_l2(x0, g[f"{tag}_x0"])) < 2e-2
+    # hipGraph replay == eager launches, bit for bit
+    x0_eager = fn(flows=flows, masks=masks, use_graph=False, **kw)
+    assert torch.equal(x0_eager, x0)
+    loss = model.compute_temporal_condition_v4(flows, x0, masks)
+    assert torch.isfinite(loss)
+
+
+def test_unet_fullwidth_vs_oracle(hip):
+    """full-width nets (320 / 256 base channels, 1024-d context), 2 frames at a 32x32 latent, vs the fp32 oracle."""
+    from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    ucfg, scfg = dict(UNET_FULL, num_frames=2), dict(STRUCT_FULL, num_frames=2)
+    unet = synth.fill_module_(InflatedUNetModelDualcondV2(**ucfg), "unet")
+    sc = synth.fill_module_(InflatedEncoderUNetModelWT(**scfg), "structcond")
+    x, lat = synth.synth_tensor("full/x", (2, 4, 32, 32)), synth.synth_tensor("full/lat", (2, 4, 32, 32), 0.5)
+    ctx = synth.synth_tensor("ctx", (1, 77, 1024))
+    t = torch.tensor([541, 541])
+    with torch.no_grad():
+        sc_ref = onets.structcond_forward(sc.state_dict(), scfg, lat, t)
+        eps_ref = onets.unet_forward(unet.state_dict(), ucfg, x, t, ctx, sc_ref)
+    sc_out = sc(lat.cuda(), t.cuda())
+    for k in sc_ref:
+        assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < 5e-3
+    eps = unet(x.cuda(), t.cuda(), context=ctx.cuda(), struct_cond={k: v.cuda() for k, v in sc_ref.items()})
+    assert record("unet_full", rel_l2(eps, eps_ref)) < 5e-3
