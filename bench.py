@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py — HR frames/s of the MGLD-VSR per-segment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic segment per GPU: VAE encode (x2, as the reference script
+does: init latent + decoder features) -> 50-step respaced DDPM sampling over the struct-cond encoder + UNet ->
+temporal-aware VAE sequence decode -> AdaIN colour fix.  Workload = BASELINE.json configs[1]: 8 frames at 512x512
+(latent 64x64x4), 50 DDPM steps, random-init weights of the shipped architecture, flow warp off.  Inputs are resident
+in HBM when the timed region starts.  N>1: one process per GPU (torch.distributed / RCCL), each rank owns its own
+segment (segments are independent in the reference: no data-path collective) -> weak scaling.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP16_TFLOPS = 2500.0   # dense MFMA fp16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic work per HR frame (measured with FlopCounterMode on the reference)
+GFLOP_STEP_PER_FRAME = 967.4
+GFLOP_ENC_PER_FRAME = 1116.7
+GFLOP_DEC_PER_FRAME = 4139.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ddpm-steps", type=int, default=50)
+    ap.add_argument("--guidance", action="store_true", help="flow-guided latent warp on (configs[2]); default off (configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    if n <= 1:
+        return 0, 1, 0
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def build_pipeline(args):
+    from mgld_vsr_amd import build
+    build.build(verbose=False)
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    cfgs = None
+    if args.small:
+        cfgs = model_configs(args.frames, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                             struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                             vae_overrides=dict(ch=32), context_dim=64)
+    else:
+        cfgs = model_configs(args.frames)
+    return VSRPipeline(num_frames=args.frames, ddpm_steps=args.ddpm_steps, configs=cfgs)
+
+
+def make_inputs(pipe, args, rank):
+    from mgld_vsr_amd import synth
+    T, S, H = args.frames, args.ddpm_steps, args.size
+    dev = pipe.engine().device
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    frames = (torch.rand(T, 3, H, H, generator=g) * 2 - 1).to(dev)            # U(-1,1) LR-upsampled frames
+    h = H // 8
+    noise = {"posterior": torch.randn(T, 4, h, h, generator=g).to(dev), "x_T": torch.randn(T, 4, h, h, generator=g).to(dev),
+             "steps": torch.randn(S, T, 4, h, h, generator=g).to(dev)}
+    flows = masks = None
+    if args.guidance:
+        from mgld_vsr_amd.flowops import forward_backward_consistency_check
+        ff, fb = synth.smooth_flow("bench/ff", T - 1, h, h).to(dev), synth.smooth_flow("bench/fb", T - 1, h, h).to(dev)
+        fo, bo = forward_backward_consistency_check(fb, ff)
+        flows, masks = (ff[None], fb[None]), (fo[None, :, None], bo[None, :, None])
+    return frames, noise, flows, masks
+
+
+def roofline(pipe, args, frames, noise, flows, masks):
+    """Dominant kernel = the 128x128-tile MFMA implicit GEMM.  Collect every igemm problem of one full pass, then time
+    each distinct problem of that tile config in isolation with hipEvents (10 back-to-back launches on the launch
+    stream) and weight by its launch count:  achieved = sum(flops) / sum(count * avg_duration)."""
+    from mgld_vsr_amd import hip
+    hip.IGEMM_LOG = []
+    pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, use_graph=False)
+    torch.cuda.synchronize()
+    log, hip.IGEMM_LOG = hip.IGEMM_LOG, None
+    groups = {}
+    for p in log:
+        cfg = hip.igemm_config(p)
+        key = (cfg, p.mode, p.M, p.N, p.K, p.Cin, p.Hin, p.Win, p.stride, p.up2, p.act, max(1, p.batch), p.lda, p.ldc)
+        g = groups.setdefault(key, {"p": p, "count": 0, "flops": hip.igemm_flops(p), "cfg": cfg})
+        g["count"] += 1
+    tot = {}
+    e0, e1 = hip.Event(), hip.Event()
+    for key, g in groups.items():
+        for _ in range(2):
+            hip.igemm_relaunch(g["p"])
+        e0.record()
+        for _ in range(10):
+            hip.igemm_relaunch(g["p"])
+        e1.record()
+        e1.sync()
+        g["ms"] = e0.elapsed_ms(e1) / 10.0
+        t = tot.setdefault(g["cfg"], {"flops": 0.0, "ms": 0.0, "launches": 0})
+        t["flops"] += g["flops"] * g["count"]
+        t["ms"] += g["ms"] * g["count"]
+        t["launches"] += g["count"]
+    dom_cfg = max(tot, key=lambda c: tot[c]["ms"])
+    d = tot[dom_cfg]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    all_flops = sum(t["flops"] for t in tot.values())
+    all_ms = sum(t["ms"] for t in tot.values())
+    return {
+        "bound": "mfma", "kernel": f"igemm_kernel<{dom_cfg // 1000},{dom_cfg % 1000}>", "achieved": round(achieved, 2),
+        "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
+        "launches_per_segment": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+        "kernel_ms_per_segment": round(d["ms"], 2),
+        "all_igemm": {"tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "ms_per_segment": round(all_ms, 2),
+                      "gflop_per_segment": round(all_flops / 1e9, 1)},
+    }
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement, fp32, 32 torch threads) on a bounded sample: ONE frame at 512x512 through one
+    DDPM step (struct-cond + UNet), one VAE encode and one VAE video decode; extrapolated to the 50-step pipeline."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
+    from mgld_vsr_amd import synth
+    from oracle import nets as onets
+    cores = min(32, os.cpu_count() or 1)   # more threads than this thrash on the small per-layer problems
+    torch.set_num_threads(cores)
+    ucfg, scfg, vdd = dict(UNET_FULL, num_frames=1), dict(STRUCT_FULL, num_frames=1), dict(VAE_DD_FULL, num_frames=1)
+    from ldm.models.autoencoder import VideoAutoencoderKLResi
+    from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
+
+    def names(m):
+        return [(k, tuple(v.shape)) for k, v in m.state_dict().items() if v.is_floating_point()]
+    usd = synth.synth_state_dict(names(InflatedUNetModelDualcondV2(**ucfg)), "unet")
+    ssd = synth.synth_state_dict(names(InflatedEncoderUNetModelWT(**scfg)), "structcond")
+    vsd = synth.synth_state_dict(names(VideoAutoencoderKLResi(ddconfig=vdd, lossconfig={"target": "torch.nn.Identity"},
+                                                              embed_dim=4)), "vae")
+    h = args.size // 8
+    x, lat = synth.synth_tensor("cpu/x", (1, 4, h, h)), synth.synth_tensor("cpu/lat", (1, 4, h, h), 0.5)
+    ctx = synth.synth_tensor("ctx", (1, 77, 1024))
+    img = synth.synth_tensor("cpu/img", (1, 3, args.size, args.size), 0.5)
+    t = torch.tensor([541])
+    with torch.no_grad():
+        t0 = time.time()
+        sc = onets.structcond_forward(ssd, scfg, lat, t)
+        onets.unet_forward(usd, ucfg, x, t, ctx, sc)
+        t_step = time.time() - t0
+        t0 = time.time()
+        _, _, fea = onets.vae_moments(vsd, vdd, img)
+        t_enc = time.time() - t0
+        t0 = time.time()
+        onets.vae_decode(vsd, vdd, x, fea)
+        t_dec = time.time() - t0
+    per_frame = args.ddpm_steps * t_step + 2 * t_enc + t_dec
+    return {"value": round(1.0 / per_frame, 5), "unit": "HR frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 on 1 frame {args.size}x{args.size}: 1 DDPM step (struct-cond+UNet) {t_step:.2f}s, "
+                      f"1 VAE encode {t_enc:.2f}s, 1 VAE video-decode {t_dec:.2f}s; extrapolated to "
+                      f"{args.ddpm_steps} steps + 2 encodes + 1 decode per frame"}
+
+
+def main():
+    args = parse()
+    rank, world, local = dist_setup(args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local)
+    pipe = build_pipeline(args)
+    frames, noise, flows, masks = make_inputs(pipe, args, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.run_segment(frames, flows=flows, masks=masks, noise=noise)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe.run_segment(frames, flows=flows, masks=masks, noise=noise)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    ok = bool(torch.isfinite(out).all())
+    ms_per_step = 1e3 * dt / args.steps
+    fps = world * args.frames * args.steps / dt
+    res = {
+        "metric": "HR frames/sec at 512^2, 50 DDPM steps", "value": round(fps, 4), "unit": "HR frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"{args.frames}-frame {args.size}x{args.size} sequence (latent {args.size // 8}x{args.size // 8}x4), "
+                               f"{args.ddpm_steps} DDPM steps, random-init SD-2.1 UNet + struct-cond encoder + KL-VAE encode x2 "
+                               f"+ temporal video decoder + AdaIN, flow-guided warp {'on' if args.guidance else 'off'}; "
+                               "one segment per GPU",
+                   "frames_per_segment": args.frames, "parallelism": f"segment-parallel x{world}", "finite": ok,
+                   "reduced_width": bool(args.small)},
+        "sustained_tflops": round(world * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
+                                                          GFLOP_DEC_PER_FRAME) / 1e3 / (dt / args.steps), 1),
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            res["roofline"] = roofline(pipe, args, frames, noise, flows, masks)
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,8 @@ typedef struct MgldIGemm {
 } MgldIGemm;
 
 int mgld_igemm(const MgldIGemm* p, void* stream);
+/* block tile the launcher selects for this problem, encoded BM*1000+BN (profiling / roofline bookkeeping) */
+int mgld_igemm_config(const MgldIGemm* p);
 
 /* ---- K3: GroupNorm (32 groups) on NHWC fp16, fp32 statistics -----------------------------------------------
  * Replaces nn.GroupNorm / GroupNorm32 (diffusionmodules/util.py:214-216, model.py:80-81, attention.py:87-88).

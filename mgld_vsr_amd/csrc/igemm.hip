@@ -292,18 +292,27 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   if (p->rowvec) MGLD_REQUIRE(p->rows_per_frame > 0, "igemm: rows_per_frame");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
+  switch (mgld_igemm_config(p)) {
+    case 128128: return launch_cfg<128, 128, 64, 64>(p, s);
+    case 64128: return launch_cfg<64, 128, 32, 64>(p, s);
+    case 128032: return launch_cfg<128, 32, 32, 32>(p, s);
+    case 128064: return launch_cfg<128, 64, 64, 32>(p, s);
+    default: return launch_cfg<64, 64, 32, 32>(p, s);
+  }
+}
+
+// tile configuration the launcher picks for a problem: BM*1000 + BN
+extern "C" int mgld_igemm_config(const MgldIGemm* p) {
+  if (!p) return 0;
   const int64_t M = p->M, N = p->N;
   const int batch = p->batch > 0 ? p->batch : 1;
   const int64_t blocks128 = (int64_t)cdiv(M, 128) * cdiv(N, 128) * batch;
-  if (p->act == MGLD_ACT_GEGLU) {
-    if (blocks128 >= 256 || M <= 64) return launch_cfg<128, 128, 64, 64>(p, s);
-    return launch_cfg<64, 128, 32, 64>(p, s);
-  }
-  if (N <= 32) return launch_cfg<128, 32, 32, 32>(p, s);
-  if (N <= 64) return launch_cfg<128, 64, 64, 32>(p, s);
-  if (blocks128 >= 512) return launch_cfg<128, 128, 64, 64>(p, s);
+  if (p->act == MGLD_ACT_GEGLU) return (blocks128 >= 256 || M <= 64) ? 128128 : 64128;
+  if (N <= 32) return 128032;
+  if (N <= 64) return 128064;
+  if (blocks128 >= 512) return 128128;
   // not enough 128x128 tiles to fill 256 CUs: shrink the tile
   const int64_t blocks64x128 = (int64_t)cdiv(M, 64) * cdiv(N, 128) * batch;
-  if (blocks64x128 >= 512) return launch_cfg<64, 128, 32, 64>(p, s);
-  return launch_cfg<64, 64, 32, 32>(p, s);
+  if (blocks64x128 >= 512) return 64128;
+  return 64064;
 }

@@ -51,7 +51,7 @@ EXPORTS = [
     "mgld_version", "mgld_last_error", "mgld_device_info",
     "mgld_graph_begin", "mgld_graph_end", "mgld_graph_launch", "mgld_graph_destroy",
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
-    "mgld_igemm", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_layernorm",
+    "mgld_igemm", "mgld_igemm_config", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_layernorm",
     "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows",
     "mgld_linear_small", "mgld_timestep_embedding",
     "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
@@ -136,8 +136,26 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
         p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = conv
     elif mode == MODE_TCONV3:
         p.Cin, p.T, p.HW = tconv
+    if IGEMM_LOG is not None:
+        IGEMM_LOG.append(MgldIGemm.from_buffer_copy(p))
     _chk(lib().mgld_igemm(C.byref(p), stream_ptr()), "igemm")
     return out
+
+
+IGEMM_LOG = None   # bench.py sets this to a list to collect the igemm problems of one pass (roofline bookkeeping)
+
+
+def igemm_relaunch(p):
+    _chk(lib().mgld_igemm(C.byref(p), stream_ptr()), "igemm")
+
+
+def igemm_config(p):
+    return lib().mgld_igemm_config(C.byref(p))
+
+
+def igemm_flops(p):
+    n_batch = max(1, p.batch)
+    return 2.0 * p.M * p.N * p.K * n_batch
 
 
 def gn_chunks(rows):

@@ -1,0 +1,133 @@
+"""Per-segment inference pipeline: the body of the reference's inference loop
+(scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py:296-329 model/schedule setup, :375-475 per-segment work)
+as a reusable object.  Everything between "LR segment resident in HBM" and "HR frames resident in HBM" runs as
+libmgld_hip launches on one stream.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import hip, synth
+from .ddpm import space_timesteps
+from .flowops import adaptive_instance_normalization, wavelet_reconstruction
+from .util import instantiate_from_config
+
+
+def model_configs(num_frames=5, unet_overrides=None, struct_overrides=None, vae_overrides=None, context_dim=1024):
+    """The `model:` sections of configs/mgldvsr/mgldvsr_512_realbasicvsr_deg.yaml:2-120 and
+    configs/video_vae/video_autoencoder_kl_64x64x4_resi.yaml:1-54 as plain dicts (same targets / params)."""
+    dd = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    dd.update(vae_overrides or {})
+    unet = dict(num_frames=num_frames, image_size=32, in_channels=4, out_channels=4, model_channels=320,
+                attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_head_channels=64,
+                use_spatial_transformer=True, use_linear_in_transformer=True, transformer_depth=1, context_dim=context_dim,
+                use_checkpoint=False, legacy=False, semb_channels=256)
+    unet.update(unet_overrides or {})
+    struct = dict(num_frames=num_frames, image_size=96, in_channels=4, model_channels=256, out_channels=256,
+                  num_res_blocks=2, attention_resolutions=[4, 2, 1], dropout=0, channel_mult=[1, 1, 2, 2], conv_resample=True,
+                  dims=2, use_checkpoint=False, use_fp16=False, num_heads=4, num_head_channels=-1, num_heads_upsample=-1,
+                  use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False)
+    struct.update(struct_overrides or {})
+    diffusion = {
+        "target": "ldm.models.diffusion.ddpm.LatentDiffusionVSRTextWT",
+        "params": dict(
+            linear_start=0.00085, linear_end=0.0120, num_timesteps_cond=1, log_every_t=200, timesteps=1000,
+            first_stage_key="image", cond_stage_key="caption", image_size=512, channels=4, num_frames=num_frames,
+            cond_stage_trainable=False, conditioning_key="crossattn", monitor="val/loss_simple_ema", scale_factor=0.18215,
+            use_ema=False, train_temporal_module=True, unfrozen_diff=False, random_size=False, time_replace=1000, use_usm=True,
+            unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedUNetModelDualcondV2", "params": unet},
+            first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                                "params": {"embed_dim": 4, "monitor": "val/rec_loss", "ddconfig": dict(dd),
+                                           "lossconfig": {"target": "torch.nn.Identity"}}},
+            cond_stage_config={"target": "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
+                               "params": {"freeze": True, "layer": "penultimate", "device": "cuda", "context_dim": context_dim}},
+            structcond_stage_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedEncoderUNetModelWT",
+                                     "params": struct},
+            flownet_config={"target": "basicsr.archs.raft_arch.RAFT_SR", "params": {"model": "normal", "load_path": None}}),
+    }
+    vae = {
+        "target": "ldm.models.autoencoder.VideoAutoencoderKLResi",
+        "params": dict(monitor="val/rec_loss", embed_dim=4, fusion_w=1.0, freeze_dec=True, synthesis_data=False, version=1,
+                       lossconfig={"target": "torch.nn.Identity"}, ddconfig=dict(dd, num_frames=num_frames)),
+    }
+    return diffusion, vae
+
+
+class VSRPipeline:
+    def __init__(self, num_frames=5, ddpm_steps=50, dec_w=1.0, colorfix_type="adain", synthetic_weights=True, configs=None,
+                 chunk_bytes=4 << 30):
+        dcfg, vcfg = configs or model_configs(num_frames)
+        self.model = instantiate_from_config(dcfg)
+        self.vq_model = instantiate_from_config(vcfg)
+        self.vq_model.decoder.fusion_w = dec_w
+        self.num_frames, self.ddpm_steps, self.colorfix_type = num_frames, ddpm_steps, colorfix_type
+        if synthetic_weights:
+            synth.fill_module_(self.model.model.diffusion_model, "unet")
+            synth.fill_module_(self.model.structcond_stage_model, "structcond")
+            synth.fill_module_(self.model.first_stage_model, "first_stage")
+            synth.fill_module_(self.vq_model, "vae")
+        self._setup_schedule(ddpm_steps)
+        self.chunk_bytes = chunk_bytes
+
+    def _setup_schedule(self, steps):
+        """oldcanvas_tile.py:308-329"""
+        m = self.model
+        m.register_schedule(given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=0.00085,
+                            linear_end=0.0120, cosine_s=8e-3)
+        m.num_timesteps = 1000
+        self.sqrt_alphas_cumprod = copy.deepcopy(m.sqrt_alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = copy.deepcopy(m.sqrt_one_minus_alphas_cumprod)
+        use = set(space_timesteps(1000, [steps]))
+        last, nb = 1.0, []
+        for i, ac in enumerate(m.alphas_cumprod):
+            if i in use:
+                nb.append(1 - ac / last)
+                last = ac
+        m.register_schedule(given_betas=np.array([b.data.cpu().numpy() for b in nb]), timesteps=len(nb))
+        m.num_timesteps = 1000
+        m.ori_timesteps = sorted(list(use))
+
+    def engine(self):
+        from .engine import Engine
+        if self.model._engine is None:
+            self.model._engine = Engine(chunk_bytes=self.chunk_bytes)
+            for sub in (self.model.model.diffusion_model, self.model.structcond_stage_model, self.model.first_stage_model,
+                        self.vq_model):
+                sub.set_engine(self.model._engine)
+        return self.model._engine
+
+    @torch.no_grad()
+    def run_segment(self, frames, flows=None, masks=None, guidance_scale=-10.0, noise=None, tile=None, use_graph=True,
+                    return_latents=False):
+        """frames: [T,3,H,W] in [-1,1] (the bicubically pre-upsampled LR segment, device or host);
+        flows/masks as the reference passes them to sample(); noise: optional dict with 'posterior' [T,4,h,w],
+        'x_T' [T,4,h,w], 'steps' [S,T,4,h,w].  Returns HR frames [T,3,H,W] in [0,1] on the device."""
+        eng = self.engine()
+        m, vq = self.model, self.vq_model
+        x = frames.to(eng.device, torch.float32).contiguous()
+        T = x.shape[0]
+        noise = noise or {}
+        post = m.encode_first_stage(x)
+        pn = noise.get("posterior")
+        init_latent = m.get_first_stage_encoding(post, pn if pn is not None else torch.randn(post.mean.shape))
+        ctx = m.cond_stage_model([""])
+        n0 = noise.get("x_T")
+        n0 = torch.randn_like(init_latent) if n0 is None else n0.to(eng.device)
+        t = torch.full((T,), 999, dtype=torch.long, device=eng.device)
+        x_T = m.q_sample_respace(init_latent, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, n0)
+        kw = dict(cond=ctx, struct_cond=init_latent, guidance_scale=guidance_scale, flows=flows, masks=masks, batch_size=1,
+                  timesteps=self.ddpm_steps, time_replace=self.ddpm_steps, x_T=x_T, noise=noise.get("steps"), use_graph=use_graph)
+        if tile is None:
+            samples = m.sample(**kw)
+        else:
+            samples = m.sample_canvas(tile_size=tile[0], tile_overlap=tile[1], batch_size_sample=1, **kw)
+        _, enc_fea = vq.encode(x)
+        x_samples = vq.decode(samples * (1.0 / m.scale_factor), enc_fea)
+        if self.colorfix_type == "adain":
+            x_samples = adaptive_instance_normalization(x_samples, x)
+        elif self.colorfix_type == "wavelet":
+            x_samples = wavelet_reconstruction(x_samples, x)
+        out = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)
+        return (out, samples) if return_latents else out

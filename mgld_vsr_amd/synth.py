@@ -38,17 +38,26 @@ def synth_param(name, shape, salt="w"):
     return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
 
 
+def _parallel(items, salt):
+    """generate many tensors concurrently (numpy releases the GIL while drawing); per-name seeding keeps it deterministic"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    with ThreadPoolExecutor(max_workers=max(1, min(32, os.cpu_count() or 1))) as ex:
+        vals = list(ex.map(lambda ns: synth_param(ns[0], ns[1], salt), items))
+    return {n: v for (n, _), v in zip(items, vals)}
+
+
 def synth_state_dict(names_shapes, salt="w"):
     """names_shapes: iterable of (name, shape) -> {name: tensor}"""
-    return {n: synth_param(n, s, salt) for n, s in names_shapes}
+    return _parallel(names_shapes, salt)
 
 
 def fill_module_(module, salt="w"):
     """In-place: overwrite every floating-point entry of module.state_dict() with the recipe."""
     sd = module.state_dict()
-    new = {}
-    for k, v in sd.items():
-        new[k] = synth_param(k, v.shape, salt).to(v.dtype) if v.is_floating_point() else v
+    gen = _parallel([(k, tuple(v.shape)) for k, v in sd.items() if v.is_floating_point()], salt)
+    new = {k: (gen[k].to(v.dtype) if k in gen else v) for k, v in sd.items()}
     module.load_state_dict(new, strict=True)
     return module
 

@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""MI355X counterpart of the reference's README inference entry
+(scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py:133-556): same argument surface, same segmenting / padding /
+resizing rules, same per-segment call sequence — with the model work done by libmgld_hip.
+
+Differences that are deliberate (SURVEY.md §3.1 "known defects", §8(f)):
+  * optical flow: RAFT is outside this path.  Flows come from `--flows-path` (`<seq>/<segment>_flows.npy`, array
+    [2, T-1, 2, h/4, w/4] = (flows_forward_prop, flows_backward_prop) as `compute_flow` returns them); without it
+    the motion guidance is switched off (and said so);
+  * the reference's non-tiled branch reads `flow_f/flow_b/fwd_occ/bwd_occ` before assignment (:492-495); here the
+    evident intent (`flows[0], flows[1], fwd_occs, bwd_occs`) is used;
+  * the VAE config path that does not exist in the reference (:303) is replaced by `--vqgan_config`;
+  * host pre/post-processing (PNG decode, bicubic resize, reflect pad) stays on the host in torch — it is §8(f) row 2.
+"""
+import argparse
+import glob
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mgld_vsr_amd.pipeline import VSRPipeline, model_configs  # noqa: E402
+
+
+def load_yaml_model_section(path):
+    import yaml
+    with open(path) as fh:
+        cfg = yaml.safe_load(fh)
+    return cfg["model"]
+
+
+def read_image(path):
+    from PIL import Image
+    im = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+    t = torch.from_numpy(im).permute(2, 0, 1)[None]
+    return (t - 0.5) / 0.5
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--seqs-path", type=str, required=True, help="dir with one sub-dir of LR PNG frames per sequence")
+    p.add_argument("--flows-path", type=str, default=None)
+    p.add_argument("--outdir", type=str, default="outputs/user_upload")
+    p.add_argument("--ddpm_steps", type=int, default=50)
+    p.add_argument("--n_frames", type=int, default=5)
+    p.add_argument("--n_samples", type=int, default=1)
+    p.add_argument("--config", type=str, default=None, help="diffusion YAML (model: section); default = shipped hyper-parameters")
+    p.add_argument("--vqgan_config", type=str, default=None)
+    p.add_argument("--ckpt", type=str, default=None)
+    p.add_argument("--vqgan_ckpt", type=str, default=None)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--precision", type=str, default="autocast", choices=["full", "autocast"])
+    p.add_argument("--select_idx", type=int, default=0)
+    p.add_argument("--n_gpus", type=int, default=1)
+    p.add_argument("--dec_w", type=float, default=1.0)
+    p.add_argument("--tile_overlap", type=int, default=32)
+    p.add_argument("--upscale", type=float, default=4.0)
+    p.add_argument("--colorfix_type", type=str, default="adain", choices=["adain", "wavelet", "nofix"])
+    p.add_argument("--vqgantile_stride", type=int, default=750)
+    p.add_argument("--vqgantile_size", type=int, default=960)
+    p.add_argument("--guidance_scale", type=float, default=-10.0)
+    return p.parse_args()
+
+
+def main():
+    opt = parse()
+    torch.manual_seed(opt.seed)
+    cfgs = model_configs(opt.n_frames)
+    if opt.config:
+        cfgs = (load_yaml_model_section(opt.config), cfgs[1])
+        cfgs[0]["params"].pop("ckpt_path", None)
+        cfgs[0]["params"]["first_stage_config"]["params"].pop("ckpt_path", None)
+    if opt.vqgan_config:
+        v = load_yaml_model_section(opt.vqgan_config)
+        v["params"].pop("ckpt_path", None)
+        v["params"]["lossconfig"] = {"target": "torch.nn.Identity"}
+        cfgs = (cfgs[0], v)
+    pipe = VSRPipeline(num_frames=opt.n_frames, ddpm_steps=opt.ddpm_steps, dec_w=opt.dec_w,
+                       colorfix_type=opt.colorfix_type, synthetic_weights=opt.ckpt is None, configs=cfgs)
+    if opt.ckpt:
+        sd = torch.load(opt.ckpt, map_location="cpu")
+        pipe.model.load_state_dict(sd["state_dict"] if "state_dict" in sd else sd, strict=False)
+        pipe._setup_schedule(opt.ddpm_steps)
+    if opt.vqgan_ckpt:
+        pipe.vq_model.init_from_ckpt(opt.vqgan_ckpt)
+    os.makedirs(opt.outdir, exist_ok=True)
+
+    seq_names = sorted(os.listdir(opt.seqs_path))
+    for seq_idx, seq in enumerate(seq_names):
+        if seq_idx % opt.n_gpus != opt.select_idx:   # the reference's process-level sharding (:337-339)
+            continue
+        paths = sorted(glob.glob(os.path.join(opt.seqs_path, seq, "*.png")))
+        if not paths:
+            continue
+        while len(paths) % opt.n_frames:             # repeat-last padding (:345-346)
+            paths.append(paths[-1])
+        frames = []
+        for pth in paths:
+            im = read_image(pth)
+            size_min = min(im.shape[-2:])
+            up = max(512.0 / size_min, opt.upscale)  # (:349-357)
+            frames.append(F.interpolate(im, size=(int(im.shape[-2] * up), int(im.shape[-1] * up)), mode="bicubic"))
+        os.makedirs(os.path.join(opt.outdir, seq), exist_ok=True)
+        for s0 in range(0, len(frames), opt.n_frames):
+            seg = torch.cat(frames[s0:s0 + opt.n_frames], 0)
+            ori_h, ori_w = seg.shape[-2:]
+            ph = 0 if ori_h % 32 == 0 else (ori_h // 32 + 1) * 32 - ori_h      # reflect-pad to /32 (:384-390)
+            pw = 0 if ori_w % 32 == 0 else (ori_w // 32 + 1) * 32 - ori_w
+            seg = F.pad(seg, (0, pw, 0, ph), mode="reflect").clamp(-1.0, 1.0)
+            flows = masks = None
+            if opt.flows_path:
+                fpath = os.path.join(opt.flows_path, seq, f"{s0 // opt.n_frames:04d}_flows.npy")
+                fl = torch.from_numpy(np.load(fpath)).float()
+                from basicsr.archs.arch_util import resize_flow
+                from scripts.util_flow import forward_backward_consistency_check
+                h8, w8 = seg.shape[-2] // 8, seg.shape[-1] // 8
+                f_fwd = resize_flow(fl[0], "shape", [h8, w8])
+                f_bwd = resize_flow(fl[1], "shape", [h8, w8])
+                # fwd_flow = flows[1] (true forward flow), bwd_flow = flows[0]  (oldcanvas_tile.py:405-409)
+                fo, bo = forward_backward_consistency_check(f_bwd, f_fwd)
+                flows, masks = (f_fwd[None], f_bwd[None]), (fo[None, :, None], bo[None, :, None])
+            else:
+                print(f"[{seq}] no flows given: motion guidance off for this segment")
+            h8, w8 = seg.shape[-2] // 8, seg.shape[-1] // 8
+            tile = None if (h8 <= 64 and w8 <= 64) else (64, opt.tile_overlap)
+            out = pipe.run_segment(seg, flows=flows, masks=masks, guidance_scale=opt.guidance_scale, tile=tile)
+            out = out[:, :, :ori_h, :ori_w].cpu()
+            from PIL import Image
+            for k in range(out.shape[0]):
+                idx = s0 + k
+                if idx >= len(set(paths)) and paths[idx] == paths[-1] and idx != len(paths) - 1:
+                    pass
+                arr = (out[k].permute(1, 2, 0).numpy() * 255.0).round().clip(0, 255).astype(np.uint8)
+                Image.fromarray(arr).save(os.path.join(opt.outdir, seq, os.path.basename(paths[idx])))
+
+
+if __name__ == "__main__":
+    main()

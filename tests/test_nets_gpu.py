@@ -170,3 +170,25 @@ def test_unet_fullwidth_vs_oracle(hip):
         assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < 5e-3
     eps = unet(x.cuda(), t.cuda(), context=ctx.cuda(), struct_cond={k: v.cuda() for k, v in sc_ref.items()})
     assert record("unet_full", rel_l2(eps, eps_ref)) < 5e-3
+
+
+def test_sample_small_50_steps_vs_oracle(hip):
+    """the full 50-step respaced loop (hipGraph replay) with motion guidance vs the oracle sampler, reduced nets."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    from oracle import flow as oflow
+    model = _small_model()
+    S, h = 50, 16
+    _respace(model, S)
+    ctx = synth.synth_tensor("ctx", (1, 77, UNET_SMALL["context_dim"]))
+    lat, xT = synth.synth_tensor("s50/lat", (T, 4, h, h), 0.5), synth.synth_tensor("s50/xT", (T, 4, h, h))
+    noise = torch.stack([synth.synth_tensor(f"s50/n{i}", (T, 4, h, h)) for i in range(S)])
+    ff, fb = synth.smooth_flow("s50/ff", T - 1, h, h), synth.smooth_flow("s50/fb", T - 1, h, h)
+    fo, bo = oflow.forward_backward_consistency_check(fb, ff)
+    flows, masks = (ff[None], fb[None]), (fo[None, :, None], bo[None, :, None])
+    usd, ssd = model.model.diffusion_model.state_dict(), model.structcond_stage_model.state_dict()
+    for tag, fl, mk in [("noguid", None, None), ("guided", flows, masks)]:
+        x0 = model.sample(cond=ctx, struct_cond=lat, guidance_scale=-10.0, flows=fl, masks=mk, batch_size=1, timesteps=S,
+                          time_replace=S, x_T=xT, noise=noise)
+        ref = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, ctx, lat, xT, [noise[S - 1 - k] for k in range(S)], S,
+                           guidance_scale=-10.0, flows=fl, masks=mk)
+        assert record(f"sample50_small_{tag}", rel_l2(x0, ref)) < (1e-2 if fl is None else 5e-2)
