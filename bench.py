@@ -118,13 +118,23 @@ def roofline(pipe, args, frames, noise, flows, masks):
         t["flops"] += g["flops"] * g["count"]
         t["ms"] += g["ms"] * g["count"]
         t["launches"] += g["count"]
+    dump = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(dump):   # per-problem table for kernel tuning (scratch output, not part of the JSON line)
+        rows = [{"cfg": g["cfg"], "mode": k[1], "M": k[2], "N": k[3], "K": k[4], "Cin": k[5], "H": k[6], "stride": k[8], "up2": k[9],
+                 "act": k[10], "batch": k[11], "count": g["count"], "us": round(1e3 * g["ms"], 2),
+                 "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 1), "total_ms": round(g["ms"] * g["count"], 2)}
+                for k, g in groups.items()]
+        rows.sort(key=lambda r: -r["total_ms"])
+        with open(os.path.join(dump, "igemm_shapes.json"), "w") as fh:
+            json.dump(rows, fh, indent=0)
     dom_cfg = max(tot, key=lambda c: tot[c]["ms"])
+    dom_tile = dom_cfg % 1000000
     d = tot[dom_cfg]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     all_flops = sum(t["flops"] for t in tot.values())
     all_ms = sum(t["ms"] for t in tot.values())
     return {
-        "bound": "mfma", "kernel": f"igemm_kernel<{dom_cfg // 1000},{dom_cfg % 1000}>", "achieved": round(achieved, 2),
+        "bound": "mfma", "kernel": f"igemm_kernel<{dom_tile // 1000},{dom_tile % 1000}>" + (f" splitK x{dom_cfg // 1000000}" if dom_cfg >= 1000000 else ""), "achieved": round(achieved, 2),
         "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
         "launches_per_segment": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
         "kernel_ms_per_segment": round(d["ms"], 2),

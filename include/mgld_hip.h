@@ -92,8 +92,13 @@ typedef struct MgldIGemm {
 } MgldIGemm;
 
 int mgld_igemm(const MgldIGemm* p, void* stream);
-/* block tile the launcher selects for this problem, encoded BM*1000+BN (profiling / roofline bookkeeping) */
+/* block tile the launcher selects for this problem, encoded BM*1000+BN, plus splits*1000000 when the problem is
+ * split along K (profiling / roofline bookkeeping) */
 int mgld_igemm_config(const MgldIGemm* p);
+/* fp32 scratch for split-K partial sums (few output tiles, deep K: the 16x16 / 8x8 UNet levels).  Caller-owned device
+ * memory, must stay valid while launches that may use it are in flight / captured; single-stream use.  Without it the
+ * launcher falls back to smaller tiles. */
+int mgld_set_workspace(void* ptr, int64_t bytes);
 
 /* ---- K3: GroupNorm (32 groups) on NHWC fp16, fp32 statistics -----------------------------------------------
  * Replaces nn.GroupNorm / GroupNorm32 (diffusionmodules/util.py:214-216, model.py:80-81, attention.py:87-88).

@@ -7,17 +7,28 @@
 //   * CONV3X3  — 3x3 conv on NHWC, stride 1/2, asymmetric zero pad, optional nearest-2x upsample folded into the
 //                gather (openaimodel.py:176,185,221; model.py:96,114-118)
 //   * TCONV3   — Conv3d (3,1,1) over the frame axis (diffusionmodules/util.py:298)
-// Layout: activations are token-major (NHWC) fp16 with leading dimension lda; weights are [N][K] fp16 with
-// K = taps*Cin contiguous.  Tiles are staged global->registers->LDS (padded rows, conflict-free ds_read_b128),
-// double-buffered, one barrier per 32-deep k-step.  The MFMA is issued with the WEIGHT tile as the row operand,
-// so each lane ends up holding 4 consecutive output channels per register group -> 8-byte vector stores and a
-// lane-local GEGLU pairing.
+//
+// Structure (gfx950):
+//   * K is consumed in 64-deep stages.  Both tiles are brought HBM -> LDS by the DMA path
+//     (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave instruction): no staging VGPRs, no ds_write pass.  The
+//     LDS image of a wave instruction is lane-linear (8 rows x 128 B), so the bank-conflict swizzle is applied on the
+//     per-lane SOURCE address (16-B chunk c of row r is stored at chunk c ^ ((r>>1)&7)) and undone on the ds_read_b128
+//     side; rows of a 16-lane ds_read_b128 group then hit 16 distinct 16-B slots.
+//   * The implicit-GEMM gather (conv taps, stride, nearest-2x upsample, frame shifts) is just that per-lane source
+//     address; zero padding / ragged tails read a 64-B device zero page.
+//   * two LDS stages; stage k+1 is in flight while stage k feeds the MFMAs; one barrier per stage.
+//   * the WEIGHT tile is the MFMA row operand, so a lane ends up holding 4 consecutive output channels per register
+//     group -> 8-byte stores and a lane-local GEGLU pairing.
+//   * problems with too few output tiles for 256 CUs but a deep K (the 16x16 / 8x8 UNet levels: M <= 2048, K up to
+//     23040) are split along K over grid.z into fp32 partials and finished by a small reduce+epilogue kernel.
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 32;     // k depth per stage (fp16 elements)
-constexpr int LDSS = 40;   // LDS row stride in halves (80 B: 16 rows hit 16 distinct 16-B slots)
+constexpr int BK = 64;          // k depth per stage (fp16 elements) = 128 B per tile row
+constexpr int ROWB = BK * 2;    // bytes per tile row in LDS
+
+__device__ uint4 g_zero_page[4];  // 64 B of zeros: source of padded / out-of-range 16-B chunks
 
 struct RowInfo {
   int64_t base;  // LINEAR: m*lda ; CONV: n*Hin*Win (pixel index) ; TCONV: m (row index)
@@ -25,124 +36,131 @@ struct RowInfo {
   bool valid;
 };
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p) {
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+struct EpiParams {
+  const float* bias; const float* bias_m; const float* rowvec; const f16* R;
+  int rows_per_frame, ld_rowvec, ldr, act; float alpha, beta;
+};
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == MGLD_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == MGLD_ACT_LRELU02) return x > 0.f ? x : 0.2f * x;
+  if (act == MGLD_ACT_SILU) return silu_f(x);
+  return x;
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
-  constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256;
+  constexpr int JA = BM / 32, JB = BN / 32;  // glds instructions per wave per stage (8 rows each, 4 waves)
+  constexpr int STAGE = (BM + BN) * ROWB;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows in units of 32");
 
-  __shared__ __attribute__((aligned(16))) f16 smem[2 * (BM + BN) * LDSS];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int bm0 = blockIdx.x * BM;
   const int bn0 = blockIdx.y * BN;
-  const int bz = blockIdx.z;
+  const bool splitk = (ws != nullptr);
+  const int bz = splitk ? 0 : blockIdx.z;
+  const int kz = splitk ? blockIdx.z : 0;
 
   const f16* __restrict__ A = (const f16*)p.A + (int64_t)bz * p.strideA;
   const f16* __restrict__ W = (const f16*)p.W + (int64_t)bz * p.strideW;
 
   const int M = p.M, N = p.N, K = p.K;
-  const int Cin = (p.mode == MGLD_MODE_LINEAR) ? K : p.Cin;
+  const int Cin = (MODE == MGLD_MODE_LINEAR) ? K : p.Cin;
+  const int k_begin = splitk ? kz * kchunk : 0;
+  const int k_end = splitk ? min(K, k_begin + kchunk) : K;
 
-  // ---- per-thread staging assignment -------------------------------------------------------------------
-  RowInfo ra[NA];
-  int a_ldsoff[NA];
+  // ---- per-lane staging assignment ------------------------------------------------------------------------
+  // wave instruction q = j*4 + wave covers tile rows [q*8, q*8+8); lane -> row q*8 + (lane>>3), physical chunk lane&7.
+  // logical chunk = phys ^ ((row>>1)&7) = (lane&7) ^ (((wave&1)*4 + (lane>>4)) & 7): the same for every j.
+  const int cphys = lane & 7;
+  const int clog = cphys ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  RowInfo ra[JA];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int v = tid + i * 256;
-    const int row = v >> 2;
+  for (int j = 0; j < JA; ++j) {
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
     const int m = bm0 + row;
-    ra[i].valid = (v < BM * 4) && (m < M);
-    a_ldsoff[i] = row * LDSS + (v & 3) * 8;
-    ra[i].base = 0; ra[i].iy0 = 0; ra[i].ix0 = 0;
-    if (ra[i].valid) {
-      if (p.mode == MGLD_MODE_LINEAR) {
-        ra[i].base = (int64_t)m * p.lda;
-      } else if (p.mode == MGLD_MODE_CONV3X3) {
-        const int hw = p.Hout * p.Wout;
-        const int n = m / hw;
-        const int r = m - n * hw;
-        const int oy = r / p.Wout, ox = r - oy * p.Wout;
-        ra[i].base = (int64_t)n * p.Hin * p.Win;
-        ra[i].iy0 = oy * p.stride - p.pad_t;
-        ra[i].ix0 = ox * p.stride - p.pad_l;
-      } else {  // TCONV3
-        const int f = m / p.HW;
-        ra[i].base = m;
-        ra[i].iy0 = f % p.T;
-      }
+    ra[j].valid = m < M;
+    ra[j].base = 0; ra[j].iy0 = 0; ra[j].ix0 = 0;
+    const int mm = ra[j].valid ? m : 0;  // computed unconditionally (branch-free); invalid rows read the zero page
+    if constexpr (MODE == MGLD_MODE_LINEAR) {
+      ra[j].base = (int64_t)mm * p.lda;
+    } else if constexpr (MODE == MGLD_MODE_CONV3X3) {
+      const int hw = p.Hout * p.Wout;
+      const int n = mm / hw;
+      const int r = mm - n * hw;
+      const int oy = r / p.Wout, ox = r - oy * p.Wout;
+      ra[j].base = (int64_t)n * p.Hin * p.Win;
+      ra[j].iy0 = oy * p.stride - p.pad_t;
+      ra[j].ix0 = ox * p.stride - p.pad_l;
+    } else {  // TCONV3
+      const int f = mm / p.HW;
+      ra[j].base = mm;
+      ra[j].iy0 = f % p.T;
     }
   }
-  int b_ldsoff[NB];
-  int64_t b_base[NB];
-  bool b_valid[NB];
+  int64_t b_base[JB];
+  bool b_valid[JB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int v = tid + i * 256;
-    const int row = v >> 2;
-    const int n = bn0 + row;
-    b_valid[i] = (v < BN * 4) && (n < N);
-    b_ldsoff[i] = (BM + row) * LDSS + (v & 3) * 8;
-    b_base[i] = (int64_t)n * p.ldw;
+  for (int j = 0; j < JB; ++j) {
+    const int n = bn0 + (j * 4 + wave) * 8 + (lane >> 3);
+    b_valid[j] = n < N;
+    b_base[j] = (int64_t)n * p.ldw;
   }
-  const int kv8 = (tid & 3) * 8;  // this thread's k offset inside a stage (same for all its vectors)
 
-  // incremental (tap, c) for k = kt*BK + kv8
-  int tap = 0, c = kv8;
-  while (c >= Cin) { c -= Cin; ++tap; }
+  // (tap, c) of this lane's chunk at stage start k_begin
+  int kl = k_begin + clog * 8;
+  int tap = kl / Cin;
+  int c = kl - tap * Cin;
+  const char* zero = (const char*)g_zero_page;
 
-  f16x8 regA[NA], regB[NB];
-  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-  auto load_stage = [&](int kt) {
-    const int kglob = kt * BK + kv8;
-    const bool kval = kglob < K;
+  auto issue_stage = [&](int buf) {
+    char* sbase = smem + buf * STAGE + wave * 1024;
+    const bool kval = kl < k_end;
+    // branch-free: the offset is always computed, the pointer is SELECTED (out-of-range -> zero page)
+    int ky = 0, kx = 0;
+    if constexpr (MODE == MGLD_MODE_CONV3X3) { ky = tap / 3; kx = tap - ky * 3; }
+    const int hlim = p.up2 ? 2 * p.Hin : p.Hin, wlim = p.up2 ? 2 * p.Win : p.Win, sh = p.up2 ? 1 : 0;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      f16x8 v = zero8;
-      if (ra[i].valid && kval) {
-        if (p.mode == MGLD_MODE_LINEAR) {
-          v = *(const f16x8*)(A + ra[i].base + kglob);
-        } else if (p.mode == MGLD_MODE_CONV3X3) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-          int iy = ra[i].iy0 + ky, ix = ra[i].ix0 + kx;
-          bool ok;
-          if (p.up2) {
-            ok = (iy >= 0) && (ix >= 0) && (iy < 2 * p.Hin) && (ix < 2 * p.Win);
-            iy >>= 1; ix >>= 1;
-          } else {
-            ok = (iy >= 0) && (ix >= 0) && (iy < p.Hin) && (ix < p.Win);
-          }
-          if (ok) v = *(const f16x8*)(A + (ra[i].base + (int64_t)iy * p.Win + ix) * p.lda + c);
-        } else {
-          const int tt = ra[i].iy0 + tap - 1;
-          if (tt >= 0 && tt < p.T) v = *(const f16x8*)(A + (ra[i].base + (int64_t)(tap - 1) * p.HW) * p.lda + c);
-        }
+    for (int j = 0; j < JA; ++j) {
+      bool ok = ra[j].valid & kval;
+      int64_t off;
+      if constexpr (MODE == MGLD_MODE_LINEAR) {
+        off = ra[j].base + kl;
+      } else if constexpr (MODE == MGLD_MODE_CONV3X3) {
+        const int iy = ra[j].iy0 + ky, ix = ra[j].ix0 + kx;
+        ok &= ((unsigned)iy < (unsigned)hlim) & ((unsigned)ix < (unsigned)wlim);
+        off = (ra[j].base + (int64_t)((iy >> sh) * p.Win + (ix >> sh))) * p.lda + c;
+      } else {
+        const int tt = ra[j].iy0 + tap - 1;
+        ok &= (unsigned)tt < (unsigned)p.T;
+        off = (ra[j].base + (int64_t)(tap - 1) * p.HW) * p.lda + c;
       }
-      regA[i] = v;
+      const f16* src = ok ? (A + off) : (const f16*)zero;
+      glds16(src, sbase + j * 4096);
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      f16x8 v = zero8;
-      if (b_valid[i] && kval) v = *(const f16x8*)(W + b_base[i] + kglob);
-      regB[i] = v;
+    for (int j = 0; j < JB; ++j) {
+      const f16* src = (b_valid[j] & kval) ? (W + b_base[j] + kl) : (const f16*)zero;
+      glds16(src, sbase + BM * ROWB + j * 4096);
     }
-    // advance (tap, c) to the next stage
+    kl += BK;
     c += BK;
     while (c >= Cin) { c -= Cin; ++tap; }
-  };
-  auto store_stage = [&](int buf) {
-    f16* s = smem + buf * (BM + BN) * LDSS;
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (NA * 256 == BM * 4 || tid + i * 256 < BM * 4) *(f16x8*)(s + a_ldsoff[i]) = regA[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (NB * 256 == BN * 4 || tid + i * 256 < BN * 4) *(f16x8*)(s + b_ldsoff[i]) = regB[i];
   };
 
   f32x16 acc[NI][MI];
@@ -153,38 +171,67 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
-
+  const int nk = (k_end - k_begin + BK - 1) / BK;
   const int l31 = lane & 31, lhi = lane >> 5;
+  // fragment row byte offsets and swizzle keys (row index within the tile; wave offsets are multiples of 32)
+  int a_off[MI], a_key[MI], w_off[NI], w_key[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int r = wm * WM + mi * 32 + l31;
+    a_off[mi] = r * ROWB; a_key[mi] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int r = wn * WN + ni * 32 + l31;
+    w_off[ni] = BM * ROWB + r * ROWB; w_key[ni] = (r >> 1) & 7;
+  }
+
+  if (nk > 0) issue_stage(0);
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_stage(kt + 1);
-    const f16* sA = smem + buf * (BM + BN) * LDSS;
-    const f16* sW = sA + BM * LDSS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // stage kt has landed for every wave; everyone is done reading the other buffer
+    if (kt + 1 < nk) issue_stage((kt + 1) & 1);
+    const char* sb = smem + (kt & 1) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
+      const int cl = ks * 2 + lhi;
       f16x8 fa[MI], fw[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        fa[mi] = *(const f16x8*)(sA + (wm * WM + mi * 32 + l31) * LDSS + ks * 16 + lhi * 8);
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const f16x8*)(sb + a_off[mi] + ((cl ^ a_key[mi]) << 4));
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        fw[ni] = *(const f16x8*)(sW + (wn * WN + ni * 32 + l31) * LDSS + ks * 16 + lhi * 8);
+      for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_stage(buf ^ 1);
-    __syncthreads();
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------
   // D[i = n_local][j = m_local]: lane holds column j = lane&31 (one output row m), rows i = (r&3)+8*(r>>2)+4*lhi
+  if (splitk) {
+    float* wz = ws + (int64_t)kz * M * N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = bm0 + wm * WM + mi * 32 + l31;
+      if (m >= M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int n0 = bn0 + wn * WN + ni * 32 + rg * 8 + lhi * 4;
+          float* dst = wz + (int64_t)m * N + n0;
+          if (n0 + 3 < N && ((N & 3) == 0)) {
+            *(f32x4*)dst = f32x4{acc[ni][mi][rg * 4], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n0 + j < N) dst[j] = acc[ni][mi][rg * 4 + j];
+          }
+        }
+    }
+    return;
+  }
   const bool geglu = (p.act == MGLD_ACT_GEGLU);
   const int64_t cbase = (int64_t)bz * p.strideC;
   const f16* __restrict__ R = p.R ? (const f16*)p.R + (int64_t)bz * p.strideR : nullptr;
@@ -227,10 +274,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p) {
               if (p.bias) x += p.bias[n];
               if (rv) x += rv[n];
             }
-            if (p.act == MGLD_ACT_RELU) x = fmaxf(x, 0.f);
-            else if (p.act == MGLD_ACT_LRELU02) x = x > 0.f ? x : 0.2f * x;
-            else if (p.act == MGLD_ACT_SILU) x = silu_f(x);
-            v[j] = x;
+            v[j] = apply_act(x, p.act);
           }
         }
         if (n0 >= Nout) continue;
@@ -262,14 +306,115 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p) {
   }
 }
 
+// split-K finish: out = alpha*act(sum_z ws[z] + bias + bias_m + rowvec) + beta*R.  One thread per 4 columns.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const MgldIGemm p, const float* __restrict__ ws, int splits) {
+  const int M = p.M, N = p.N;
+  const int nq = (N + 3) >> 2;
+  const int64_t total = (int64_t)M * nq;
+  const int64_t MN = (int64_t)M * N;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / nq);
+    const int n0 = (int)(idx - (int64_t)m * nq) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (n0 + 3 < N) && ((N & 3) == 0);
+    for (int z = 0; z < splits; ++z) {
+      const float* src = ws + z * MN + (int64_t)m * N + n0;
+      if (vec) {
+        const f32x4 t = *(const f32x4*)src;
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      } else {
+        for (int j = 0; j < 4; ++j) if (n0 + j < N) v[j] += src[j];
+      }
+    }
+    const float bm = p.bias_m ? p.bias_m[m] : 0.f;
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec : nullptr;
+    const f16* R = (const f16*)p.R;
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j;
+      if (n >= N) break;
+      float x = v[j] + bm;
+      if (p.bias) x += p.bias[n];
+      if (rv) x += rv[n];
+      x = apply_act(x, p.act) * p.alpha;
+      if (R) x += p.beta * (float)R[(int64_t)m * p.ldr + n];
+      if (p.out_f32) ((float*)p.C)[(int64_t)m * p.ldc + n] = x;
+      else ((f16*)p.C)[(int64_t)m * p.ldc + n] = (f16)x;
+    }
+  }
+}
+
+float* g_ws = nullptr;     // split-K workspace (set by mgld_set_workspace; single-stream use)
+size_t g_ws_bytes = 0;
+
+template <int MODE, int BM, int BN, int WM, int WN>
+void launch_mode(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
+  constexpr int LDS = 2 * (BM + BN) * ROWB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<MODE, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), splits > 1 ? splits : (p->batch > 0 ? p->batch : 1));
+  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), LDS, s, *p, splits > 1 ? g_ws : nullptr, kchunk);
+}
+
 template <int BM, int BN, int WM, int WN>
-int launch_cfg(const MgldIGemm* p, hipStream_t s) {
-  dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), p->batch > 0 ? p->batch : 1);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, *p);
+int launch_cfg(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
+  if (p->mode == MGLD_MODE_LINEAR) launch_mode<MGLD_MODE_LINEAR, BM, BN, WM, WN>(p, s, splits, kchunk);
+  else if (p->mode == MGLD_MODE_CONV3X3) launch_mode<MGLD_MODE_CONV3X3, BM, BN, WM, WN>(p, s, splits, kchunk);
+  else launch_mode<MGLD_MODE_TCONV3, BM, BN, WM, WN>(p, s, splits, kchunk);
+  if (splits > 1) {
+    const int64_t total = (int64_t)p->M * ((p->N + 3) >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, *p, g_ws, splits);
+  }
   return mgld_check_launch("igemm");
 }
 
+// (config, splits): config encoded BM*1000+BN
+void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
+  const int64_t M = p->M, N = p->N, K = p->K;
+  const int batch = p->batch > 0 ? p->batch : 1;
+  const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128) * batch;
+  *splits = 1;
+  *kchunk = (int)K;
+  if (p->act == MGLD_ACT_GEGLU) { *cfg = (t128 >= 256 || M <= 64) ? 128128 : 64128; return; }
+  if (N <= 32) { *cfg = 128032; return; }
+  if (N <= 64) { *cfg = 128064; return; }
+  if (t128 >= 384) { *cfg = 128128; return; }
+  // too few 128x128 tiles for 256 CUs
+  if (batch == 1 && K >= 1536 && g_ws != nullptr) {
+    int s = (int)((448 + t128 - 1) / t128);
+    const int smax = (int)(K / 512);
+    if (s > smax) s = smax;
+    if (s > 16) s = 16;
+    if (s >= 2 && (size_t)s * M * N * sizeof(float) <= g_ws_bytes) {
+      int kc = (int)((K + s - 1) / s);
+      kc = (kc + BK - 1) / BK * BK;
+      s = (int)((K + kc - 1) / kc);
+      if (s >= 2) { *cfg = 128128; *splits = s; *kchunk = kc; return; }
+    }
+  }
+  const int64_t t64x128 = (int64_t)cdiv(M, 64) * cdiv(N, 128) * batch;
+  *cfg = (t64x128 >= 384) ? 64128 : 64064;
+}
+
 }  // namespace
+
+extern "C" int mgld_set_workspace(void* ptr, int64_t bytes) {
+  g_ws = (float*)ptr;
+  g_ws_bytes = ptr ? (size_t)bytes : 0;
+  return MGLD_OK;
+}
+
+// tile configuration the launcher picks for a problem: BM*1000 + BN (+ splits*1000000 when split along K)
+extern "C" int mgld_igemm_config(const MgldIGemm* p) {
+  if (!p) return 0;
+  int cfg, splits, kchunk;
+  choose(p, &cfg, &splits, &kchunk);
+  return cfg + (splits > 1 ? splits * 1000000 : 0);
+}
 
 extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   MGLD_REQUIRE(p && p->A && p->W && p->C, "igemm: null pointer");
@@ -292,27 +437,13 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   if (p->rowvec) MGLD_REQUIRE(p->rows_per_frame > 0, "igemm: rows_per_frame");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
-  switch (mgld_igemm_config(p)) {
-    case 128128: return launch_cfg<128, 128, 64, 64>(p, s);
-    case 64128: return launch_cfg<64, 128, 32, 64>(p, s);
-    case 128032: return launch_cfg<128, 32, 32, 32>(p, s);
-    case 128064: return launch_cfg<128, 64, 64, 32>(p, s);
-    default: return launch_cfg<64, 64, 32, 32>(p, s);
+  int cfg, splits, kchunk;
+  choose(p, &cfg, &splits, &kchunk);
+  switch (cfg) {
+    case 128128: return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
+    case 64128: return launch_cfg<64, 128, 32, 64>(p, s, 1, kchunk);
+    case 128032: return launch_cfg<128, 32, 32, 32>(p, s, 1, kchunk);
+    case 128064: return launch_cfg<128, 64, 64, 32>(p, s, 1, kchunk);
+    default: return launch_cfg<64, 64, 32, 32>(p, s, 1, kchunk);
   }
-}
-
-// tile configuration the launcher picks for a problem: BM*1000 + BN
-extern "C" int mgld_igemm_config(const MgldIGemm* p) {
-  if (!p) return 0;
-  const int64_t M = p->M, N = p->N;
-  const int batch = p->batch > 0 ? p->batch : 1;
-  const int64_t blocks128 = (int64_t)cdiv(M, 128) * cdiv(N, 128) * batch;
-  if (p->act == MGLD_ACT_GEGLU) return (blocks128 >= 256 || M <= 64) ? 128128 : 64128;
-  if (N <= 32) return 128032;
-  if (N <= 64) return 128064;
-  if (blocks128 >= 512) return 128128;
-  // not enough 128x128 tiles to fill 256 CUs: shrink the tile
-  const int64_t blocks64x128 = (int64_t)cdiv(M, 64) * cdiv(N, 128) * batch;
-  if (blocks64x128 >= 512) return 64128;
-  return 64064;
 }

@@ -126,7 +126,7 @@ class Engine:
 
     GROUPS = 32
 
-    def __init__(self, device="cuda", chunk_bytes=1 << 30):
+    def __init__(self, device="cuda", chunk_bytes=1 << 30, workspace_bytes=256 << 20):
         hip.lib()  # fail loudly if the HIP library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("mgld_vsr_amd needs a HIP device: the hot path has no CPU fallback")
@@ -134,6 +134,8 @@ class Engine:
         self.arena = Arena(self.device, chunk_bytes)
         self._wcache = {}
         self.launches = 0
+        # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
+        self._splitk_ws = hip.ensure_workspace(workspace_bytes) if self.device.type == "cuda" else None
 
     # ---- memory ----
     def reset(self):

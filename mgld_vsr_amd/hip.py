@@ -51,7 +51,7 @@ EXPORTS = [
     "mgld_version", "mgld_last_error", "mgld_device_info",
     "mgld_graph_begin", "mgld_graph_end", "mgld_graph_launch", "mgld_graph_destroy",
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
-    "mgld_igemm", "mgld_igemm_config", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_layernorm",
+    "mgld_igemm", "mgld_igemm_config", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_layernorm",
     "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows",
     "mgld_linear_small", "mgld_timestep_embedding",
     "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
@@ -151,6 +151,23 @@ def igemm_relaunch(p):
 
 def igemm_config(p):
     return lib().mgld_igemm_config(C.byref(p))
+
+
+def set_workspace(t):
+    """register a device uint8/float tensor as the split-K scratch (the caller keeps it alive); None unregisters"""
+    _chk(lib().mgld_set_workspace(_p(t), C.c_int64(t.numel() * t.element_size() if t is not None else 0)), "set_workspace")
+
+
+_WORKSPACE = None
+
+
+def ensure_workspace(nbytes=256 << 20):
+    """process-lifetime split-K scratch (one per process: the library holds a single pointer)"""
+    global _WORKSPACE
+    if _WORKSPACE is None or _WORKSPACE.numel() < nbytes:
+        _WORKSPACE = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    set_workspace(_WORKSPACE)
+    return _WORKSPACE
 
 
 def igemm_flops(p):

@@ -20,4 +20,15 @@ def hip():
         pytest.skip("no GPU visible")
     from mgld_vsr_amd import hip as _hip
     _hip.lib()
+    _hip._test_ws = _hip.ensure_workspace()   # process-lifetime split-K scratch
     return _hip
+
+
+@pytest.fixture(autouse=True)
+def _restore_workspace(request):
+    """tests may unregister the split-K scratch; put it back after every GPU test"""
+    yield
+    if "hip" in request.fixturenames:
+        from mgld_vsr_amd import hip as _hip
+        if getattr(_hip, "_test_ws", None) is not None:
+            _hip.ensure_workspace()

@@ -43,6 +43,29 @@ def test_igemm_linear(hip, M, N, K):
     assert rel_l2(out.cpu().float(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 1280, 11520), (2048, 640, 5760), (300, 200, 2048), (64, 1280, 23040)])
+def test_igemm_splitk(hip, M, N, K):
+    """few output tiles + deep K -> split along K into fp32 partials + reduce/epilogue kernel"""
+    ws = hip._test_ws   # session-lifetime scratch registered by the `hip` fixture
+    hip.set_workspace(ws)
+    a, w, b = h16(rnd(M, K, seed=1)), h16(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
+    r = h16(rnd(M, N, seed=4))
+    ref = 0.5 * F.silu(a.float() @ w.float().t() + b) + 2.0 * r.float()
+    out = torch.empty(M, N, dtype=torch.half, device=DEV)
+    ad, wd = a.to(DEV), w.to(DEV)
+    hip.igemm(ad, wd, out, bias=b.to(DEV), resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+    p = hip.MgldIGemm()
+    p.M, p.N, p.K, p.batch, p.act = M, N, K, 1, hip.ACT_SILU
+    assert hip.igemm_config(p) >= 2000000, "expected the split-K path"
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+    hip.set_workspace(None)
+    out2 = torch.empty(M, N, dtype=torch.half, device=DEV)
+    hip.igemm(ad, wd, out2, bias=b.to(DEV), resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+    assert hip.igemm_config(p) < 1000000
+    assert rel_l2(out2.cpu().float(), ref) < 1e-3
+    hip.set_workspace(ws)
+
+
 def test_igemm_transpose_detect(hip):
     # A = I-like with asymmetric W catches row/col swaps of the MFMA output mapping
     M = N = K = 64
