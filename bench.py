@@ -48,12 +48,8 @@ def parse():
 def dist_setup(n):
     if n <= 1:
         return 0, 1, 0
-    import torch.distributed as dist
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    return rank, world, local
+    from mgld_vsr_amd import parallel
+    return parallel.init(backend="nccl")   # RCCL over xGMI; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun
 
 
 def build_pipeline(args):
@@ -194,26 +190,18 @@ def main():
     pipe = build_pipeline(args)
     frames, noise, flows, masks = make_inputs(pipe, args, rank)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
+    from mgld_vsr_amd import parallel
+    # every rank owns its own segment (weak scaling): the reference's `seq_idx % n_gpus == select_idx` sharding
+    assert parallel.shard_segments(world, rank, world) == [rank]
 
     for _ in range(args.warmup):
         pipe.run_segment(frames, flows=flows, masks=masks, noise=noise)
-    barrier()
+    parallel.barrier()                       # barrier + torch.cuda.synchronize() on both sides of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = pipe.run_segment(frames, flows=flows, masks=masks, noise=noise)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0)
     ok = bool(torch.isfinite(out).all())
     ms_per_step = 1e3 * dt / args.steps
     fps = world * args.frames * args.steps / dt

@@ -55,7 +55,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   return x;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int MODE, bool FAST, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -89,78 +89,167 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
   // logical chunk = phys ^ ((row>>1)&7) = (lane&7) ^ (((wave&1)*4 + (lane>>4)) & 7): the same for every j.
   const int cphys = lane & 7;
   const int clog = cphys ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const char* zero = (const char*)g_zero_page;
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+
+  // ======== FAST path state: K % 64 == 0, and for the gather modes Cin % 64 == 0 and no upsample fold. ========
+  // Every 64-deep stage then lies inside ONE tap, so the tap / channel offset is wave-uniform (SGPR) and a lane's
+  // source address is  row_pointer + uniform_offset : one 64-bit add + a validity select per 16-B chunk.
+  const char* fa_ptr[JA];     // LINEAR: running pointer ; CONV/TCONV: pointer of tap (0,0)/(dt=0) incl. this lane's chunk
+  unsigned fa_step[JA];       // LINEAR: bytes to advance per stage (0 for rows past M -> stay on the zero page)
+  unsigned fa_mask[JA];       // CONV/TCONV: bit t set = tap t is inside the image / clip for this row
+  const char* fw_ptr[JB];
+  unsigned fw_step[JB];
+  int s_tap = 0, s_c0 = 0;    // wave-uniform tap / channel offset of the current stage
+  // ======== GENERAL path state ========
   RowInfo ra[JA];
-#pragma unroll
-  for (int j = 0; j < JA; ++j) {
-    const int row = (j * 4 + wave) * 8 + (lane >> 3);
-    const int m = bm0 + row;
-    ra[j].valid = m < M;
-    ra[j].base = 0; ra[j].iy0 = 0; ra[j].ix0 = 0;
-    const int mm = ra[j].valid ? m : 0;  // computed unconditionally (branch-free); invalid rows read the zero page
-    if constexpr (MODE == MGLD_MODE_LINEAR) {
-      ra[j].base = (int64_t)mm * p.lda;
-    } else if constexpr (MODE == MGLD_MODE_CONV3X3) {
-      const int hw = p.Hout * p.Wout;
-      const int n = mm / hw;
-      const int r = mm - n * hw;
-      const int oy = r / p.Wout, ox = r - oy * p.Wout;
-      ra[j].base = (int64_t)n * p.Hin * p.Win;
-      ra[j].iy0 = oy * p.stride - p.pad_t;
-      ra[j].ix0 = ox * p.stride - p.pad_l;
-    } else {  // TCONV3
-      const int f = mm / p.HW;
-      ra[j].base = mm;
-      ra[j].iy0 = f % p.T;
-    }
-  }
   int64_t b_base[JB];
   bool b_valid[JB];
-#pragma unroll
-  for (int j = 0; j < JB; ++j) {
-    const int n = bn0 + (j * 4 + wave) * 8 + (lane >> 3);
-    b_valid[j] = n < N;
-    b_base[j] = (int64_t)n * p.ldw;
-  }
-
-  // (tap, c) of this lane's chunk at stage start k_begin
   int kl = k_begin + clog * 8;
-  int tap = kl / Cin;
-  int c = kl - tap * Cin;
-  const char* zero = (const char*)g_zero_page;
+  int tap = 0, c = 0;
 
-  auto issue_stage = [&](int buf) {
-    char* sbase = smem + buf * STAGE + wave * 1024;
-    const bool kval = kl < k_end;
-    // branch-free: the offset is always computed, the pointer is SELECTED (out-of-range -> zero page)
-    int ky = 0, kx = 0;
-    if constexpr (MODE == MGLD_MODE_CONV3X3) { ky = tap / 3; kx = tap - ky * 3; }
-    const int hlim = p.up2 ? 2 * p.Hin : p.Hin, wlim = p.up2 ? 2 * p.Win : p.Win, sh = p.up2 ? 1 : 0;
+  if constexpr (FAST) {
+    if constexpr (MODE != MGLD_MODE_LINEAR) { s_tap = k_begin / Cin; s_c0 = k_begin - s_tap * Cin; }
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-      bool ok = ra[j].valid & kval;
-      int64_t off;
+      const int row = (j * 4 + wave) * 8 + (lane >> 3);
+      const int m = bm0 + row;
+      const bool valid = m < M;
+      const int mm = valid ? m : 0;
+      fa_step[j] = 0; fa_mask[j] = 0;
       if constexpr (MODE == MGLD_MODE_LINEAR) {
-        off = ra[j].base + kl;
+        fa_ptr[j] = valid ? (const char*)(A + (int64_t)mm * p.lda + k_begin + clog * 8) : zero;
+        fa_step[j] = valid ? BK * 2 : 0;
       } else if constexpr (MODE == MGLD_MODE_CONV3X3) {
-        const int iy = ra[j].iy0 + ky, ix = ra[j].ix0 + kx;
-        ok &= ((unsigned)iy < (unsigned)hlim) & ((unsigned)ix < (unsigned)wlim);
-        off = (ra[j].base + (int64_t)((iy >> sh) * p.Win + (ix >> sh))) * p.lda + c;
+        const int hw = p.Hout * p.Wout;
+        const int n = mm / hw;
+        const int r = mm - n * hw;
+        const int oy = r / p.Wout, ox = r - oy * p.Wout;
+        const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+        fa_ptr[j] = (const char*)(A + (((int64_t)n * p.Hin + iy0) * p.Win + ix0) * p.lda + clog * 8);
+        unsigned msk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+          if (valid && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) msk |= 1u << t;
+        }
+        fa_mask[j] = msk;
       } else {
-        const int tt = ra[j].iy0 + tap - 1;
-        ok &= (unsigned)tt < (unsigned)p.T;
-        off = (ra[j].base + (int64_t)(tap - 1) * p.HW) * p.lda + c;
+        const int f = mm / p.HW;
+        const int t0 = f % p.T;
+        fa_ptr[j] = (const char*)(A + ((int64_t)mm - p.HW) * p.lda + clog * 8);   // dt = 0 reads frame t-1
+        unsigned msk = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (valid && (unsigned)(t0 + t - 1) < (unsigned)p.T) msk |= 1u << t;
+        fa_mask[j] = msk;
       }
-      const f16* src = ok ? (A + off) : (const f16*)zero;
-      glds16(src, sbase + j * 4096);
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-      const f16* src = (b_valid[j] & kval) ? (W + b_base[j] + kl) : (const f16*)zero;
-      glds16(src, sbase + BM * ROWB + j * 4096);
+      const int n = bn0 + (j * 4 + wave) * 8 + (lane >> 3);
+      const bool valid = n < N;
+      fw_ptr[j] = valid ? (const char*)(W + (int64_t)n * p.ldw + k_begin + clog * 8) : zero;
+      fw_step[j] = valid ? BK * 2 : 0;
     }
-    kl += BK;
-    c += BK;
-    while (c >= Cin) { c -= Cin; ++tap; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const int row = (j * 4 + wave) * 8 + (lane >> 3);
+      const int m = bm0 + row;
+      ra[j].valid = m < M;
+      ra[j].base = 0; ra[j].iy0 = 0; ra[j].ix0 = 0;
+      const int mm = ra[j].valid ? m : 0;  // computed unconditionally (branch-free); invalid rows read the zero page
+      if constexpr (MODE == MGLD_MODE_LINEAR) {
+        ra[j].base = (int64_t)mm * p.lda;
+      } else if constexpr (MODE == MGLD_MODE_CONV3X3) {
+        const int hw = p.Hout * p.Wout;
+        const int n = mm / hw;
+        const int r = mm - n * hw;
+        const int oy = r / p.Wout, ox = r - oy * p.Wout;
+        ra[j].base = (int64_t)n * p.Hin * p.Win;
+        ra[j].iy0 = oy * p.stride - p.pad_t;
+        ra[j].ix0 = ox * p.stride - p.pad_l;
+      } else {  // TCONV3
+        const int f = mm / p.HW;
+        ra[j].base = mm;
+        ra[j].iy0 = f % p.T;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int n = bn0 + (j * 4 + wave) * 8 + (lane >> 3);
+      b_valid[j] = n < N;
+      b_base[j] = (int64_t)n * p.ldw;
+    }
+    tap = kl / Cin;
+    c = kl - tap * Cin;
+  }
+
+  auto issue_stage = [&](int buf) {
+    char* sbase = smem + buf * STAGE + wave * 1024;
+    if constexpr (FAST) {
+      if constexpr (MODE == MGLD_MODE_LINEAR) {
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+          glds16(fa_ptr[j], sbase + j * 4096);
+          fa_ptr[j] += fa_step[j];
+        }
+      } else {
+        // uniform byte offset of this stage's tap + channel block
+        int64_t soff;
+        if constexpr (MODE == MGLD_MODE_CONV3X3) {
+          const int ky = s_tap / 3, kx = s_tap - ky * 3;
+          soff = ((int64_t)(ky * p.Win + kx) * p.lda + s_c0) * 2;
+        } else {
+          soff = ((int64_t)s_tap * p.HW * p.lda + s_c0) * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+          const char* src = ((fa_mask[j] >> s_tap) & 1u) ? fa_ptr[j] + soff : zero;
+          glds16(src, sbase + j * 4096);
+        }
+        s_c0 += BK;
+        if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        glds16(fw_ptr[j], sbase + BM * ROWB + j * 4096);
+        fw_ptr[j] += fw_step[j];
+      }
+    } else {
+      const bool kval = kl < k_end;
+      // branch-free: the offset is always computed, the pointer is SELECTED (out-of-range -> zero page)
+      int ky = 0, kx = 0;
+      if constexpr (MODE == MGLD_MODE_CONV3X3) { ky = tap / 3; kx = tap - ky * 3; }
+      const int hlim = p.up2 ? 2 * p.Hin : p.Hin, wlim = p.up2 ? 2 * p.Win : p.Win, sh = p.up2 ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < JA; ++j) {
+        bool ok = ra[j].valid & kval;
+        int64_t off;
+        if constexpr (MODE == MGLD_MODE_LINEAR) {
+          off = ra[j].base + kl;
+        } else if constexpr (MODE == MGLD_MODE_CONV3X3) {
+          const int iy = ra[j].iy0 + ky, ix = ra[j].ix0 + kx;
+          ok &= ((unsigned)iy < (unsigned)hlim) & ((unsigned)ix < (unsigned)wlim);
+          off = (ra[j].base + (int64_t)((iy >> sh) * p.Win + (ix >> sh))) * p.lda + c;
+        } else {
+          const int tt = ra[j].iy0 + tap - 1;
+          ok &= (unsigned)tt < (unsigned)p.T;
+          off = (ra[j].base + (int64_t)(tap - 1) * p.HW) * p.lda + c;
+        }
+        const f16* src = ok ? (A + off) : (const f16*)zero;
+        glds16(src, sbase + j * 4096);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const f16* src = (b_valid[j] & kval) ? (W + b_base[j] + kl) : (const f16*)zero;
+        glds16(src, sbase + BM * ROWB + j * 4096);
+      }
+      kl += BK;
+      c += BK;
+      while (c >= Cin) { c -= Cin; ++tap; }
+    }
   };
 
   f32x16 acc[NI][MI];
@@ -171,7 +260,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  const int nk = (k_end - k_begin + BK - 1) / BK;
   const int l31 = lane & 31, lhi = lane >> 5;
   // fragment row byte offsets and swizzle keys (row index within the tile; wave offsets are multiples of 32)
   int a_off[MI], a_key[MI], w_off[NI], w_key[NI];
@@ -346,16 +434,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MgldIGemm p, c
 float* g_ws = nullptr;     // split-K workspace (set by mgld_set_workspace; single-stream use)
 size_t g_ws_bytes = 0;
 
-template <int MODE, int BM, int BN, int WM, int WN>
-void launch_mode(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
+template <int MODE, bool FAST, int BM, int BN, int WM, int WN>
+void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   constexpr int LDS = 2 * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<MODE, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<MODE, FAST, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), splits > 1 ? splits : (p->batch > 0 ? p->batch : 1));
-  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), LDS, s, *p, splits > 1 ? g_ws : nullptr, kchunk);
+  hipLaunchKernelGGL((igemm_kernel<MODE, FAST, BM, BN, WM, WN>), grid, dim3(256), LDS, s, *p, splits > 1 ? g_ws : nullptr, kchunk);
+}
+
+// FAST: every 64-deep stage lies inside one tap and inside K (see the kernel)
+inline bool fast_ok(const MgldIGemm* p) {
+  if (p->K % BK) return false;
+  if (p->mode == MGLD_MODE_LINEAR) return true;
+  return (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2);
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+void launch_mode(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
+  if (fast_ok(p)) launch_fast<MODE, true, BM, BN, WM, WN>(p, s, splits, kchunk);
+  else launch_fast<MODE, false, BM, BN, WM, WN>(p, s, splits, kchunk);
 }
 
 template <int BM, int BN, int WM, int WN>

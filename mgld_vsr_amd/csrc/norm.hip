@@ -40,10 +40,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
   if (rr < rpi) {
-    for (int r = r0 + rr; r < r1; r += rpi) {
-      const f16x8 d = *(const f16x8*)(xf + (int64_t)r * ld + v * 8);
+    constexpr int U = 4;  // rows in flight per thread
+    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = r0 + rr; r < r1; r += rpi * U) {
+      f16x8 d[U];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = (float)d[j]; s[j] += f; q[j] += f * f; }
+      for (int u = 0; u < U; ++u)
+        d[u] = (r + u * rpi < r1) ? *(const f16x8*)(xf + (int64_t)(r + u * rpi) * ld + v * 8) : z8;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)d[u][j]; s[j] += f; q[j] += f * f; }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -90,36 +97,65 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
                                                        const f16* __restrict__ gb, int ldgb, const f16* __restrict__ skip,
                                                        int ldskip, f16* __restrict__ y, int ldy, int64_t total_rows,
                                                        int rows_per_frame, int C, int groups, int silu) {
+  // grid (row chunks, frames).  A thread owns ONE 8-channel vector column for all its rows, so the per-channel scale /
+  // shift (rstd*gamma, beta - mean*rstd*gamma) are computed once into registers and the row loop is load-fma-store.
   const int NV = C >> 3;
   const int cg = C / groups;
-  const int64_t total = total_rows * NV;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int64_t row = idx / NV;
-    const int v = (int)(idx - row * NV);
-    const int frame = (int)(row / rows_per_frame);
+  const int frame = blockIdx.y;
+  const int rows_per_chunk = (rows_per_frame + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(rows_per_frame, r0 + rows_per_chunk);
+  const float* st = stats + (int64_t)frame * groups * 2;
+  const int64_t fbase = (int64_t)frame * rows_per_frame;
+  const int rpi = NV >= 256 ? 1 : 256 / NV;
+  const int rr = NV >= 256 ? 0 : threadIdx.x / NV;
+  if (rr >= rpi) return;
+  (void)total_rows;
+  for (int v = NV >= 256 ? threadIdx.x : threadIdx.x - rr * NV; v < NV; v += 256) {
     const int c0 = v * 8;
-    const f16x8 d = *(const f16x8*)(x + row * ldx + c0);
-    f16x8 gm, bt, sk;
-    if (SPADE) {
-      gm = *(const f16x8*)(gb + row * ldgb + c0);
-      bt = *(const f16x8*)(gb + row * ldgb + C + c0);
-      sk = *(const f16x8*)(skip + row * ldskip + c0);
-    }
-    const float* st = stats + (int64_t)frame * groups * 2;
-    f16x8 o;
+    float sa[8], sb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c0 + j;
       const int g = c / cg;
-      float f = ((float)d[j] - st[g * 2]) * st[g * 2 + 1] * gamma[c] + beta[c];
-      if (SPADE) {
-        f = f * (1.f + (float)gm[j]) + (float)bt[j] + (float)sk[j];
-      } else if (silu) {
-        f = silu_f(f);
-      }
-      o[j] = (f16)f;
+      sa[j] = st[g * 2 + 1] * gamma[c];
+      sb[j] = beta[c] - st[g * 2] * sa[j];
     }
-    *(f16x8*)(y + row * ldy + c0) = o;
+    constexpr int U = 4;  // rows in flight per thread
+    for (int r = r0 + rr; r < r1; r += rpi * U) {
+      f16x8 d[U], gm[U], bt[U], sk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = fbase + r + u * rpi;
+        if (r + u * rpi < r1) {
+          d[u] = *(const f16x8*)(x + row * ldx + c0);
+          if (SPADE) {
+            gm[u] = *(const f16x8*)(gb + row * ldgb + c0);
+            bt[u] = *(const f16x8*)(gb + row * ldgb + C + c0);
+            sk[u] = *(const f16x8*)(skip + row * ldskip + c0);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (r + u * rpi < r1) {
+          const int64_t row = fbase + r + u * rpi;
+          f16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float f = (float)d[u][j] * sa[j] + sb[j];
+            if (SPADE) {
+              f = f * (1.f + (float)gm[u][j]) + (float)bt[u][j] + (float)sk[u][j];
+            } else if (silu) {
+              f = silu_f(f);
+            }
+            o[j] = (f16)f;
+          }
+          *(f16x8*)(y + row * ldy + c0) = o;
+        }
+      }
+    }
+    if (NV < 256) break;
   }
 }
 
@@ -204,12 +240,19 @@ static int elem_grid(int64_t total) {
   return (int)b;
 }
 
+static dim3 apply_grid(int frames, int rows) {
+  int chunks = cdiv(rows, 32);
+  const int cap = 4096 / (frames > 0 ? frames : 1);
+  if (chunks > cap) chunks = cap > 0 ? cap : 1;
+  return dim3(chunks, frames);
+}
+
 extern "C" int mgld_gn_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta, void* y,
                              int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
   MGLD_REQUIRE(x && stats && gamma && beta && y, "gn_apply: null pointer");
   MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C % groups == 0, "gn_apply: alignment");
   const int64_t total_rows = (int64_t)frames * rows;
-  hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(elem_grid(total_rows * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((gn_apply_kernel<false>), apply_grid(frames, rows), dim3(256), 0, (hipStream_t)stream,
                      (const f16*)x, ldx, stats, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, total_rows, rows, C,
                      groups, silu);
   return mgld_check_launch("gn_apply");
@@ -222,7 +265,7 @@ extern "C" int mgld_spade_apply(const void* h, int ldh, const float* stats, cons
   MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0,
                "spade_apply: alignment");
   const int64_t total_rows = (int64_t)frames * rows;
-  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(elem_grid(total_rows * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((gn_apply_kernel<true>), apply_grid(frames, rows), dim3(256), 0, (hipStream_t)stream,
                      (const f16*)h, ldh, stats, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy,
                      total_rows, rows, C, groups, 0);
   return mgld_check_launch("spade_apply");
