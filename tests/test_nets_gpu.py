@@ -172,6 +172,85 @@ def test_unet_fullwidth_vs_oracle(hip):
     assert record("unet_full", rel_l2(eps, eps_ref)) < 5e-3
 
 
+def test_pipeline_small_end_to_end_vs_oracle(hip):
+    """LR-upsampled frames -> HR frames through the WHOLE per-segment path (first-stage encode, q_sample, 50 guided
+    DDPM steps, video-VAE encode/decode, AdaIN, clamp) vs the oracle chained the same way; reduced-width nets."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    from oracle import colorfix as ocf
+    from oracle import flow as oflow
+    from oracle import schedule as osched
+    S, H, h = 50, 128, 16
+    cfgs = model_configs(T, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                         struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                         vae_overrides=dict(ch=32, resolution=H), context_dim=64)
+    pipe = VSRPipeline(num_frames=T, ddpm_steps=S, configs=cfgs)
+    x = synth.synth_tensor("e2e/x", (T, 3, H, H), 0.5).clamp(-1, 1)
+    noise = {"posterior": synth.synth_tensor("e2e/np", (T, 4, h, h)), "x_T": synth.synth_tensor("e2e/n0", (T, 4, h, h)),
+             "steps": torch.stack([synth.synth_tensor(f"e2e/n{i}", (T, 4, h, h)) for i in range(S)])}
+    ff, fb = synth.smooth_flow("e2e/ff", T - 1, h, h), synth.smooth_flow("e2e/fb", T - 1, h, h)
+    fo, bo = oflow.forward_backward_consistency_check(fb, ff)
+    flows, masks = (ff[None], fb[None]), (fo[None, :, None], bo[None, :, None])
+    out, lat = pipe.run_segment(x, flows=flows, masks=masks, guidance_scale=-10.0, noise=noise, return_latents=True)
+    # ---- oracle chain ----
+    m, vq = pipe.model, pipe.vq_model
+    dd = cfgs[1]["params"]["ddconfig"]
+    with torch.no_grad():
+        mean, logvar, _ = onets.vae_moments(m.first_stage_model.state_dict(), dd, x)
+        init = 0.18215 * (mean + torch.exp(0.5 * logvar) * noise["posterior"])
+        full, _, _ = osched.respaced_schedule(S)
+        tt = torch.full((T,), 999, dtype=torch.long)
+        xT = osched.q_sample_respace(init, tt, full["sqrt_alphas_cumprod"], full["sqrt_one_minus_alphas_cumprod"], noise["x_T"])
+        ucfg, scfg = cfgs[0]["params"]["unet_config"]["params"], cfgs[0]["params"]["structcond_stage_config"]["params"]
+        ctx = synth.synth_tensor("ctx", (1, 77, 64))
+        x0 = osamp.sample(m.model.diffusion_model.state_dict(), ucfg, m.structcond_stage_model.state_dict(), scfg, ctx, init,
+                          xT, [noise["steps"][S - 1 - k] for k in range(S)], S, guidance_scale=-10.0, flows=flows, masks=masks)
+        _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
+        dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
+        ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
+    record("e2e_small_latent", rel_l2(lat, x0))
+    assert record("e2e_small_frames", rel_l2(out, ref)) < 1e-2
+
+
+def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
+    """The shipped architecture at FULL width (935 M-param UNet, 52 M struct-cond encoder, full KL-VAE + video decoder),
+    2 frames of 256x256 (latent 32x32), 4 guided DDPM steps, end to end vs the oracle (BASELINE configs[0] scaled to what
+    the CPU oracle finishes in about a minute)."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    from oracle import colorfix as ocf
+    from oracle import flow as oflow
+    from oracle import schedule as osched
+    Tn, S, H, h = 2, 4, 256, 32
+    cfgs = model_configs(Tn)
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=cfgs)
+    x = synth.synth_tensor("e2ef/x", (Tn, 3, H, H), 0.5).clamp(-1, 1)
+    noise = {"posterior": synth.synth_tensor("e2ef/np", (Tn, 4, h, h)), "x_T": synth.synth_tensor("e2ef/n0", (Tn, 4, h, h)),
+             "steps": torch.stack([synth.synth_tensor(f"e2ef/n{i}", (Tn, 4, h, h)) for i in range(S)])}
+    ff, fb = synth.smooth_flow("e2ef/ff", Tn - 1, h, h), synth.smooth_flow("e2ef/fb", Tn - 1, h, h)
+    fo, bo = oflow.forward_backward_consistency_check(fb, ff)
+    flows, masks = (ff[None], fb[None]), (fo[None, :, None], bo[None, :, None])
+    out, lat = pipe.run_segment(x, flows=flows, masks=masks, guidance_scale=-10.0, noise=noise, return_latents=True)
+    m, vq = pipe.model, pipe.vq_model
+    dd = cfgs[1]["params"]["ddconfig"]
+    with torch.no_grad():
+        mean, logvar, _ = onets.vae_moments(m.first_stage_model.state_dict(), dd, x)
+        init = 0.18215 * (mean + torch.exp(0.5 * logvar) * noise["posterior"])
+        full, _, _ = osched.respaced_schedule(S)
+        tt = torch.full((Tn,), 999, dtype=torch.long)
+        xT = osched.q_sample_respace(init, tt, full["sqrt_alphas_cumprod"], full["sqrt_one_minus_alphas_cumprod"], noise["x_T"])
+        ucfg, scfg = cfgs[0]["params"]["unet_config"]["params"], cfgs[0]["params"]["structcond_stage_config"]["params"]
+        ctx = synth.synth_tensor("ctx", (1, 77, 1024))
+        x0 = osamp.sample(m.model.diffusion_model.state_dict(), ucfg, m.structcond_stage_model.state_dict(), scfg, ctx, init,
+                          xT, [noise["steps"][S - 1 - k] for k in range(S)], S, guidance_scale=-10.0, flows=flows, masks=masks)
+        _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
+        dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
+        ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
+    record("e2e_full_latent", rel_l2(lat, x0))
+    record("e2e_full_decoder_only", rel_l2(vq.decode(x0.cuda() / 0.18215, [f.cuda() for f in fea]), dec))
+    assert record("e2e_full_frames", rel_l2(out, ref)) < 1e-2
+
+
 def test_sample_small_50_steps_vs_oracle(hip):
     """the full 50-step respaced loop (hipGraph replay) with motion guidance vs the oracle sampler, reduced nets."""
     torch.set_num_threads(min(32, os.cpu_count() or 8))
