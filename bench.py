@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddpm-steps", type=int, default=50)
     ap.add_argument("--guidance", action="store_true", help="flow-guided latent warp on (configs[2]); default off (configs[1])")
+    ap.add_argument("--tile", action="store_true", help="aggregation sampling over 64x64 latent tiles, overlap 32 (configs[3]: use with --size 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
@@ -90,7 +91,7 @@ def roofline(pipe, args, frames, noise, flows, masks):
     stream) and weight by its launch count:  achieved = sum(flops) / sum(count * avg_duration)."""
     from mgld_vsr_amd import hip
     hip.IGEMM_LOG = []
-    pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, use_graph=False)
+    pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, use_graph=False, tile=TILE)
     torch.cuda.synchronize()
     log, hip.IGEMM_LOG = hip.IGEMM_LOG, None
     groups = {}
@@ -181,8 +182,13 @@ def cpu_baseline(args):
                       f"{args.ddpm_steps} steps + 2 encodes + 1 decode per frame"}
 
 
+TILE = None
+
+
 def main():
+    global TILE
     args = parse()
+    TILE = (64, 32) if args.tile else None
     rank, world, local = dist_setup(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
@@ -195,11 +201,11 @@ def main():
     assert parallel.shard_segments(world, rank, world) == [rank]
 
     for _ in range(args.warmup):
-        pipe.run_segment(frames, flows=flows, masks=masks, noise=noise)
+        pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE)
     parallel.barrier()                       # barrier + torch.cuda.synchronize() on both sides of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe.run_segment(frames, flows=flows, masks=masks, noise=noise)
+        out = pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE)
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0)
     ok = bool(torch.isfinite(out).all())
@@ -211,7 +217,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{args.frames}-frame {args.size}x{args.size} sequence (latent {args.size // 8}x{args.size // 8}x4), "
                                f"{args.ddpm_steps} DDPM steps, random-init SD-2.1 UNet + struct-cond encoder + KL-VAE encode x2 "
-                               f"+ temporal video decoder + AdaIN, flow-guided warp {'on' if args.guidance else 'off'}; "
+                               f"+ temporal video decoder + AdaIN, flow-guided warp {'on' if args.guidance else 'off'}{', aggregation sampling 64/32' if args.tile else ''}; "
                                "one segment per GPU",
                    "frames_per_segment": args.frames, "parallelism": f"segment-parallel x{world}", "finite": ok,
                    "reduced_width": bool(args.small)},

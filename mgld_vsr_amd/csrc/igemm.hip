@@ -22,8 +22,13 @@
 //   * problems with too few output tiles for 256 CUs but a deep K (the 16x16 / 8x8 UNet levels: M <= 2048, K up to
 //     23040) are split along K over grid.z into fp32 partials and finished by a small reduce+epilogue kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
+
+#ifndef MGLD_IGEMM_OPT_DEFAULT
+#define MGLD_IGEMM_OPT_DEFAULT 0
+#endif
 
 constexpr int BK = 64;          // k depth per stage (fp16 elements) = 128 B per tile row
 constexpr int ROWB = BK * 2;    // bytes per tile row in LDS
@@ -55,14 +60,16 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   return x;
 }
 
-template <int MODE, bool FAST, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk) {
+template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk,
+                                                                          int opt) {
   constexpr int WAVES_N = BN / WN;
+  constexpr int NW = (BM / WM) * (BN / WN);       // waves per block: 4 (256 threads) or 8 (512 threads)
   constexpr int MI = WM / 32, NI = WN / 32;
-  constexpr int JA = BM / 32, JB = BN / 32;  // glds instructions per wave per stage (8 rows each, 4 waves)
+  constexpr int JA = BM / (8 * NW), JB = BN / (8 * NW);  // glds instructions per wave per stage (8 rows each)
   constexpr int STAGE = (BM + BN) * ROWB;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows in units of 32");
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows in units of 8*waves");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -70,8 +77,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int bm0 = blockIdx.x * BM;
-  const int bn0 = blockIdx.y * BN;
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (opt & 1) {
+    // XCD-aware 1-D tile order: block b lands on XCD b%8 (observed dispatch, speed only).  Each XCD gets a contiguous
+    // run of tiles swept n-fastest, so the n-tiles of one A row-panel hit that XCD's L2 back to back.
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int total = gridDim.x;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_m = lin / tiles_n;
+    tile_n = lin - tile_m * tiles_n;
+  }
+  const int bm0 = tile_m * BM;
+  const int bn0 = tile_n * BN;
   const bool splitk = (ws != nullptr);
   const int bz = splitk ? 0 : blockIdx.z;
   const int kz = splitk ? blockIdx.z : 0;
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
     if constexpr (MODE != MGLD_MODE_LINEAR) { s_tap = k_begin / Cin; s_c0 = k_begin - s_tap * Cin; }
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-      const int row = (j * 4 + wave) * 8 + (lane >> 3);
+      const int row = (j * NW + wave) * 8 + (lane >> 3);
       const int m = bm0 + row;
       const bool valid = m < M;
       const int mm = valid ? m : 0;
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-      const int n = bn0 + (j * 4 + wave) * 8 + (lane >> 3);
+      const int n = bn0 + (j * NW + wave) * 8 + (lane >> 3);
       const bool valid = n < N;
       fw_ptr[j] = valid ? (const char*)(W + (int64_t)n * p.ldw + k_begin + clog * 8) : zero;
       fw_step[j] = valid ? BK * 2 : 0;
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
   } else {
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-      const int row = (j * 4 + wave) * 8 + (lane >> 3);
+      const int row = (j * NW + wave) * 8 + (lane >> 3);
       const int m = bm0 + row;
       ra[j].valid = m < M;
       ra[j].base = 0; ra[j].iy0 = 0; ra[j].ix0 = 0;
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-      const int n = bn0 + (j * 4 + wave) * 8 + (lane >> 3);
+      const int n = bn0 + (j * NW + wave) * 8 + (lane >> 3);
       b_valid[j] = n < N;
       b_base[j] = (int64_t)n * p.ldw;
     }
@@ -192,7 +211,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
       if constexpr (MODE == MGLD_MODE_LINEAR) {
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
-          glds16(fa_ptr[j], sbase + j * 4096);
+          glds16(fa_ptr[j], sbase + j * (NW * 1024));
           fa_ptr[j] += fa_step[j];
         }
       } else {
@@ -207,14 +226,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
           const char* src = ((fa_mask[j] >> s_tap) & 1u) ? fa_ptr[j] + soff : zero;
-          glds16(src, sbase + j * 4096);
+          glds16(src, sbase + j * (NW * 1024));
         }
         s_c0 += BK;
         if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
       }
 #pragma unroll
       for (int j = 0; j < JB; ++j) {
-        glds16(fw_ptr[j], sbase + BM * ROWB + j * 4096);
+        glds16(fw_ptr[j], sbase + BM * ROWB + j * (NW * 1024));
         fw_ptr[j] += fw_step[j];
       }
     } else {
@@ -239,12 +258,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
           off = (ra[j].base + (int64_t)(tap - 1) * p.HW) * p.lda + c;
         }
         const f16* src = ok ? (A + off) : (const f16*)zero;
-        glds16(src, sbase + j * 4096);
+        glds16(src, sbase + j * (NW * 1024));
       }
 #pragma unroll
       for (int j = 0; j < JB; ++j) {
         const f16* src = (b_valid[j] & kval) ? (W + b_base[j] + kl) : (const f16*)zero;
-        glds16(src, sbase + BM * ROWB + j * 4096);
+        glds16(src, sbase + BM * ROWB + j * (NW * 1024));
       }
       kl += BK;
       c += BK;
@@ -274,12 +293,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
     w_off[ni] = BM * ROWB + r * ROWB; w_key[ni] = (r >> 1) & 7;
   }
 
-  if (nk > 0) issue_stage(0);
+  // NST-deep ring of LDS stages: stages kt+1 .. kt+NST-1 are in flight (DMA) while stage kt feeds the MFMAs.
+  // A wave waits only for ITS OWN stage-kt loads with a counted vmcnt (newer stages stay in flight across the
+  // barrier), then the barrier makes every wave's stage kt visible and retires all reads of the buffer about to be
+  // refilled.
+  static_assert(NST == 2 || NST == 3, "2 or 3 stages");
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue_stage(s);
+  int cur = 0;  // buffer of stage kt
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // stage kt has landed for every wave; everyone is done reading the other buffer
-    if (kt + 1 < nk) issue_stage((kt + 1) & 1);
-    const char* sb = smem + (kt & 1) * STAGE;
+    if (NST == 3 && kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JB) : "memory");   // one newer stage may stay outstanding
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if constexpr (NST == 2) {
+      __syncthreads();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    {
+      const int nxt = kt + NST - 1;
+      int nb = cur + NST - 1;
+      if (nb >= NST) nb -= NST;
+      if (nxt < nk) issue_stage(nb);
+    }
+    const char* sb = smem + cur * STAGE;
+    cur = (cur + 1 == NST) ? 0 : cur + 1;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int cl = ks * 2 + lhi;
@@ -288,11 +330,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MgldIGemm p, float* __
       for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const f16x8*)(sb + a_off[mi] + ((cl ^ a_key[mi]) << 4));
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
+      if (opt & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      if (opt & 2) __builtin_amdgcn_s_setprio(0);
     }
   }
 
@@ -434,16 +478,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MgldIGemm p, c
 float* g_ws = nullptr;     // split-K workspace (set by mgld_set_workspace; single-stream use)
 size_t g_ws_bytes = 0;
 
-template <int MODE, bool FAST, int BM, int BN, int WM, int WN>
+// tuning switches (bitmask, env MGLD_IGEMM_OPT, read once): 1 = XCD-aware 1-D tile order, 2 = s_setprio around the
+// MFMA cluster, 4 = 256x128 tiles (8 waves) for large problems
+int igemm_opt() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MGLD_IGEMM_OPT");
+    v = e ? atoi(e) : MGLD_IGEMM_OPT_DEFAULT;
+  }
+  return v;
+}
+
+template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
 void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
-  constexpr int LDS = 2 * (BM + BN) * ROWB;
+  constexpr int LDS = NST * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<MODE, FAST, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<MODE, FAST, BM, BN, WM, WN, NST>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), splits > 1 ? splits : (p->batch > 0 ? p->batch : 1));
-  hipLaunchKernelGGL((igemm_kernel<MODE, FAST, BM, BN, WM, WN>), grid, dim3(256), LDS, s, *p, splits > 1 ? g_ws : nullptr, kchunk);
+  constexpr int THREADS = 64 * (BM / WM) * (BN / WN);
+  const int opt = igemm_opt();
+  const int gz = splits > 1 ? splits : (p->batch > 0 ? p->batch : 1);
+  dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), gz);
+  if (opt & 1) grid = dim3(cdiv(p->M, BM) * cdiv(p->N, BN), 1, gz);
+  hipLaunchKernelGGL((igemm_kernel<MODE, FAST, BM, BN, WM, WN, NST>), grid, dim3(THREADS), LDS, s, *p,
+                     splits > 1 ? g_ws : nullptr, kchunk, opt);
 }
 
 // FAST: every 64-deep stage lies inside one tap and inside K (see the kernel)
@@ -453,17 +514,17 @@ inline bool fast_ok(const MgldIGemm* p) {
   return (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int MODE, int BM, int BN, int WM, int WN, int NST>
 void launch_mode(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
-  if (fast_ok(p)) launch_fast<MODE, true, BM, BN, WM, WN>(p, s, splits, kchunk);
-  else launch_fast<MODE, false, BM, BN, WM, WN>(p, s, splits, kchunk);
+  if (fast_ok(p)) launch_fast<MODE, true, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
+  else launch_fast<MODE, false, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST = 2>
 int launch_cfg(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
-  if (p->mode == MGLD_MODE_LINEAR) launch_mode<MGLD_MODE_LINEAR, BM, BN, WM, WN>(p, s, splits, kchunk);
-  else if (p->mode == MGLD_MODE_CONV3X3) launch_mode<MGLD_MODE_CONV3X3, BM, BN, WM, WN>(p, s, splits, kchunk);
-  else launch_mode<MGLD_MODE_TCONV3, BM, BN, WM, WN>(p, s, splits, kchunk);
+  if (p->mode == MGLD_MODE_LINEAR) launch_mode<MGLD_MODE_LINEAR, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
+  else if (p->mode == MGLD_MODE_CONV3X3) launch_mode<MGLD_MODE_CONV3X3, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
+  else launch_mode<MGLD_MODE_TCONV3, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
   if (splits > 1) {
     const int64_t total = (int64_t)p->M * ((p->N + 3) >> 2);
     int blocks = (int)((total + 255) / 256);
@@ -483,6 +544,7 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   if (p->act == MGLD_ACT_GEGLU) { *cfg = (t128 >= 256 || M <= 64) ? 128128 : 64128; return; }
   if (N <= 32) { *cfg = 128032; return; }
   if (N <= 64) { *cfg = 128064; return; }
+  if ((igemm_opt() & 4) && (int64_t)cdiv(M, 256) * cdiv(N, 128) * batch >= 256 && N >= 128) { *cfg = 256128; return; }
   if (t128 >= 384) { *cfg = 128128; return; }
   // too few 128x128 tiles for 256 CUs
   if (batch == 1 && K >= 1536 && g_ws != nullptr) {
@@ -541,7 +603,10 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   int cfg, splits, kchunk;
   choose(p, &cfg, &splits, &kchunk);
   switch (cfg) {
-    case 128128: return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
+    case 256128: return launch_cfg<256, 128, 64, 64, 3>(p, s, 1, kchunk);
+    case 128128:
+      if (igemm_opt() & 8) return launch_cfg<128, 128, 64, 64, 3>(p, s, splits, kchunk);
+      return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
     case 64128: return launch_cfg<64, 128, 32, 64>(p, s, 1, kchunk);
     case 128032: return launch_cfg<128, 32, 32, 32>(p, s, 1, kchunk);
     case 128064: return launch_cfg<128, 64, 64, 32>(p, s, 1, kchunk);
