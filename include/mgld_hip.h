@@ -88,6 +88,9 @@ typedef struct MgldIGemm {
   int32_t out_f32;
   float alpha, beta;      /* out = alpha*act(acc+bias+rowvec) + beta*R                      */
   int32_t batch;          /* grid.z batches (>=1)                                           */
+  int32_t tap_inner;      /* CONV3X3/TCONV3 with Cin % 64 == 0 and no upsample fold: 1 = the K axis of W is ordered
+                             (64-channel block, tap, channel) instead of (tap, Cin): all taps of one channel block are
+                             consumed back to back, so the shifted re-reads of the input hit L1/L2                  */
   int64_t strideA, strideW, strideC, strideR; /* element strides between batches            */
 } MgldIGemm;
 

@@ -128,7 +128,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   int tap = 0, c = 0;
 
   if constexpr (FAST) {
-    if constexpr (MODE != MGLD_MODE_LINEAR) { s_tap = k_begin / Cin; s_c0 = k_begin - s_tap * Cin; }
+    if constexpr (MODE != MGLD_MODE_LINEAR) {
+      if (p.tap_inner) {
+        constexpr int NTAP = (MODE == MGLD_MODE_CONV3X3) ? 9 : 3;
+        const int st = k_begin / BK;           // stage index -> (channel block, tap)
+        s_c0 = (st / NTAP) * BK;
+        s_tap = st - (st / NTAP) * NTAP;
+      } else {
+        s_tap = k_begin / Cin;
+        s_c0 = k_begin - s_tap * Cin;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const int row = (j * NW + wave) * 8 + (lane >> 3);
@@ -206,6 +216,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   }
 
   auto issue_stage = [&](int buf) {
+    if (opt & 256) return;  // ablation (timing only): no global->LDS traffic at all
     char* sbase = smem + buf * STAGE + wave * 1024;
     if constexpr (FAST) {
       if constexpr (MODE == MGLD_MODE_LINEAR) {
@@ -228,13 +239,26 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
           const char* src = ((fa_mask[j] >> s_tap) & 1u) ? fa_ptr[j] + soff : zero;
           glds16(src, sbase + j * (NW * 1024));
         }
-        s_c0 += BK;
-        if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
+        if (p.tap_inner) {  // K order (chunk64, tap, c): all taps of one 64-channel block back to back (L1/L2 reuse)
+          constexpr int NTAP = (MODE == MGLD_MODE_CONV3X3) ? 9 : 3;
+          if (++s_tap == NTAP) { s_tap = 0; s_c0 += BK; }
+        } else {            // K order (tap, Cin)
+          s_c0 += BK;
+          if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
+        }
       }
+      if (!(opt & 16)) {  // (opt bit 16: ablation, timing only — skip the weight-tile traffic)
 #pragma unroll
-      for (int j = 0; j < JB; ++j) {
-        glds16(fw_ptr[j], sbase + BM * ROWB + j * (NW * 1024));
-        fw_ptr[j] += fw_step[j];
+        for (int j = 0; j < JB; ++j) {
+          glds16(fw_ptr[j], sbase + BM * ROWB + j * (NW * 1024));
+          fw_ptr[j] += fw_step[j];
+        }
+      }
+      if (opt & 64) {     // (opt bit 64: ablation — re-read the FIRST A stage only: no A traffic growth with K)
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+          if constexpr (MODE == MGLD_MODE_LINEAR) fa_ptr[j] -= fa_step[j];
+        }
       }
     } else {
       const bool kval = kl < k_end;
@@ -322,6 +346,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     }
     const char* sb = smem + cur * STAGE;
     cur = (cur + 1 == NST) ? 0 : cur + 1;
+    if (opt & 128) continue;  // ablation (timing only): no LDS reads, no MFMA
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int cl = ks * 2 + lhi;
@@ -331,106 +356,126 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
       if (opt & 2) __builtin_amdgcn_s_setprio(1);
+      if (opt & 32) {  // ablation (timing only): keep the LDS reads, skip the matrix pipe
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[mi]));
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ni]));
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      }
       if (opt & 2) __builtin_amdgcn_s_setprio(0);
     }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------
-  // D[i = n_local][j = m_local]: lane holds column j = lane&31 (one output row m), rows i = (r&3)+8*(r>>2)+4*lhi
-  if (splitk) {
-    float* wz = ws + (int64_t)kz * M * N;
+  // D[i = n_local][j = m_local]: a lane holds ONE output row (m = lane&31) and 4-channel groups of it, i.e. the natural
+  // store would be 8-byte pieces scattered over 32 rows.  Instead every wave transposes its 32-row slices through its own
+  // LDS patch (fp32, bias/activation already applied) and writes whole row segments: 8 lanes x 16 B = 128 B contiguous
+  // per output row, residual rows read the same way.  (Wave-local: no block barrier except the one releasing the stages.)
+  __syncthreads();
+  if (opt & 512) return;  // ablation (timing only): no epilogue
+  const bool geglu = (!splitk) && (p.act == MGLD_ACT_GEGLU);
+  constexpr int LDW = WN + 4;                       // patch row stride (floats): 16-B aligned, conflict-free b128
+  float* patch = (float*)smem + wave * (32 * LDW);
+  const int Nout = splitk ? N : (geglu ? N / 2 : N);
+  const int wcols = geglu ? WN / 2 : WN;            // output columns this wave produces
+  const int ncol0 = geglu ? (bn0 + wn * WN) / 2 : bn0 + wn * WN;
+  const int64_t cbase = splitk ? (int64_t)kz * M * N : (int64_t)bz * p.strideC;
+  const int ldo = splitk ? N : p.ldc;
+  const bool of32 = splitk || p.out_f32;
+  const f16* __restrict__ R = (!splitk && p.R) ? (const f16*)p.R + (int64_t)bz * p.strideR : nullptr;
+  const int act = splitk ? MGLD_ACT_NONE : p.act;
+  const float alpha = splitk ? 1.f : p.alpha;
+  char* outp = splitk ? (char*)ws : (char*)p.C;
+  const int lpr = wcols >> 3;                       // lanes per output row (8 columns each)
+  const int rpi = 64 / lpr;                         // rows per wave pass
+  const int prow = lane / lpr, pcv = (lane - prow * lpr) * 8;
+  const int n = ncol0 + pcv;                        // this lane's 8 output columns [n, n+8)
+  const bool full = (n + 8 <= Nout);
+  // per-lane column constants (same for every row): bias of the 8 columns (value and gate halves for GEGLU)
+  float bcol[8], bgate[8];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = bm0 + wm * WM + mi * 32 + l31;
-      if (m >= M) continue;
+  for (int j = 0; j < 8; ++j) { bcol[j] = 0.f; bgate[j] = 0.f; }
+  if (!splitk && p.bias) {
+    const int nb = geglu ? bn0 + wn * WN + pcv : n;   // packed row index of the value half
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int n0 = bn0 + wn * WN + ni * 32 + rg * 8 + lhi * 4;
-          float* dst = wz + (int64_t)m * N + n0;
-          if (n0 + 3 < N && ((N & 3) == 0)) {
-            *(f32x4*)dst = f32x4{acc[ni][mi][rg * 4], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (n0 + j < N) dst[j] = acc[ni][mi][rg * 4 + j];
-          }
-        }
+    for (int j = 0; j < 8; ++j) {
+      if (nb + j < N) bcol[j] = p.bias[nb + j];
+      if (geglu && nb + 32 + j < N) bgate[j] = p.bias[nb + 32 + j];
     }
-    return;
   }
-  const bool geglu = (p.act == MGLD_ACT_GEGLU);
-  const int64_t cbase = (int64_t)bz * p.strideC;
-  const f16* __restrict__ R = p.R ? (const f16*)p.R + (int64_t)bz * p.strideR : nullptr;
-  const int Nout = geglu ? N / 2 : N;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int m = bm0 + wm * WM + mi * 32 + l31;
-    if (m >= M) continue;
-    const float bm = p.bias_m ? p.bias_m[m] : 0.f;
-    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec : nullptr;
+    // ---- phase 1: raw accumulators -> patch[row = l31][col] ----
 #pragma unroll
-    for (int ni = 0; ni < (geglu ? 1 : NI); ++ni) {
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int nl = rg * 8 + lhi * 4;  // local n within the 32-wide MFMA tile
-        float v[4];
-        int n0;
+      for (int rg = 0; rg < 4; ++rg)
+        *(f32x4*)(patch + l31 * LDW + ni * 32 + rg * 8 + lhi * 4) =
+            f32x4{acc[ni][mi][rg * 4], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+    // ---- phase 2: patch rows -> epilogue math -> global, 8 columns (16 B of fp16 / 32 B of fp32) per lane ----
+    for (int r0 = 0; r0 < 32; r0 += rpi) {
+      const int row = r0 + prow;
+      const int m = bm0 + wm * WM + mi * 32 + row;
+      if (row < 32 && m < M && n < Nout) {
+        const f32x4 a0 = *(const f32x4*)(patch + row * LDW + pcv);
+        const f32x4 a1 = *(const f32x4*)(patch + row * LDW + pcv + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         if (geglu) {
-          if constexpr (NI == 2) {
-            const int npk = bn0 + wn * WN + nl;  // packed row of the value half; gate half is +32
-            n0 = (bn0 + wn * WN) / 2 + nl;
+          const f32x4 g0 = *(const f32x4*)(patch + row * LDW + 32 + pcv);
+          const f32x4 g1 = *(const f32x4*)(patch + row * LDW + 32 + pcv + 4);
+          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float x = acc[0][mi][rg * 4 + j], g = acc[1][mi][rg * 4 + j];
-              if (p.bias && npk + j + 32 < N) { x += p.bias[npk + j]; g += p.bias[npk + j + 32]; }
-              v[j] = x * gelu_f(g);
+          for (int j = 0; j < 8; ++j) v[j] = (v[j] + bcol[j]) * gelu_f(g[j] + bgate[j]) * alpha;
+        } else if (!splitk) {
+          const float bm = p.bias_m ? p.bias_m[m] : 0.f;
+          float rvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (p.rowvec) {
+            const float* rv = p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec + n;
+            if (full && ((((uintptr_t)rv) & 15) == 0)) {
+              const f32x4 r0v = *(const f32x4*)rv, r1v = *(const f32x4*)(rv + 4);
+              rvv[0] = r0v[0]; rvv[1] = r0v[1]; rvv[2] = r0v[2]; rvv[3] = r0v[3];
+              rvv[4] = r1v[0]; rvv[5] = r1v[1]; rvv[6] = r1v[2]; rvv[7] = r1v[3];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) if (n + j < Nout) rvv[j] = rv[j];
             }
-          } else {
-            n0 = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = 0.f;
           }
-        } else {
-          n0 = bn0 + wn * WN + ni * 32 + nl;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x = acc[ni][mi][rg * 4 + j] + bm;
-            const int n = n0 + j;
-            if (n < N) {
-              if (p.bias) x += p.bias[n];
-              if (rv) x += rv[n];
-            }
-            v[j] = apply_act(x, p.act);
+          for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bm + bcol[j] + rvv[j], act) * alpha;
+        }
+        if (R) {
+          const f16* rp = R + (int64_t)m * p.ldr + n;
+          if (full && ((((uintptr_t)rp) & 15) == 0)) {
+            const f16x8 rr = *(const f16x8*)rp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += p.beta * (float)rr[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * (float)rp[j];
           }
         }
-        if (n0 >= Nout) continue;
-        const bool full = (n0 + 3 < Nout);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] *= p.alpha;
-          if (R && n0 + j < Nout) v[j] += p.beta * (float)R[(int64_t)m * p.ldr + n0 + j];
-        }
-        if (p.out_f32) {
-          float* Cf = (float*)p.C + cbase + (int64_t)m * p.ldc + n0;
-          if (full && ((p.ldc & 3) == 0) && ((((uintptr_t)Cf) & 15) == 0)) {
-            *(f32x4*)Cf = f32x4{v[0], v[1], v[2], v[3]};
+        if (of32) {
+          float* cp = (float*)outp + cbase + (int64_t)m * ldo + n;
+          if (full && ((((uintptr_t)cp) & 15) == 0)) {
+            *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
           } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (n0 + j < Nout) Cf[j] = v[j];
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = v[j];
           }
         } else {
-          f16* Ch = (f16*)p.C + cbase + (int64_t)m * p.ldc + n0;
-          if (full && ((((uintptr_t)Ch) & 7) == 0)) {
-            *(f16x4*)Ch = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          f16* cp = (f16*)outp + cbase + (int64_t)m * ldo + n;
+          if (full && ((((uintptr_t)cp) & 15) == 0)) {
+            *(f16x8*)cp = f16x8{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
           } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (n0 + j < Nout) Ch[j] = (f16)v[j];
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j];
           }
         }
       }
@@ -597,13 +642,18 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
       MGLD_REQUIRE(p->T > 0 && p->HW > 0 && p->M % (p->T * p->HW) == 0, "igemm: tconv geometry");
     }
   }
+  if (p->tap_inner)
+    MGLD_REQUIRE(p->mode != MGLD_MODE_LINEAR && (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2),
+                 "igemm: tap_inner needs a gather mode with Cin % 64 == 0 and no upsample fold");
   if (p->rowvec) MGLD_REQUIRE(p->rows_per_frame > 0, "igemm: rows_per_frame");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;
   choose(p, &cfg, &splits, &kchunk);
   switch (cfg) {
-    case 256128: return launch_cfg<256, 128, 64, 64, 3>(p, s, 1, kchunk);
+    case 256128:
+      if (igemm_opt() & 8) return launch_cfg<256, 128, 64, 64, 3>(p, s, 1, kchunk);
+      return launch_cfg<256, 128, 64, 64, 2>(p, s, 1, kchunk);
     case 128128:
       if (igemm_opt() & 8) return launch_cfg<128, 128, 64, 64, 3>(p, s, splits, kchunk);
       return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);

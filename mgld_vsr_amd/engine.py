@@ -13,13 +13,25 @@ from . import hip
 # ------------------------------------------------------------------------------------------------------------------
 # weight packing (done once, on the host, in fp32 -> fp16)
 # ------------------------------------------------------------------------------------------------------------------
-def pack_conv3x3(w, cin_pad=None):
-    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin_pad] with K index = (ky*3+kx)*Cin_pad + c  (tap-major, channel contiguous)."""
+def conv_tap_inner(cin_pad, up2=False):
+    """K-axis order the igemm uses for a 3x3 conv: True = (64-channel block, tap, channel) — all 9 taps of one channel
+    block back to back so the shifted re-reads of the input hit L1/L2; False = (tap, Cin) (any Cin % 8, upsample fold)."""
+    return (cin_pad % 64 == 0) and not up2
+
+
+def pack_conv3x3(w, cin_pad=None, tap_inner=None):
+    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin_pad].  K index = (ky*3+kx)*Cin_pad + c, or, when tap_inner (default: whenever
+    Cin_pad % 64 == 0), K index = ((c // 64) * 9 + (ky*3+kx)) * 64 + c % 64."""
     cout, cin, kh, kw = w.shape
     assert kh == 3 and kw == 3
     cp = cin_pad or ((cin + 7) // 8 * 8)
+    if tap_inner is None:
+        tap_inner = conv_tap_inner(cp)
     out = torch.zeros(cout, 9, cp, dtype=w.dtype)
     out[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, 9, cin)
+    if tap_inner:
+        assert cp % 64 == 0
+        out = out.reshape(cout, 9, cp // 64, 64).permute(0, 2, 1, 3)
     return out.reshape(cout, 9 * cp).contiguous()
 
 
@@ -181,7 +193,8 @@ class Engine:
         assert wp.shape[1] == 9 * cin, (wp.shape, cin)
         hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec,
                   rows_per_frame=rows_per_frame or ho * wo, resid=None if resid is None else resid.v, act=act, alpha=alpha,
-                  beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0))
+                  beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0),
+                  tap_inner=1 if conv_tap_inner(cin, up2) else 0)   # must match pack_conv3x3(..., tap_inner) of wp
         self.launches += 1
         return out
 

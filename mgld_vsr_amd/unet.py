@@ -58,7 +58,8 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
 
     def run(self, eng, x, out=None):
-        w = eng.weight("c3", (self.conv.weight,), pack_conv3x3)
+        # nearest-2x upsample folded into the conv gather: per-lane taps -> (tap, Cin) weight order
+        w = eng.weight("c3up", (self.conv.weight,), lambda t: pack_conv3x3(t, tap_inner=False))
         b = eng.f32("b", self.conv.bias)
         return eng.conv3x3(x, w, b, self.out_channels, out=out, up2=True)
 

@@ -24,7 +24,8 @@ def Normalize(in_channels, num_groups=32):
 
 
 def _conv3(eng, conv, x, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, **kw):
-    w = eng.weight("c3", (conv.weight,), lambda t: pack_conv3x3(t, x.C))
+    up2 = bool(kw.get("up2", False))
+    w = eng.weight("c3up" if up2 else "c3", (conv.weight,), lambda t: pack_conv3x3(t, x.C, tap_inner=False if up2 else None))
     return eng.conv3x3(x, w, eng.f32("b", conv.bias), conv.out_channels, out=out, resid=resid, act=act, alpha=alpha, beta=beta,
                        **kw)
 

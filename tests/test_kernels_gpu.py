@@ -158,6 +158,23 @@ def test_igemm_conv3x3(hip, n, cin, cout, h, w, stride, pads, up2):
     assert rel_l2(_from_tok(out.cpu().float(), n, ho, wo), ref) < 1e-3
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,stride", [(2, 128, 96, 16, 16, 1), (1, 320, 320, 24, 16, 1), (2, 64, 64, 16, 16, 2),
+                                                   (8, 1280, 256, 8, 8, 1)])
+def test_igemm_conv3x3_tap_inner(hip, n, cin, cout, h, w, stride):
+    """(64-channel block, tap, channel) K order — the layout the engine packs whenever Cin % 64 == 0"""
+    from mgld_vsr_amd.engine import pack_conv3x3
+    x = h16(rnd(n, cin, h, w, seed=60))
+    wt = h16(rnd(cout, cin, 3, 3, seed=61, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=62)
+    ref = F.conv2d(x.float(), wt.float(), b, stride=stride, padding=1)
+    ho, wo = ref.shape[2], ref.shape[3]
+    wk = pack_conv3x3(wt, tap_inner=True).to(DEV)
+    out = torch.empty(n * ho * wo, cout, dtype=torch.half, device=DEV)
+    hip.igemm(_to_tok(x).to(DEV), wk, out, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=(cin, h, w, ho, wo, stride, 1, 1, 0),
+              tap_inner=1)
+    assert rel_l2(_from_tok(out.cpu().float(), n, ho, wo), ref) < 1e-3
+
+
 def test_igemm_conv_rowvec(hip):
     n, cin, cout, h, w = 3, 32, 64, 8, 8
     x = h16(rnd(n, cin, h, w, seed=23))

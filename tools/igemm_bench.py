@@ -50,7 +50,8 @@ def main():
 
         def launch():
             if mode == 1:
-                hip.igemm(a, w, out, mode=1, bias=bias, conv=(Cin, H, H, H, H, 1, 1, 1, 0))
+                hip.igemm(a, w, out, mode=1, bias=bias, conv=(Cin, H, H, H, H, 1, 1, 1, 0),
+                          tap_inner=int(os.environ.get("MGLD_TAP_INNER", "1")) if Cin % 64 == 0 else 0)
             else:
                 hip.igemm(a, w, out, bias=bias, act=act)
         for _ in range(3):
