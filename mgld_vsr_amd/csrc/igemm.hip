@@ -29,6 +29,10 @@ namespace {
 #ifndef MGLD_IGEMM_OPT_DEFAULT
 #define MGLD_IGEMM_OPT_DEFAULT 0
 #endif
+#ifndef MGLD_IGEMM_ABLATE
+#define MGLD_IGEMM_ABLATE 0   // timing-only ablation builds: 16 no W traffic, 32 no MFMA, 128 no compute, 256 no DMA, 512 no epilogue
+#endif
+constexpr int ABL = MGLD_IGEMM_ABLATE;
 
 constexpr int BK = 64;          // k depth per stage (fp16 elements) = 128 B per tile row
 constexpr int ROWB = BK * 2;    // bytes per tile row in LDS
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   }
 
   auto issue_stage = [&](int buf) {
-    if (opt & 256) return;  // ablation (timing only): no global->LDS traffic at all
+    if constexpr (ABL & 256) return;  // ablation build (timing only): no global->LDS traffic at all
     char* sbase = smem + buf * STAGE + wave * 1024;
     if constexpr (FAST) {
       if constexpr (MODE == MGLD_MODE_LINEAR) {
@@ -247,17 +251,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
           if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
         }
       }
-      if (!(opt & 16)) {  // (opt bit 16: ablation, timing only — skip the weight-tile traffic)
+      if constexpr (!(ABL & 16)) {  // (ablation build bit 16: skip the weight-tile traffic)
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
           glds16(fw_ptr[j], sbase + BM * ROWB + j * (NW * 1024));
           fw_ptr[j] += fw_step[j];
-        }
-      }
-      if (opt & 64) {     // (opt bit 64: ablation — re-read the FIRST A stage only: no A traffic growth with K)
-#pragma unroll
-        for (int j = 0; j < JA; ++j) {
-          if constexpr (MODE == MGLD_MODE_LINEAR) fa_ptr[j] -= fa_step[j];
         }
       }
     } else {
@@ -346,29 +344,32 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     }
     const char* sb = smem + cur * STAGE;
     cur = (cur + 1 == NST) ? 0 : cur + 1;
-    if (opt & 128) continue;  // ablation (timing only): no LDS reads, no MFMA
+    if constexpr (ABL & 128) continue;  // ablation build (timing only): no LDS reads, no MFMA
+    // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run (two register sets, static indices)
+    f16x8 fa[2][MI], fw[2][NI];
+    auto load_frags = [&](int ks, int set) {
+      const int cl = ks * 2 + lhi;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[set][mi] = *(const f16x8*)(sb + a_off[mi] + ((cl ^ a_key[mi]) << 4));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fw[set][ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
+    };
+    load_frags(0, 0);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      const int cl = ks * 2 + lhi;
-      f16x8 fa[MI], fw[NI];
+      if (ks + 1 < BK / 16) load_frags(ks + 1, (ks + 1) & 1);
+      if constexpr (ABL & 32) {  // ablation build: keep the LDS reads, skip the matrix pipe
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const f16x8*)(sb + a_off[mi] + ((cl ^ a_key[mi]) << 4));
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[ks & 1][mi]));
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
-      if (opt & 2) __builtin_amdgcn_s_setprio(1);
-      if (opt & 32) {  // ablation (timing only): keep the LDS reads, skip the matrix pipe
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[mi]));
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ni]));
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ks & 1][ni]));
       } else {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks & 1][ni], fa[ks & 1][mi], acc[ni][mi], 0, 0, 0);
       }
-      if (opt & 2) __builtin_amdgcn_s_setprio(0);
     }
   }
 
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   // LDS patch (fp32, bias/activation already applied) and writes whole row segments: 8 lanes x 16 B = 128 B contiguous
   // per output row, residual rows read the same way.  (Wave-local: no block barrier except the one releasing the stages.)
   __syncthreads();
-  if (opt & 512) return;  // ablation (timing only): no epilogue
+  if constexpr (ABL & 512) return;  // ablation build (timing only): no epilogue
   const bool geglu = (!splitk) && (p.act == MGLD_ACT_GEGLU);
   constexpr int LDW = WN + 4;                       // patch row stride (floats): 16-B aligned, conflict-free b128
   float* patch = (float*)smem + wave * (32 * LDW);
@@ -593,7 +594,9 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   if (t128 >= 384) { *cfg = 128128; return; }
   // too few 128x128 tiles for 256 CUs
   if (batch == 1 && K >= 1536 && g_ws != nullptr) {
-    int s = (int)((448 + t128 - 1) / t128);
+    static int target = -1;   // blocks to aim for (env MGLD_SPLITK_TARGET, tuning)
+    if (target < 0) { const char* e = getenv("MGLD_SPLITK_TARGET"); target = e ? atoi(e) : 448; }
+    int s = (int)((target + t128 - 1) / t128);
     const int smax = (int)(K / 512);
     if (s > smax) s = smax;
     if (s > 16) s = 16;
