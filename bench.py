@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--ddpm-steps", type=int, default=50)
     ap.add_argument("--guidance", action="store_true", help="flow-guided latent warp on (configs[2]); default off (configs[1])")
     ap.add_argument("--tile", action="store_true", help="aggregation sampling over 64x64 latent tiles, overlap 32 (configs[3]: use with --size 1024)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (PMC profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
@@ -126,13 +127,23 @@ def roofline(pipe, args, frames, noise, flows, masks):
             json.dump(rows, fh, indent=0)
     dom_cfg = max(tot, key=lambda c: tot[c]["ms"])
     dom_tile = dom_cfg % 1000000
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; they come
+    # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/, see its note)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pm = json.load(fh)
+        if f"<{dom_tile // 1000},{dom_tile % 1000}>" in pm.get("kernel", ""):
+            traffic = round(pm["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
     d = tot[dom_cfg]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     all_flops = sum(t["flops"] for t in tot.values())
     all_ms = sum(t["ms"] for t in tot.values())
     return {
         "bound": "mfma", "kernel": f"igemm_kernel<{dom_tile // 1000},{dom_tile % 1000}>" + (f" splitK x{dom_cfg // 1000000}" if dom_cfg >= 1000000 else ""), "achieved": round(achieved, 2),
-        "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
+        "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
         "launches_per_segment": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
         "kernel_ms_per_segment": round(d["ms"], 2),
         "all_igemm": {"tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "ms_per_segment": round(all_ms, 2),
@@ -183,12 +194,14 @@ def cpu_baseline(args):
 
 
 TILE = None
+GRAPH = True
 
 
 def main():
-    global TILE
+    global TILE, GRAPH
     args = parse()
     TILE = (64, 32) if args.tile else None
+    GRAPH = not args.no_graph
     rank, world, local = dist_setup(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
@@ -201,11 +214,11 @@ def main():
     assert parallel.shard_segments(world, rank, world) == [rank]
 
     for _ in range(args.warmup):
-        pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE)
+        pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH)
     parallel.barrier()                       # barrier + torch.cuda.synchronize() on both sides of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE)
+        out = pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH)
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0)
     ok = bool(torch.isfinite(out).all())

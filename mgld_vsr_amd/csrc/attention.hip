@@ -121,35 +121,45 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const MgldAttn p) {
       }
     }
     // ---- online softmax (lane: query q0+l31; keys (r&3)+8*(r>>2)+4*lhi of each 32-key tile) ----
+    // The running max is kept in RAW score units; the softmax scale (with log2 e folded in) enters through one FMA per
+    // element, p = exp2(s*sc - m*sc).  Keys past Nkv exist only in the last tile (wave-uniform branch).
+    if (kbase + KT > Nkv) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + k2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (key >= Nkv) st[k2][r] = -1e30f;
+        }
+    }
     float mx = -1e30f;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kbase + k2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const float s = (key < Nkv) ? st[k2][r] * sc : -1e30f;
-        st[k2][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[k2][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float mneg = -m_new * sc;
     float rs = 0.f;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(st[k2][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[k2][r], sc, mneg));
         st[k2][r] = e;
         rs += e;
       }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
+    if (__any(m_new != m_run)) {  // rescale only when some row's max moved (rare after the first tiles)
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    l_run += rs;
     m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
 
     // ---- O^T += V^T P^T : 4 chunks of 16 keys; slot jj of chunk c <-> register 8*(c&1)+jj of tile c>>1 ----
 #pragma unroll
