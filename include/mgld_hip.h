@@ -105,18 +105,18 @@ int mgld_set_workspace(void* ptr, int64_t bytes);
 
 /* ---- K3: GroupNorm (32 groups) on NHWC fp16, fp32 statistics -----------------------------------------------
  * Replaces nn.GroupNorm / GroupNorm32 (diffusionmodules/util.py:214-216, model.py:80-81, attention.py:87-88).
- * stats: two-stage (per-chunk per-channel partial sums -> fp64 combine) -> mean/rstd [frames, groups, 2].
- * `partials` workspace: frames * chunks(=mgld_gn_chunks(rows)) * C * 2 floats.
+ * mgld_gn_stats: one launch; per (frame, row chunk) the per-group (sum, sumsq) in fp64 ->
+ *   gsums[frames][chunks = mgld_gn_chunks(rows)][groups][2] doubles.  The consumers below finish the reduction over
+ *   chunks (fp64) in their prologue and derive mean / rstd themselves — no separate finalize launch.  groups <= 64.
  */
 int mgld_gn_chunks(int rows_per_frame);
-int mgld_gn_stats(const void* x, int frames, int rows_per_frame, int C, int ld, int groups, float eps,
-                  float* partials, float* stats_out, void* stream);
+int mgld_gn_stats(const void* x, int frames, int rows_per_frame, int C, int ld, int groups, double* gsums, void* stream);
 /* y = [silu]((x-mean)*rstd*gamma+beta); x,y fp16 NHWC */
-int mgld_gn_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta,
+int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta,
                   void* y, int ldy, int frames, int rows_per_frame, int C, int groups, int silu, void* stream);
 /* SPADE modulation + residual (spade.py:93-111, openaimodel.py:481-482):
  * y = skip + ((h-mean)*rstd*gamma+beta) * (1+gb[:, 0:C]) + gb[:, C:2C]          */
-int mgld_spade_apply(const void* h, int ldh, const float* stats, const float* gamma, const float* beta,
+int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, const float* gamma, const float* beta,
                      const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
                      int frames, int rows_per_frame, int C, int groups, void* stream);
 /* LayerNorm over C per token (attention.py:125,427-429), eps 1e-5 */

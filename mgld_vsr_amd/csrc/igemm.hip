@@ -219,7 +219,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     c = kl - tap * Cin;
   }
 
-  auto issue_stage = [&](int buf) {
+  // (tap / channel offset are passed BY VALUE and advanced in the caller's scope: captured by reference and mutated
+  // inside the lambda they ended up in scratch memory, turning the whole address computation into per-lane VALU work.)
+  auto issue_stage = [&](int buf, const int u_tap, const int u_c0) {
     if constexpr (ABL & 256) return;  // ablation build (timing only): no global->LDS traffic at all
     char* sbase = smem + buf * STAGE + wave * 1024;
     if constexpr (FAST) {
@@ -233,22 +235,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
         // uniform byte offset of this stage's tap + channel block
         int64_t soff;
         if constexpr (MODE == MGLD_MODE_CONV3X3) {
-          const int ky = s_tap / 3, kx = s_tap - ky * 3;
-          soff = ((int64_t)(ky * p.Win + kx) * p.lda + s_c0) * 2;
+          const int ky = (u_tap * 11) >> 5, kx = u_tap - ky * 3;   // tap / 3 for tap in [0, 9)
+          soff = ((int64_t)(ky * p.Win + kx) * p.lda + u_c0) * 2;
         } else {
-          soff = ((int64_t)s_tap * p.HW * p.lda + s_c0) * 2;
+          soff = ((int64_t)u_tap * p.HW * p.lda + u_c0) * 2;
         }
+        const unsigned tbit = 1u << u_tap;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
-          const char* src = ((fa_mask[j] >> s_tap) & 1u) ? fa_ptr[j] + soff : zero;
+          const char* src = (fa_mask[j] & tbit) ? fa_ptr[j] + soff : zero;
           glds16(src, sbase + j * (NW * 1024));
-        }
-        if (p.tap_inner) {  // K order (chunk64, tap, c): all taps of one 64-channel block back to back (L1/L2 reuse)
-          constexpr int NTAP = (MODE == MGLD_MODE_CONV3X3) ? 9 : 3;
-          if (++s_tap == NTAP) { s_tap = 0; s_c0 += BK; }
-        } else {            // K order (tap, Cin)
-          s_c0 += BK;
-          if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
         }
       }
       if constexpr (!(ABL & 16)) {  // (ablation build bit 16: skip the weight-tile traffic)
@@ -320,9 +316,27 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   // barrier), then the barrier makes every wave's stage kt visible and retires all reads of the buffer about to be
   // refilled.
   static_assert(NST == 2 || NST == 3, "2 or 3 stages");
+  // wave-uniform K position of the NEXT stage to issue; kept in this scope as plain scalars (SGPRs)
+  int u_tap = __builtin_amdgcn_readfirstlane(s_tap), u_c0 = __builtin_amdgcn_readfirstlane(s_c0);
+#define MGLD_ADVANCE_TAP()                                                            \
+  if constexpr (FAST && MODE != MGLD_MODE_LINEAR) {                                   \
+    constexpr int NTAP_ = (MODE == MGLD_MODE_CONV3X3) ? 9 : 3;                        \
+    if (p.tap_inner) { /* K order (chunk64, tap, c): taps of one 64-channel block back to back (L1/L2 reuse) */ \
+      const bool wrap_ = (u_tap + 1 == NTAP_);                                        \
+      u_c0 = wrap_ ? u_c0 + BK : u_c0;                                                \
+      u_tap = wrap_ ? 0 : u_tap + 1;                                                  \
+    } else {           /* K order (tap, Cin) */                                       \
+      const bool wrap_ = (u_c0 + BK >= Cin);                                          \
+      u_c0 = wrap_ ? u_c0 + BK - Cin : u_c0 + BK;                                     \
+      u_tap = wrap_ ? u_tap + 1 : u_tap;                                              \
+    }                                                                                 \
+  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) issue_stage(s);
+    if (s < nk) {
+      issue_stage(s, u_tap, u_c0);
+      MGLD_ADVANCE_TAP();
+    }
   int cur = 0;  // buffer of stage kt
   for (int kt = 0; kt < nk; ++kt) {
     if (NST == 3 && kt + 1 < nk) {
@@ -340,7 +354,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
       const int nxt = kt + NST - 1;
       int nb = cur + NST - 1;
       if (nb >= NST) nb -= NST;
-      if (nxt < nk) issue_stage(nb);
+      if (nxt < nk) {
+        issue_stage(nb, u_tap, u_c0);
+        MGLD_ADVANCE_TAP();
+      }
     }
     const char* sb = smem + cur * STAGE;
     cur = (cur + 1 == NST) ? 0 : cur + 1;

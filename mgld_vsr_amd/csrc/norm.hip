@@ -5,18 +5,20 @@
 
 namespace {
 
-// ---- stage 1: per-(frame, chunk) per-channel partial sums -------------------------------------------------
-// grid (chunks, frames), 256 threads.  partials layout: [frame][chunk][C][2] (sum, sumsq).
+// ---- stage 1: per-(frame, chunk) per-GROUP partial sums ----------------------------------------------------
+// grid (chunks, frames), 256 threads.  Per-channel fp32 sums over the chunk's rows are combined per group in fp64 and
+// written as gsums[frame][chunk][group][2] (sum, sumsq; doubles).  The consumers (gn_apply / spade_apply) finish the
+// reduction over chunks in their prologue, so there is no separate "finalize" launch.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x, int rows, int C, int ld,
-                                                         int rows_per_chunk, float* __restrict__ partials) {
-  extern __shared__ float sred[];  // [rpi][C][2] when rpi > 1
+                                                         int rows_per_chunk, int groups, double* __restrict__ gsums) {
+  extern __shared__ float sred[];  // [max(rpi,1)][C][2]
   const int NV = C >> 3;
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, frame = blockIdx.y, chunks = gridDim.x;
   const int r0 = chunk * rows_per_chunk;
   const int r1 = min(rows, r0 + rows_per_chunk);
   const f16* xf = x + (int64_t)frame * rows * ld;
-  float* pout = partials + ((int64_t)(frame * chunks + chunk) * C) * 2;
+  double* gout = gsums + ((int64_t)(frame * chunks + chunk) * groups) * 2;
 
   if (NV >= 256) {
     // wide rows: each thread owns vector columns tid, tid+256, ... ; one row at a time
@@ -30,87 +32,97 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
         for (int j = 0; j < 8; ++j) { const float f = (float)d[j]; s[j] += f; q[j] += f * f; }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { pout[(v * 8 + j) * 2] = s[j]; pout[(v * 8 + j) * 2 + 1] = q[j]; }
+      for (int j = 0; j < 8; ++j) { sred[(v * 8 + j) * 2] = s[j]; sred[(v * 8 + j) * 2 + 1] = q[j]; }
     }
-    return;
-  }
-  const int rpi = 256 / NV;  // rows handled per iteration
-  const int rr = tid / NV, v = tid - rr * NV;
-  float s[8], q[8];
+  } else {
+    const int rpi = 256 / NV;  // rows handled per iteration
+    const int rr = tid / NV, v = tid - rr * NV;
+    float s[8], q[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  if (rr < rpi) {
-    constexpr int U = 4;  // rows in flight per thread
-    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = r0 + rr; r < r1; r += rpi * U) {
-      f16x8 d[U];
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (rr < rpi) {
+      constexpr int U = 4;  // rows in flight per thread
+      const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = r0 + rr; r < r1; r += rpi * U) {
+        f16x8 d[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        d[u] = (r + u * rpi < r1) ? *(const f16x8*)(xf + (int64_t)(r + u * rpi) * ld + v * 8) : z8;
+        for (int u = 0; u < U; ++u)
+          d[u] = (r + u * rpi < r1) ? *(const f16x8*)(xf + (int64_t)(r + u * rpi) * ld + v * 8) : z8;
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = (float)d[u][j]; s[j] += f; q[j] += f * f; }
+          for (int j = 0; j < 8; ++j) { const float f = (float)d[u][j]; s[j] += f; q[j] += f * f; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sred[((rr * C) + v * 8 + j) * 2] = s[j];
+        sred[((rr * C) + v * 8 + j) * 2 + 1] = q[j];
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sred[((rr * C) + v * 8 + j) * 2] = s[j];
-      sred[((rr * C) + v * 8 + j) * 2 + 1] = q[j];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {   // fold the rpi row slots into slot 0 (column c is touched by this thread only)
+      float ss = 0.f, qq = 0.f;
+      for (int r = 0; r < rpi; ++r) { ss += sred[(r * C + c) * 2]; qq += sred[(r * C + c) * 2 + 1]; }
+      sred[c * 2] = ss; sred[c * 2 + 1] = qq;
     }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float ss = 0.f, qq = 0.f;
-    for (int r = 0; r < rpi; ++r) { ss += sred[(r * C + c) * 2]; qq += sred[(r * C + c) * 2 + 1]; }
-    pout[c * 2] = ss; pout[c * 2 + 1] = qq;
+  const int cg = C / groups;
+  for (int g = tid; g < groups; g += 256) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < cg; ++i) { s += (double)sred[(g * cg + i) * 2]; q += (double)sred[(g * cg + i) * 2 + 1]; }
+    gout[g * 2] = s; gout[g * 2 + 1] = q;
   }
 }
 
-// ---- stage 2: combine in fp64 -> (mean, rstd) per (frame, group).  grid (groups, frames), 64 threads.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partials, int chunks, int C,
-                                                        int groups, int rows, float eps, float* __restrict__ stats) {
-  const int g = blockIdx.x, frame = blockIdx.y;
-  const int cg = C / groups;
-  const float* p = partials + (int64_t)frame * chunks * C * 2;
-  double s = 0.0, q = 0.0;
-  const int items = chunks * cg;
-  for (int i = threadIdx.x; i < items; i += 64) {
-    const int ch = i / cg, cc = i - ch * cg;
-    const float* e = p + ((int64_t)ch * C + g * cg + cc) * 2;
-    s += (double)e[0]; q += (double)e[1];
+// ---- (mean, rstd) of every group of one frame from the chunk sums, fp64 combine; result in LDS [groups][2].
+// Called by all 256 threads of a block; ends with a barrier.
+constexpr int GN_MAX_GROUPS = 64;
+__device__ __forceinline__ void gn_group_stats(const double* __restrict__ gs, int chunks, int groups, int rows, int cg,
+                                               float eps, float (*st)[2]) {
+  const int tid = threadIdx.x;
+  const int sub = tid & 7;
+  for (int g = tid >> 3; g < groups; g += 32) {
+    double s = 0.0, q = 0.0;
+    for (int ch = sub; ch < chunks; ch += 8) {
+      s += gs[((int64_t)ch * groups + g) * 2];
+      q += gs[((int64_t)ch * groups + g) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (sub == 0) {
+      const double n = (double)rows * cg;
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      st[g][0] = (float)mean;
+      st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
-  s = wave_sum_d(s); q = wave_sum_d(q);
-  if (threadIdx.x == 0) {
-    const double n = (double)rows * cg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[(frame * groups + g) * 2] = (float)mean;
-    stats[(frame * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
+  __syncthreads();
 }
 
 // ---- apply: y = [silu]((x-mean)*rstd*gamma+beta) ----------------------------------------------------------------
 template <bool SPADE>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int ldx, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const f16* __restrict__ gb, int ldgb, const f16* __restrict__ skip,
-                                                       int ldskip, f16* __restrict__ y, int ldy, int64_t total_rows,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int ldx, const double* __restrict__ gsums,
+                                                       int chunks, float eps, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const f16* __restrict__ gb, int ldgb,
+                                                       const f16* __restrict__ skip, int ldskip, f16* __restrict__ y, int ldy,
                                                        int rows_per_frame, int C, int groups, int silu) {
   // grid (row chunks, frames).  A thread owns ONE 8-channel vector column for all its rows, so the per-channel scale /
   // shift (rstd*gamma, beta - mean*rstd*gamma) are computed once into registers and the row loop is load-fma-store.
+  __shared__ float st[GN_MAX_GROUPS][2];
   const int NV = C >> 3;
   const int cg = C / groups;
   const int frame = blockIdx.y;
+  gn_group_stats(gsums + (int64_t)frame * chunks * groups * 2, chunks, groups, rows_per_frame, cg, eps, st);
   const int rows_per_chunk = (rows_per_frame + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(rows_per_frame, r0 + rows_per_chunk);
-  const float* st = stats + (int64_t)frame * groups * 2;
   const int64_t fbase = (int64_t)frame * rows_per_frame;
   const int rpi = NV >= 256 ? 1 : 256 / NV;
   const int rr = NV >= 256 ? 0 : threadIdx.x / NV;
   if (rr >= rpi) return;
-  (void)total_rows;
   for (int v = NV >= 256 ? threadIdx.x : threadIdx.x - rr * NV; v < NV; v += 256) {
     const int c0 = v * 8;
     float sa[8], sb[8];
@@ -118,8 +130,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     for (int j = 0; j < 8; ++j) {
       const int c = c0 + j;
       const int g = c / cg;
-      sa[j] = st[g * 2 + 1] * gamma[c];
-      sb[j] = beta[c] - st[g * 2] * sa[j];
+      sa[j] = st[g][1] * gamma[c];
+      sb[j] = beta[c] - st[g][0] * sa[j];
     }
     constexpr int U = 4;  // rows in flight per thread
     for (int r = r0 + rr; r < r1; r += rpi * U) {
@@ -214,30 +226,21 @@ extern "C" int mgld_gn_chunks(int rows_per_frame) {
   return cdiv(rows_per_frame, rows_per_chunk_for(rows_per_frame));
 }
 
-extern "C" int mgld_gn_stats(const void* x, int frames, int rows, int C, int ld, int groups, float eps,
-                             float* partials, float* stats_out, void* stream) {
-  MGLD_REQUIRE(x && partials && stats_out, "gn_stats: null pointer");
+extern "C" int mgld_gn_stats(const void* x, int frames, int rows, int C, int ld, int groups, double* gsums,
+                             void* stream) {
+  MGLD_REQUIRE(x && gsums, "gn_stats: null pointer");
   MGLD_REQUIRE(frames > 0 && rows > 0 && C > 0 && groups > 0, "gn_stats: empty");
-  MGLD_REQUIRE((C & 7) == 0 && (ld & 7) == 0 && C % groups == 0, "gn_stats: C%8, ld%8, C%groups");
+  MGLD_REQUIRE((C & 7) == 0 && (ld & 7) == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "gn_stats: C%8, ld%8, C%groups");
   MGLD_REQUIRE(((uintptr_t)x & 15) == 0, "gn_stats: alignment");
   const int rpc = rows_per_chunk_for(rows);
   const int chunks = cdiv(rows, rpc);
   const int NV = C >> 3;
   const int rpi = NV >= 256 ? 1 : 256 / NV;
-  const size_t shm = NV >= 256 ? 0 : (size_t)rpi * C * 2 * sizeof(float);
+  const size_t shm = (size_t)rpi * C * 2 * sizeof(float);
   MGLD_REQUIRE(shm <= 64 * 1024, "gn_stats: LDS budget");
   hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, frames), dim3(256), shm, (hipStream_t)stream, (const f16*)x, rows, C,
-                     ld, rpc, partials);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, frames), dim3(64), 0, (hipStream_t)stream, partials, chunks, C,
-                     groups, rows, eps, stats_out);
+                     ld, rpc, groups, gsums);
   return mgld_check_launch("gn_stats");
-}
-
-static int elem_grid(int64_t total) {
-  int64_t b = (total + 255) / 256;
-  if (b > 256 * 16) b = 256 * 16;
-  if (b < 1) b = 1;
-  return (int)b;
 }
 
 static dim3 apply_grid(int frames, int rows) {
@@ -247,27 +250,27 @@ static dim3 apply_grid(int frames, int rows) {
   return dim3(chunks, frames);
 }
 
-extern "C" int mgld_gn_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                             int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
-  MGLD_REQUIRE(x && stats && gamma && beta && y, "gn_apply: null pointer");
-  MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C % groups == 0, "gn_apply: alignment");
-  const int64_t total_rows = (int64_t)frames * rows;
+extern "C" int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta,
+                             void* y, int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
+  MGLD_REQUIRE(x && gsums && gamma && beta && y, "gn_apply: null pointer");
+  MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS,
+               "gn_apply: alignment");
   hipLaunchKernelGGL((gn_apply_kernel<false>), apply_grid(frames, rows), dim3(256), 0, (hipStream_t)stream,
-                     (const f16*)x, ldx, stats, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, total_rows, rows, C,
-                     groups, silu);
+                     (const f16*)x, ldx, gsums, mgld_gn_chunks(rows), eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy,
+                     rows, C, groups, silu);
   return mgld_check_launch("gn_apply");
 }
 
-extern "C" int mgld_spade_apply(const void* h, int ldh, const float* stats, const float* gamma, const float* beta,
-                                const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy, int frames,
-                                int rows, int C, int groups, void* stream) {
-  MGLD_REQUIRE(h && stats && gamma && beta && gb && skip && y, "spade_apply: null pointer");
-  MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0,
+extern "C" int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, const float* gamma,
+                                const float* beta, const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
+                                int frames, int rows, int C, int groups, void* stream) {
+  MGLD_REQUIRE(h && gsums && gamma && beta && gb && skip && y, "spade_apply: null pointer");
+  MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0 &&
+                   groups <= GN_MAX_GROUPS,
                "spade_apply: alignment");
-  const int64_t total_rows = (int64_t)frames * rows;
   hipLaunchKernelGGL((gn_apply_kernel<true>), apply_grid(frames, rows), dim3(256), 0, (hipStream_t)stream,
-                     (const f16*)h, ldh, stats, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy,
-                     total_rows, rows, C, groups, 0);
+                     (const f16*)h, ldh, gsums, mgld_gn_chunks(rows), eps, gamma, beta, (const f16*)gb, ldgb,
+                     (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0);
   return mgld_check_launch("spade_apply");
 }
 

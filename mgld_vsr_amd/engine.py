@@ -221,17 +221,18 @@ class Engine:
         return out
 
     def gn_stats(self, x, eps, groups=None):
+        """One launch: per-chunk group sums (fp64).  Returns (gsums, eps); the apply kernels finish the reduction."""
         g = groups or self.GROUPS
-        partials = self.arena.alloc((x.n * hip.gn_chunks(x.hw) * x.C * 2,), torch.float32)
-        stats = self.arena.alloc((x.n, g, 2), torch.float32)
-        hip.gn_stats(x.v, x.n, x.hw, g, eps, partials, stats)
-        self.launches += 2
-        return stats
+        gsums = self.arena.alloc((x.n, hip.gn_chunks(x.hw), g, 2), torch.float64)
+        hip.gn_stats(x.v, x.n, x.hw, g, gsums)
+        self.launches += 1
+        return gsums, float(eps)
 
     def gn_apply(self, x, stats, gamma, beta, silu, out=None, groups=None):
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C)
-        hip.gn_apply(x.v, stats, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
+        gsums, eps = stats
+        hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
         self.launches += 1
         return out
 
@@ -241,7 +242,8 @@ class Engine:
     def spade_apply(self, h, stats, gamma, beta, gb, skip, out=None):
         if out is None:
             out = self.act(h.n, h.h, h.w, h.C)
-        hip.spade_apply(h.v, stats, gamma, beta, gb.v, skip.v, out.v, h.n, h.hw, self.GROUPS)
+        gsums, eps = stats
+        hip.spade_apply(h.v, gsums, eps, gamma, beta, gb.v, skip.v, out.v, h.n, h.hw, self.GROUPS)
         self.launches += 1
         return out
 

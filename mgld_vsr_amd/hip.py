@@ -180,24 +180,25 @@ def gn_chunks(rows):
     return lib().mgld_gn_chunks(int(rows))
 
 
-def gn_stats(x, frames, rows, groups, eps, partials, stats):
-    _req_cuda(x, partials, stats)
-    _chk(lib().mgld_gn_stats(_p(x), frames, rows, x.shape[1], _ld(x), groups, C.c_float(eps), _p(partials), _p(stats),
-                             stream_ptr()), "gn_stats")
-    return stats
+def gn_stats(x, frames, rows, groups, gsums):
+    """gsums: float64 [frames, gn_chunks(rows), groups, 2] per-chunk group (sum, sumsq)."""
+    _req_cuda(x, gsums)
+    assert gsums.dtype == torch.float64 and gsums.numel() >= frames * gn_chunks(rows) * groups * 2
+    _chk(lib().mgld_gn_stats(_p(x), frames, rows, x.shape[1], _ld(x), groups, _p(gsums), stream_ptr()), "gn_stats")
+    return gsums
 
 
-def gn_apply(x, stats, gamma, beta, y, frames, rows, groups, silu):
-    _req_cuda(x, stats, gamma, beta, y)
-    _chk(lib().mgld_gn_apply(_p(x), _ld(x), _p(stats), _p(gamma), _p(beta), _p(y), _ld(y), frames, rows, x.shape[1], groups,
-                             1 if silu else 0, stream_ptr()), "gn_apply")
+def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu):
+    _req_cuda(x, gsums, gamma, beta, y)
+    _chk(lib().mgld_gn_apply(_p(x), _ld(x), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), _p(y), _ld(y), frames, rows,
+                             x.shape[1], groups, 1 if silu else 0, stream_ptr()), "gn_apply")
     return y
 
 
-def spade_apply(h, stats, gamma, beta, gb, skip, y, frames, rows, groups):
-    _req_cuda(h, stats, gamma, beta, gb, skip, y)
-    _chk(lib().mgld_spade_apply(_p(h), _ld(h), _p(stats), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip), _ld(skip), _p(y),
-                                _ld(y), frames, rows, h.shape[1], groups, stream_ptr()), "spade_apply")
+def spade_apply(h, gsums, eps, gamma, beta, gb, skip, y, frames, rows, groups):
+    _req_cuda(h, gsums, gamma, beta, gb, skip, y)
+    _chk(lib().mgld_spade_apply(_p(h), _ld(h), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip),
+                                _ld(skip), _p(y), _ld(y), frames, rows, h.shape[1], groups, stream_ptr()), "spade_apply")
     return y
 
 

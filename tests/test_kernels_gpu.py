@@ -209,7 +209,7 @@ def test_igemm_tconv(hip, clips, T):
 # norms
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("frames,C,h,w,eps", [(2, 320, 16, 16, 1e-5), (1, 1920, 8, 8, 1e-5), (3, 128, 24, 24, 1e-6),
-                                              (1, 2560, 8, 8, 1e-5), (2, 64, 4, 4, 1e-6)])
+                                              (1, 2560, 8, 8, 1e-5), (2, 64, 4, 4, 1e-6), (2, 320, 64, 64, 1e-5)])
 def test_groupnorm(hip, frames, C, h, w, eps):
     x = h16(rnd(frames, C, h, w, seed=30) * 1.5 + 0.3)
     gamma, beta = 1 + 0.1 * rnd(C, seed=31), 0.1 * rnd(C, seed=32)
@@ -218,15 +218,16 @@ def test_groupnorm(hip, frames, C, h, w, eps):
     xt[:, 8:8 + C] = _to_tok(x).to(DEV)
     xv = xt[:, 8:8 + C]
     rows = h * w
-    partials = torch.empty(frames * hip.gn_chunks(rows) * C * 2, dtype=torch.float32, device=DEV)
-    stats = torch.empty(frames, 32, 2, dtype=torch.float32, device=DEV)
-    hip.gn_stats(xv, frames, rows, 32, eps, partials, stats)
+    gsums = torch.empty(frames, hip.gn_chunks(rows), 32, 2, dtype=torch.float64, device=DEV)
+    hip.gn_stats(xv, frames, rows, 32, gsums)
     y = torch.empty(frames * rows, C, dtype=torch.half, device=DEV)
-    hip.gn_apply(xv, stats, gamma.to(DEV), beta.to(DEV), y, frames, rows, 32, True)
+    hip.gn_apply(xv, gsums, eps, gamma.to(DEV), beta.to(DEV), y, frames, rows, 32, True)
     ref = F.silu(F.group_norm(x.float(), 32, gamma, beta, eps))
-    xg = x.float().reshape(frames, 32, -1)
-    assert torch.allclose(stats[:, :, 0].cpu(), xg.mean(-1), atol=2e-5)
-    assert rel_l2(stats[:, :, 1].cpu(), 1 / torch.sqrt(xg.var(-1, unbiased=False) + eps)) < 1e-5
+    xg = x.double().reshape(frames, 32, -1)
+    tot = gsums.sum(1).cpu()                       # [frames, groups, (sum, sumsq)]: the chunk sums add up to the moments
+    n = xg.shape[-1]
+    assert torch.allclose(tot[:, :, 0] / n, xg.mean(-1), atol=2e-5)
+    assert rel_l2(tot[:, :, 1] / n, (xg * xg).mean(-1)) < 1e-5
     assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
 
 
@@ -236,12 +237,11 @@ def test_spade_apply(hip):
     hh, skip = h16(rnd(frames * rows, C, seed=33)), h16(rnd(frames * rows, C, seed=34))
     gb = h16(rnd(frames * rows, 2 * C, seed=35, scale=0.5))
     gamma, beta = 1 + 0.1 * rnd(C, seed=36), 0.1 * rnd(C, seed=37)
-    partials = torch.empty(frames * hip.gn_chunks(rows) * C * 2, dtype=torch.float32, device=DEV)
-    stats = torch.empty(frames, 32, 2, dtype=torch.float32, device=DEV)
+    gsums = torch.empty(frames, hip.gn_chunks(rows), 32, 2, dtype=torch.float64, device=DEV)
     hd = hh.to(DEV)
-    hip.gn_stats(hd, frames, rows, 32, 1e-5, partials, stats)
+    hip.gn_stats(hd, frames, rows, 32, gsums)
     y = torch.empty(frames * rows, C, dtype=torch.half, device=DEV)
-    hip.spade_apply(hd, stats, gamma.to(DEV), beta.to(DEV), gb.to(DEV), skip.to(DEV), y, frames, rows, 32)
+    hip.spade_apply(hd, gsums, 1e-5, gamma.to(DEV), beta.to(DEV), gb.to(DEV), skip.to(DEV), y, frames, rows, 32)
     hn = F.group_norm(_from_tok(hh.float(), frames, h, w), 32, gamma, beta, 1e-5)
     ref = _from_tok(skip.float(), frames, h, w) + hn * (1 + _from_tok(gb.float()[:, :C], frames, h, w)) + _from_tok(
         gb.float()[:, C:], frames, h, w)

@@ -38,7 +38,10 @@ def main():
     e0, e1 = hip.Event(), hip.Event()
     tot_ms = 0.0
     rows = []
-    for name, mode, M, N, K, Cin, H, act, weight in SHAPES:
+    only = os.environ.get("MGLD_BENCH_ONLY")            # e.g. "0,12": indices into SHAPES (for PMC passes)
+    iters = int(os.environ.get("MGLD_BENCH_ITERS", "20"))
+    shapes = [SHAPES[int(i)] for i in only.split(",")] if only else SHAPES
+    for name, mode, M, N, K, Cin, H, act, weight in shapes:
         if mode == 1:
             frames = M // (H * H)
             a = torch.randn(frames * H * H, Cin, device=dev).half()
@@ -57,11 +60,11 @@ def main():
         for _ in range(3):
             launch()
         e0.record()
-        for _ in range(20):
+        for _ in range(iters):
             launch()
         e1.record()
         e1.sync()
-        us = 1e3 * e0.elapsed_ms(e1) / 20
+        us = 1e3 * e0.elapsed_ms(e1) / iters
         tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
         tot_ms += us * weight / 1e3
         rows.append((name, us, tf))
