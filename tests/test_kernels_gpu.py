@@ -43,9 +43,10 @@ def test_igemm_linear(hip, M, N, K):
     assert rel_l2(out.cpu().float(), ref) < 1e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 1280, 11520), (2048, 640, 5760), (300, 200, 2048), (64, 1280, 23040)])
+@pytest.mark.parametrize("M,N,K", [(512, 1280, 11520), (2048, 640, 5760), (300, 200, 2048), (64, 1280, 23040),
+                                   (8192, 640, 2560), (2048, 1280, 5120)])
 def test_igemm_splitk(hip, M, N, K):
-    """few output tiles + deep K -> split along K into fp32 partials + reduce/epilogue kernel"""
+    """few output tiles + deep K -> split along K into fp32 slabs + reduce/epilogue kernel"""
     ws = hip._test_ws   # session-lifetime scratch registered by the `hip` fixture
     hip.set_workspace(ws)
     a, w, b = h16(rnd(M, K, seed=1)), h16(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
@@ -64,6 +65,25 @@ def test_igemm_splitk(hip, M, N, K):
     assert hip.igemm_config(p) < 1000000
     assert rel_l2(out2.cpu().float(), ref) < 1e-3
     hip.set_workspace(ws)
+
+
+def test_igemm_splitk_repeatable(hip):
+    """the K slices are summed in a fixed order: back-to-back launches of the same problem (no host sync in between)
+    give bit-identical results"""
+    M, N, K = 8192, 640, 2560
+    a, w = h16(rnd(M, K, seed=5)).to(DEV), h16(rnd(N, K, seed=6, scale=K ** -0.5)).to(DEV)
+    p = hip.MgldIGemm()
+    p.M, p.N, p.K, p.batch = M, N, K, 1
+    cfg = hip.igemm_config(p)
+    assert cfg >= 2000000, cfg               # split along K
+    outs = [torch.empty(M, N, dtype=torch.float32, device=DEV) for _ in range(12)]
+    for o in outs:
+        hip.igemm(a, w, o)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t()
+    assert rel_l2(outs[0], ref) < 1e-3
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 def test_igemm_transpose_detect(hip):
@@ -143,6 +163,8 @@ def _from_tok(t, n, h, w):
     (2, 64, 48, 8, 8, 1, (1, 1, 1, 1), 1),       # nearest-2x upsample folded into the gather
     (1, 544, 32, 10, 10, 1, (1, 1, 1, 1), 0),    # RDB growth conv
     (3, 320, 4, 8, 8, 1, (1, 1, 1, 1), 0),       # out conv
+    (3, 128, 200, 12, 12, 1, (1, 1, 1, 1), 0),   # (tap, Cin) K order, FAST path, K = 1152
+    (2, 192, 96, 16, 16, 2, (0, 1, 0, 1), 0),    # stride 2 + asymmetric pad, FAST path
 ])
 def test_igemm_conv3x3(hip, n, cin, cout, h, w, stride, pads, up2):
     x = h16(rnd(n, cin, h, w, seed=20))
@@ -188,9 +210,9 @@ def test_igemm_conv_rowvec(hip):
     assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
 
 
-@pytest.mark.parametrize("clips,T", [(1, 5), (2, 3), (1, 1)])
-def test_igemm_tconv(hip, clips, T):
-    c, h, w = 64, 6, 6
+@pytest.mark.parametrize("clips,T,c", [(1, 5, 64), (2, 3, 64), (1, 1, 64), (2, 4, 384)])
+def test_igemm_tconv(hip, clips, T, c):
+    h, w = 6, 6
     x = h16(rnd(clips * T, c, h, w, seed=27))
     wt = h16(rnd(c, c, 3, 1, 1, seed=28, scale=(3 * c) ** -0.5))
     b = rnd(c, seed=29)
