@@ -13,14 +13,17 @@
 //    (any permutation of the contraction index is legal as long as both operands agree), so P never
 //    moves between lanes.  V arrives already transposed ([head][d][key], written so by the V projection
 //    GEMM), so V^T fragments are two 8-byte LDS reads.
-//  * K and V^T tiles (64 keys) are staged global->registers->LDS; the next tile's global loads are issued
-//    before the current tile's MFMAs (issue-early / write-late).
+//  * K and V^T tiles (64 keys) are staged global->registers->LDS into TWO LDS buffers: while tile t feeds the MFMAs,
+//    tile t+1 is written into the other buffer and tile t+2's global loads are in flight; one barrier per tile.
 #include "common.h"
 
 namespace {
 
+// (amdgpu_waves_per_eu pins the register budget: 3 blocks per CU at D=64, 2 at D=128; it also makes the compiler keep
+//  the MFMA results in VGPRs, so the softmax reads them without v_accvgpr moves.)
 template <int D>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const MgldAttn p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 2, D == 64 ? 3 : 2)))
+void flash_attn_kernel(const MgldAttn p) {
   constexpr int KT = 64;             // keys per tile
   constexpr int KS = D + 8;          // K LDS row stride (halves): conflict-free ds_read_b128
   constexpr int VS = KT + 4;         // V^T LDS row stride (halves): 34 banks -> conflict-free ds_read_b64
@@ -28,8 +31,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const MgldAttn p) {
   constexpr int DT = D / 32;         // 32-row tiles of O^T
   constexpr int NKV = KT * D / 8 / 256;  // staging vectors per thread for K (and for V^T)
 
-  __shared__ __attribute__((aligned(16))) f16 sK[KT * KS];
-  __shared__ __attribute__((aligned(16))) f16 sV[D * VS];
+  constexpr int KBUF = KT * KS, VBUF = D * VS;   // halves per buffer
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  f16* const sKb = (f16*)smem_raw;               // [2][KBUF]
+  f16* const sVb = sKb + 2 * KBUF;               // [2][VBUF]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -60,33 +65,45 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const MgldAttn p) {
   float m_run = -1e30f, l_run = 0.f;
   const float sc = p.scale * 1.44269504088896340736f;  // fold log2(e): softmax via exp2
 
+  // Staging loads are branch-free: a full tile adds a wave-uniform offset to per-thread base pointers; the (single)
+  // ragged tile clamps its key indices into the valid range instead of predicating: K rows past Nkv repeat the last row
+  // (their scores are masked to -1e30 below), V^T columns past Nkv are zeroed.
   f16x8 rk[NKV], rv[NKV];
+  const f16* kptr[NKV];
+  const f16* vptr[NKV];
+  int krow[NKV], vkey[NKV];
+#pragma unroll
+  for (int i = 0; i < NKV; ++i) {
+    const int v = tid + i * 256;
+    krow[i] = v / (D / 8);
+    kptr[i] = Kp + (v - krow[i] * (D / 8)) * 8;
+    vkey[i] = (v & 7) * 8;
+    vptr[i] = Vp + (int64_t)(v >> 3) * p.vt_sd;
+  }
+  const int kv_last8 = ((Nkv + 7) & ~7) - 8;   // last 8-key group of a V^T row (rows are zero-padded to a multiple of 8)
   auto load_tile = [&](int kbase) {
+    if (kbase + KT <= Nkv) {
 #pragma unroll
-    for (int i = 0; i < NKV; ++i) {
-      const int v = tid + i * 256;
-      {  // K: 64 rows x D/8 vectors
-        const int row = v / (D / 8), cv = v - row * (D / 8);
-        const int key = kbase + row;
-        rk[i] = (key < Nkv) ? *(const f16x8*)(Kp + (int64_t)key * p.k_si + cv * 8) : zero8;
+      for (int i = 0; i < NKV; ++i) {
+        rk[i] = *(const f16x8*)(kptr[i] + (int64_t)(kbase + krow[i]) * p.k_si);
+        rv[i] = *(const f16x8*)(vptr[i] + kbase + vkey[i]);
       }
-      {  // V^T: D rows x 8 vectors of 8 keys
-        const int d = v >> 3, kv = v & 7;
-        const int key0 = kbase + kv * 8;
-        f16x8 t = zero8;
-        if (key0 < Nkv) {
-          t = *(const f16x8*)(Vp + (int64_t)d * p.vt_sd + key0);
-          if (key0 + 8 > Nkv) {
+    } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (key0 + j >= Nkv) t[j] = (f16)0.f;
-          }
-        }
+      for (int i = 0; i < NKV; ++i) {
+        rk[i] = *(const f16x8*)(kptr[i] + (int64_t)min(kbase + krow[i], Nkv - 1) * p.k_si);
+        const int key0 = kbase + vkey[i];
+        f16x8 t = *(const f16x8*)(vptr[i] + min(key0, kv_last8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (key0 + j >= Nkv) t[j] = (f16)0.f;   // the pad columns of a V^T row are not required to hold zeros
         rv[i] = t;
       }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    f16* const sK = sKb + buf * KBUF;
+    f16* const sV = sVb + buf * VBUF;
 #pragma unroll
     for (int i = 0; i < NKV; ++i) {
       const int v = tid + i * 256;
@@ -101,12 +118,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const MgldAttn p) {
 
   const int ntiles = (Nkv + KT - 1) / KT;
   load_tile(0);
-  store_tile();
+  store_tile(0);
+  if (ntiles > 1) load_tile(KT);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int kbase = t * KT;
-    if (t + 1 < ntiles) load_tile(kbase + KT);  // in flight under the MFMAs below
+    const int cur = t & 1;
+    if (t + 1 < ntiles) {
+      store_tile(cur ^ 1);                            // tile t+1 (registers) -> the buffer tile t-1 was read from
+      if (t + 2 < ntiles) load_tile(kbase + 2 * KT);  // in flight under this tile's MFMAs
+    }
+    const f16* const sK = sKb + cur * KBUF;
+    const f16* const sV = sVb + cur * VBUF;
 
     // ---- S^T = K Q^T for 2 key tiles of 32 ----
     f32x16 st[2];
@@ -177,11 +201,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const MgldAttn p) {
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
       }
     }
-    __syncthreads();  // everyone done reading this tile
-    if (t + 1 < ntiles) {
-      store_tile();
-      __syncthreads();
-    }
+    __syncthreads();  // everyone done reading buffer `cur`; tile t+1 visible in the other one
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ----
@@ -239,10 +259,16 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
                "attention: pointer alignment");
   MGLD_REQUIRE(p->vt_sd >= ((p->Nkv + 7) & ~7), "attention: vt rows must be padded to a multiple of 8 keys");
   dim3 grid(cdiv(p->Nq, 128), p->heads, p->batch);
+  constexpr int LDS64 = 2 * (64 * (64 + 8) + 64 * (64 + 4)) * 2, LDS128 = 2 * (64 * (128 + 8) + 128 * (64 + 4)) * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+    attr_done = true;
+  }
   if (p->head_dim == 64)
-    hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), LDS64, (hipStream_t)stream, *p);
   else
-    hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), LDS128, (hipStream_t)stream, *p);
   return mgld_check_launch("attention");
 }
 

@@ -74,7 +74,8 @@ def lib():
             raise RuntimeError(
                 f"{_LIB_PATH} is missing: the MGLD-VSR hot path has no CPU/eager fallback. "
                 "Build it with `python -m mgld_vsr_amd.build` (hipcc --offload-arch=gfx950).")
-        _lib = C.CDLL(_LIB_PATH)
+        # MGLD_HIP_LIB: load another build of the same library (kernel A/B tuning only)
+        _lib = C.CDLL(os.environ.get("MGLD_HIP_LIB") or _LIB_PATH)
         _lib.mgld_last_error.restype = C.c_char_p
         _lib.mgld_gn_chunks.restype = C.c_int
     return _lib
