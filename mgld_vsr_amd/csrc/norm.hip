@@ -6,19 +6,25 @@
 namespace {
 
 // ---- stage 1: per-(frame, chunk) per-GROUP partial sums ----------------------------------------------------
-// grid (chunks, frames), 256 threads.  Per-channel fp32 sums over the chunk's rows are combined per group in fp64 and
-// written as gsums[frame][chunk][group][2] (sum, sumsq; doubles).  The consumers (gn_apply / spade_apply) finish the
-// reduction over chunks in their prologue, so there is no separate "finalize" launch.
-__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x, int rows, int C, int ld,
-                                                         int rows_per_chunk, int groups, double* __restrict__ gsums) {
-  extern __shared__ float sred[];  // [max(rpi,1)][C][2]
+// grid (chunks, frames, channel windows), 256 threads.  A block reduces a window of Cb channels (whole groups, a multiple
+// of 8) over the chunk's rows: per-channel fp32 sums, combined per group in fp64 and written as
+// gsums[frame][chunk][group][2] (sum, sumsq; doubles).  The channel split keeps the GPU busy on the low-resolution, wide
+// tensors (8x8 / 16x16 latents with 1280-2560 channels).  The consumers (gn_apply / spade_apply) finish the reduction over
+// chunks in their prologue, so there is no separate "finalize" launch.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x, int rows, int Cfull, int ld,
+                                                         int rows_per_chunk, int groups, int Cb,
+                                                         double* __restrict__ gsums) {
+  extern __shared__ float sred[];  // [max(rpi,1)][C][2]   (C = channels of this block's window)
+  const int c_off = blockIdx.z * Cb;
+  const int C = min(Cb, Cfull - c_off);
+  const int cg = Cfull / groups;
   const int NV = C >> 3;
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, frame = blockIdx.y, chunks = gridDim.x;
   const int r0 = chunk * rows_per_chunk;
   const int r1 = min(rows, r0 + rows_per_chunk);
-  const f16* xf = x + (int64_t)frame * rows * ld;
-  double* gout = gsums + ((int64_t)(frame * chunks + chunk) * groups) * 2;
+  const f16* xf = x + (int64_t)frame * rows * ld + c_off;
+  double* gout = gsums + ((int64_t)(frame * chunks + chunk) * groups + c_off / cg) * 2;
 
   if (NV >= 256) {
     // wide rows: each thread owns vector columns tid, tid+256, ... ; one row at a time
@@ -67,8 +73,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
     }
   }
   __syncthreads();
-  const int cg = C / groups;
-  for (int g = tid; g < groups; g += 256) {
+  for (int g = tid; g < C / cg; g += 256) {
     double s = 0.0, q = 0.0;
     for (int i = 0; i < cg; ++i) { s += (double)sred[(g * cg + i) * 2]; q += (double)sred[(g * cg + i) * 2 + 1]; }
     gout[g * 2] = s; gout[g * 2 + 1] = q;
@@ -108,11 +113,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
                                                        int chunks, float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const f16* __restrict__ gb, int ldgb,
                                                        const f16* __restrict__ skip, int ldskip, f16* __restrict__ y, int ldy,
-                                                       int rows_per_frame, int C, int groups, int silu) {
+                                                       int rows_per_frame, int C, int groups, int silu, int Cb) {
   // grid (row chunks, frames).  A thread owns ONE 8-channel vector column for all its rows, so the per-channel scale /
   // shift (rstd*gamma, beta - mean*rstd*gamma) are computed once into registers and the row loop is load-fma-store.
   __shared__ float st[GN_MAX_GROUPS][2];
-  const int NV = C >> 3;
+  const int c_off = blockIdx.z * Cb;            // this block's channel window [c_off, c_off + Cb)
+  const int NV = min(Cb, C - c_off) >> 3;
   const int cg = C / groups;
   const int frame = blockIdx.y;
   gn_group_stats(gsums + (int64_t)frame * chunks * groups * 2, chunks, groups, rows_per_frame, cg, eps, st);
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   const int rr = NV >= 256 ? 0 : threadIdx.x / NV;
   if (rr >= rpi) return;
   for (int v = NV >= 256 ? threadIdx.x : threadIdx.x - rr * NV; v < NV; v += 256) {
-    const int c0 = v * 8;
+    const int c0 = c_off + v * 8;
     float sa[8], sb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -226,6 +232,20 @@ extern "C" int mgld_gn_chunks(int rows_per_frame) {
   return cdiv(rows_per_frame, rows_per_chunk_for(rows_per_frame));
 }
 
+// channel-window size: whole groups, a multiple of 8 channels, chosen so that about `want_blocks` blocks exist
+static int channel_window(int C, int groups, int64_t blocks_without_split, int want_blocks) {
+  const int cg = C / groups;
+  int unit = cg;
+  while (unit & 7) unit += cg;                     // lcm(cg, 8)
+  if (unit > C || C % unit) return C;
+  const int nmax = C / unit;
+  int64_t want = (want_blocks + blocks_without_split - 1) / blocks_without_split;
+  if (want < 1) want = 1;
+  if (want > nmax) want = nmax;
+  const int per = (int)((nmax + want - 1) / want);
+  return per * unit;
+}
+
 extern "C" int mgld_gn_stats(const void* x, int frames, int rows, int C, int ld, int groups, double* gsums,
                              void* stream) {
   MGLD_REQUIRE(x && gsums, "gn_stats: null pointer");
@@ -234,20 +254,22 @@ extern "C" int mgld_gn_stats(const void* x, int frames, int rows, int C, int ld,
   MGLD_REQUIRE(((uintptr_t)x & 15) == 0, "gn_stats: alignment");
   const int rpc = rows_per_chunk_for(rows);
   const int chunks = cdiv(rows, rpc);
-  const int NV = C >> 3;
+  const int Cb = channel_window(C, groups, (int64_t)chunks * frames, 512);
+  const int NV = Cb >> 3;
   const int rpi = NV >= 256 ? 1 : 256 / NV;
-  const size_t shm = (size_t)rpi * C * 2 * sizeof(float);
+  const size_t shm = (size_t)rpi * Cb * 2 * sizeof(float);
   MGLD_REQUIRE(shm <= 64 * 1024, "gn_stats: LDS budget");
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, frames), dim3(256), shm, (hipStream_t)stream, (const f16*)x, rows, C,
-                     ld, rpc, groups, gsums);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, frames, cdiv(C, Cb)), dim3(256), shm, (hipStream_t)stream,
+                     (const f16*)x, rows, C, ld, rpc, groups, Cb, gsums);
   return mgld_check_launch("gn_stats");
 }
 
-static dim3 apply_grid(int frames, int rows) {
+static dim3 apply_grid(int frames, int rows, int C, int groups, int* Cb) {
   int chunks = cdiv(rows, 32);
   const int cap = 4096 / (frames > 0 ? frames : 1);
   if (chunks > cap) chunks = cap > 0 ? cap : 1;
-  return dim3(chunks, frames);
+  *Cb = channel_window(C, groups, (int64_t)chunks * frames, 512);
+  return dim3(chunks, frames, cdiv(C, *Cb));
 }
 
 extern "C" int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta,
@@ -255,9 +277,10 @@ extern "C" int mgld_gn_apply(const void* x, int ldx, const double* gsums, float 
   MGLD_REQUIRE(x && gsums && gamma && beta && y, "gn_apply: null pointer");
   MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS,
                "gn_apply: alignment");
-  hipLaunchKernelGGL((gn_apply_kernel<false>), apply_grid(frames, rows), dim3(256), 0, (hipStream_t)stream,
-                     (const f16*)x, ldx, gsums, mgld_gn_chunks(rows), eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy,
-                     rows, C, groups, silu);
+  int Cb;
+  const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
+  hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, gsums,
+                     mgld_gn_chunks(rows), eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb);
   return mgld_check_launch("gn_apply");
 }
 
@@ -268,9 +291,11 @@ extern "C" int mgld_spade_apply(const void* h, int ldh, const double* gsums, flo
   MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0 &&
                    groups <= GN_MAX_GROUPS,
                "spade_apply: alignment");
-  hipLaunchKernelGGL((gn_apply_kernel<true>), apply_grid(frames, rows), dim3(256), 0, (hipStream_t)stream,
-                     (const f16*)h, ldh, gsums, mgld_gn_chunks(rows), eps, gamma, beta, (const f16*)gb, ldgb,
-                     (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0);
+  int Cb;
+  const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
+  hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)h, ldh, gsums,
+                     mgld_gn_chunks(rows), eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy,
+                     rows, C, groups, 0, Cb);
   return mgld_check_launch("spade_apply");
 }
 
