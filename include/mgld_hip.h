@@ -92,6 +92,10 @@ typedef struct MgldIGemm {
                              (64-channel block, tap, channel) instead of (tap, Cin): all taps of one channel block are
                              consumed back to back, so the shifted re-reads of the input hit L1/L2                  */
   int64_t strideA, strideW, strideC, strideR; /* element strides between batches            */
+  int32_t t_off;          /* TCONV3 on a frame-sharded clip: output frame f sits at position f + t_off of a clip of T
+                             frames whose rows start t_off frames BEFORE `A` (A points at the first output frame inside a
+                             halo-extended buffer); M = (#output frames)*HW.  0 = whole clips (M % (T*HW) == 0).       */
+  int32_t reserved0;
 } MgldIGemm;
 
 int mgld_igemm(const MgldIGemm* p, void* stream);

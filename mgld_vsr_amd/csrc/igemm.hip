@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
         fa_mask[j] = msk;
       } else {
         const int f = mm / p.HW;
-        const int t0 = f % p.T;
+        const int t0 = (f + p.t_off) % p.T;
         fa_ptr[j] = (const char*)(A + ((int64_t)mm - p.HW) * p.lda + clog * 8);   // dt = 0 reads frame t-1
         unsigned msk = 0;
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
       } else {  // TCONV3
         const int f = mm / p.HW;
         ra[j].base = mm;
-        ra[j].iy0 = f % p.T;
+        ra[j].iy0 = (f + p.t_off) % p.T;
       }
     }
 #pragma unroll
@@ -604,10 +604,18 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128) * batch;
   *splits = 1;
   *kchunk = (int)K;
+  {
+    static int force = -1;   // env MGLD_IGEMM_FORCE=<BM*1000+BN>: tile override for tuning runs (non-GEGLU, N > 64)
+    if (force < 0) { const char* e = getenv("MGLD_IGEMM_FORCE"); force = e ? atoi(e) : 0; }
+    if (force && p->act != MGLD_ACT_GEGLU && N > 64) { *cfg = force; return; }
+  }
   if (p->act == MGLD_ACT_GEGLU) { *cfg = (t128 >= 256 || M <= 64) ? 128128 : 64128; return; }
   if (N <= 32) { *cfg = 128032; return; }
   if (N <= 64) { *cfg = 128064; return; }
   if ((igemm_opt() & 4) && (int64_t)cdiv(M, 256) * cdiv(N, 128) * batch >= 256 && N >= 128) { *cfg = 256128; return; }
+  // N = 64 (mod 128), e.g. the 320-channel level: 128-wide tiles would idle a sixth of the MFMA work on padding, 64-wide
+  // tiles divide N exactly and fit three blocks per CU
+  if ((N & 127) == 64 && N <= 448 && (int64_t)cdiv(M, 128) * (N / 64) * batch >= 512) { *cfg = 128064; return; }
   if (t128 >= 384) { *cfg = 128128; return; }
   // too few 128x128 tiles for 256 CUs
   if (batch == 1 && K >= 1536 && g_ws != nullptr) {
@@ -659,7 +667,9 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
       MGLD_REQUIRE(p->stride == 1 || p->stride == 2, "igemm: stride must be 1 or 2");
       MGLD_REQUIRE(p->M % (p->Hout * p->Wout) == 0, "igemm: M must be frames*Hout*Wout");
     } else {
-      MGLD_REQUIRE(p->T > 0 && p->HW > 0 && p->M % (p->T * p->HW) == 0, "igemm: tconv geometry");
+      MGLD_REQUIRE(p->T > 0 && p->HW > 0 && p->t_off >= 0, "igemm: tconv geometry");
+      if (p->t_off == 0) MGLD_REQUIRE(p->M % (p->T * p->HW) == 0, "igemm: tconv M must be clips*T*HW");
+      else MGLD_REQUIRE(p->M % p->HW == 0 && p->M / p->HW + p->t_off <= p->T, "igemm: sharded tconv frames exceed the clip");
     }
   }
   if (p->tap_inner)

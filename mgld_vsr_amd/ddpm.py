@@ -315,7 +315,17 @@ class LatentDiffusionVSRTextWT(nn.Module):
             hip.tile_normalize(acc, cnt, eps)
         if st["guided"]:
             hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], st["z"], st["noise_stride"])
-            hip.guidance(st["z"], st["ff"], st["fb"], st["fo"], st["bo"], st["coef"], st["step_idx"], st["gscale"], x, st["work"])
+            sh = eng.shard
+            if sh is None:
+                hip.guidance(st["z"], st["ff"], st["fb"], st["fo"], st["bo"], st["coef"], st["step_idx"], st["gscale"], x,
+                             st["work"])
+            else:
+                # frame-sharded clip: the guidance chain couples neighbouring frames -> all-gather the (64 KiB/frame)
+                # latents, evaluate the tiny gradient on the whole clip on every rank, keep this rank's frames
+                zf = sh.all_gather(st["z"])
+                hip.guidance(zf, st["ff"], st["fb"], st["fo"], st["bo"], st["coef"], st["step_idx"], st["gscale"],
+                             st["x_full"], st["work"])
+                x.copy_(sh.local(st["x_full"]))
         else:
             hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], x, st["noise_stride"])
         hip.step_advance(st["step_idx"], -1)
@@ -352,11 +362,18 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 "ctx": self.model.diffusion_model.context_cache(eng, ctx), "guided": flows is not None,
                 "gscale": float(guidance_scale), "tiles": None,
             }
+            sh = eng.shard
+            if sh is not None:
+                assert tile is None and T_total == sh.F, "frame sharding: one clip per segment, local frames only"
+                use_graph = use_graph and sh.world == 1   # collectives sit between the launches of a step
             if flows is not None:
-                assert T_total == self.num_frames, "guidance expects one clip of num_frames frames"
+                T_clip = T_total if sh is None else sh.T
+                assert T_clip == self.num_frames, "guidance expects one clip of num_frames frames"
                 st["ff"], st["fb"], st["fo"], st["bo"] = self._flows_to_device(eng, flows, masks)
                 st["z"] = torch.empty_like(x)
-                st["work"] = torch.empty(hip.guidance_work_bytes(T_total, c, h, w), dtype=torch.uint8, device=dev)
+                st["work"] = torch.empty(hip.guidance_work_bytes(T_clip, c, h, w), dtype=torch.uint8, device=dev)
+                if sh is not None:
+                    st["x_full"] = torch.empty((T_clip, c, h, w), device=dev)
             # persistent (non-arena) conditioning buffers
             if tile is None:
                 la = torch.empty(T_total * h * w, 8, dtype=torch.float16, device=dev)

@@ -146,6 +146,7 @@ class Engine:
         self.arena = Arena(self.device, chunk_bytes)
         self._wcache = {}
         self.launches = 0
+        self.shard = None   # parallel.FrameShard when the frames of one segment are split over ranks
         # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
         self._splitk_ws = hip.ensure_workspace(workspace_bytes) if self.device.type == "cuda" else None
 
@@ -215,9 +216,25 @@ class Engine:
         """SpatialTemporalConv: out = a*(conv3d_t(x)+b) + (1-a)*x."""
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C)
-        hip.igemm(x.v, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
-                  tconv=(x.C, T, x.hw))
-        self.launches += 1
+        sh = self.shard
+        if sh is None:
+            hip.igemm(x.v, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
+                      tconv=(x.C, T, x.hw))
+            self.launches += 1
+            return out
+        # frame-sharded clip (parallel.FrameShard): this rank holds F consecutive frames.  The conv runs on a halo-extended
+        # copy [left neighbour's last frame | F frames | right neighbour's first frame]; zero frames at the clip's ends
+        # reproduce the Conv3d zero padding.
+        if x.n != sh.F:
+            raise RuntimeError(f"sharded temporal conv: {x.n} local frames, shard expects {sh.F} (one clip per segment)")
+        F, hw = x.n, x.hw
+        ext = self.arena.alloc(((F + 2) * hw, x.C), torch.float16)
+        mid = ext[hw:(F + 1) * hw]
+        hip.copy2d(x.v, mid)
+        sh.halo(x.v, hw, ext[:hw], ext[(F + 1) * hw:])
+        hip.igemm(mid, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
+                  tconv=(x.C, F + 2, hw), t_off=1)
+        self.launches += 2
         return out
 
     def gn_stats(self, x, eps, groups=None):

@@ -31,6 +31,7 @@ class MgldIGemm(C.Structure):
         ("alpha", C.c_float), ("beta", C.c_float),
         ("batch", C.c_int32), ("tap_inner", C.c_int32),
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
+        ("t_off", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -111,7 +112,7 @@ def _ld(t):
 
 def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None,
           act=ACT_NONE, alpha=1.0, beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0,
-          M=None, N=None, K=None, tap_inner=0):
+          M=None, N=None, K=None, tap_inner=0, t_off=0):
     """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h)."""
     _req_cuda(a, w, out)
     p = MgldIGemm()
@@ -133,6 +134,7 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
     p.alpha, p.beta = alpha, beta
     p.batch = batch
     p.tap_inner = tap_inner
+    p.t_off = t_off
     p.strideA, p.strideW, p.strideC, p.strideR = strideA, strideW, strideC, strideR
     if mode == MODE_CONV3X3:
         p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = conv

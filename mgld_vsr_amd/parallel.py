@@ -82,3 +82,121 @@ def gather_frames(local_frames, segment_ids, n_segments, device=None):
         for i, f in part:
             out[i] = f
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Intra-segment frame sharding (second scheme): the T frames of ONE segment are split over the ranks.
+# Frames are independent except at three coupling points, each served by one exchange over RCCL/xGMI:
+#   * SpatialTemporalConv (UNet mid block x2, VAE video decoder x13): +-1-frame halo  -> neighbour send/recv
+#   * TemporalAttention (UNet mid block): every frame attends to all T frames         -> all-gather of q|k|v rows
+#   * motion guidance (compute_temporal_condition_v4): chain over neighbouring frames -> all-gather of the latents
+# Zero padding at the two ends of the clip (Conv3d padding, diffusionmodules/util.py:298) is kept on the first / last rank.
+# ----------------------------------------------------------------------------------------------------------------------
+class DistComm:
+    """torch.distributed transport ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+
+    def all_gather(self, t, shard):
+        import torch.distributed as dist
+        t = t.contiguous()
+        out = torch.empty((shard.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        try:
+            dist.all_gather_into_tensor(out, t)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(out.chunk(shard.world, 0)), t)
+        return out
+
+    def exchange(self, x, rows_per_frame, recv_left, recv_right, shard):
+        """x: [F*rows_per_frame, C] local frames.  recv_left <- last frame of rank-1, recv_right <- first frame of rank+1
+        (zeros at the ends of the clip)."""
+        import torch.distributed as dist
+        ops, keep = [], []
+        if shard.rank > 0:
+            first = x[:rows_per_frame].contiguous()
+            keep.append(first)
+            ops += [dist.P2POp(dist.isend, first, shard.rank - 1), dist.P2POp(dist.irecv, recv_left, shard.rank - 1)]
+        else:
+            recv_left.zero_()
+        if shard.rank < shard.world - 1:
+            last = x[x.shape[0] - rows_per_frame:].contiguous()
+            keep.append(last)
+            ops += [dist.P2POp(dist.isend, last, shard.rank + 1), dist.P2POp(dist.irecv, recv_right, shard.rank + 1)]
+        else:
+            recv_right.zero_()
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+class RecordingComm:
+    """World-size-1 transport that keeps a copy of every tensor handed to it: the full-clip reference trace that
+    ReplayComm serves to a virtual rank (single-GPU validation of the sharded math, tests/test_nets_gpu.py)."""
+
+    def __init__(self):
+        self.trace = []
+
+    def all_gather(self, t, shard):
+        self.trace.append(("gather", t.detach().clone()))
+        return t
+
+    def exchange(self, x, rows_per_frame, recv_left, recv_right, shard):
+        self.trace.append(("halo", x.detach().clone()))
+        recv_left.zero_()
+        recv_right.zero_()
+
+
+class ReplayComm:
+    """Serves virtual rank `shard.rank` of `shard.world` from a RecordingComm trace of the full clip and checks, call by
+    call, that what this rank contributes equals its slice of the full-clip tensors (max relative deviation kept in
+    `worst`)."""
+
+    def __init__(self, trace):
+        self.trace, self.pos, self.worst = trace, 0, 0.0
+
+    def _next(self, kind, local, shard, unit):
+        k, full = self.trace[self.pos]
+        self.pos += 1
+        assert k == kind, f"communication sequence diverged: expected {k}, got {kind}"
+        mine = full[shard.rank * local.shape[0]:(shard.rank + 1) * local.shape[0]]
+        assert mine.shape == local.shape, (mine.shape, local.shape)
+        den = float(mine.float().norm()) + 1e-30
+        self.worst = max(self.worst, float((local.float() - mine.float()).norm()) / den)
+        return full
+
+    def all_gather(self, t, shard):
+        return self._next("gather", t, shard, None).clone()
+
+    def exchange(self, x, rows_per_frame, recv_left, recv_right, shard):
+        full = self._next("halo", x, shard, rows_per_frame)
+        lo = shard.rank * x.shape[0]
+        hi = lo + x.shape[0]
+        if lo > 0:
+            recv_left.copy_(full[lo - rows_per_frame:lo])
+        else:
+            recv_left.zero_()
+        if hi < full.shape[0]:
+            recv_right.copy_(full[hi:hi + rows_per_frame])
+        else:
+            recv_right.zero_()
+
+
+class FrameShard:
+    """Frames [f0, f1) of a T-frame segment live on this rank (T % world == 0)."""
+
+    def __init__(self, T, rank, world, comm=None):
+        if T % world:
+            raise ValueError(f"frame sharding needs the segment length ({T}) to be a multiple of the rank count ({world})")
+        self.T, self.rank, self.world = int(T), int(rank), int(world)
+        self.F = self.T // self.world
+        self.f0, self.f1 = self.rank * self.F, (self.rank + 1) * self.F
+        self.comm = comm if comm is not None else DistComm()
+
+    def local(self, t, dim=0):
+        """this rank's frames of a full-clip tensor"""
+        return t.narrow(dim, self.f0, self.F)
+
+    def all_gather(self, t):
+        """[F*k, ...] per rank -> [T*k, ...] in rank (= frame) order"""
+        return self.comm.all_gather(t, self)
+
+    def halo(self, x, rows_per_frame, recv_left, recv_right):
+        self.comm.exchange(x, rows_per_frame, recv_left, recv_right, self)

@@ -100,15 +100,43 @@ class VSRPipeline:
 
     @torch.no_grad()
     def run_segment(self, frames, flows=None, masks=None, guidance_scale=-10.0, noise=None, tile=None, use_graph=True,
-                    return_latents=False):
+                    return_latents=False, shard=None, gather=True):
         """frames: [T,3,H,W] in [-1,1] (the bicubically pre-upsampled LR segment, device or host);
         flows/masks as the reference passes them to sample(); noise: optional dict with 'posterior' [T,4,h,w],
-        'x_T' [T,4,h,w], 'steps' [S,T,4,h,w].  Returns HR frames [T,3,H,W] in [0,1] on the device."""
+        'x_T' [T,4,h,w], 'steps' [S,T,4,h,w].  Returns HR frames [T,3,H,W] in [0,1] on the device.
+
+        shard: parallel.FrameShard — the T frames of this segment are split over the ranks (every rank passes the SAME
+        full-clip arguments and works on frames [f0, f1)); temporal convolutions exchange one-frame halos, temporal
+        attention and the guidance chain all-gather.  With gather=True every rank returns the whole clip."""
         eng = self.engine()
         m, vq = self.model, self.vq_model
+        eng.shard = shard
+        try:
+            return self._run_segment(eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents,
+                                     shard, gather)
+        finally:
+            eng.shard = None
+
+    def _run_segment(self, eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents, shard, gather):
+        m, vq = self.model, self.vq_model
+        noise = dict(noise or {})
+        if shard is not None:
+            if tile is not None:
+                raise NotImplementedError("frame sharding and aggregation sampling are separate multi-GPU schemes")
+            if frames.shape[0] != shard.T:
+                raise ValueError(f"segment has {frames.shape[0]} frames, shard was built for {shard.T}")
+            # noise the caller did not inject is drawn for the WHOLE clip from a generator every rank seeds alike, then
+            # sliced: the result does not depend on how many ranks share the segment
+            lat_shape = (shard.T, 4, frames.shape[2] // 8, frames.shape[3] // 8)
+            g = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
+            for k, shp in (("posterior", lat_shape), ("x_T", lat_shape), ("steps", (self.ddpm_steps,) + lat_shape)):
+                if noise.get(k) is None:
+                    noise[k] = torch.randn(shp, generator=g)
+            frames = shard.local(frames)
+            for k, dim in (("posterior", 0), ("x_T", 0), ("steps", 1)):
+                noise[k] = shard.local(noise[k], dim)
         x = frames.to(eng.device, torch.float32).contiguous()
         T = x.shape[0]
-        noise = noise or {}
         post = m.encode_first_stage(x)
         pn = noise.get("posterior")
         init_latent = m.get_first_stage_encoding(post, pn if pn is not None else torch.randn(post.mean.shape))
@@ -130,4 +158,6 @@ class VSRPipeline:
         elif self.colorfix_type == "wavelet":
             x_samples = wavelet_reconstruction(x_samples, x)
         out = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)
+        if shard is not None and gather and shard.world > 1:
+            out, samples = shard.all_gather(out), shard.all_gather(samples)
         return (out, samples) if return_latents else out

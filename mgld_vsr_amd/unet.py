@@ -362,13 +362,25 @@ class TemporalAttention(nn.Module):
         n = eng.layernorm(x, eng.f32("g", self.norm.weight), eng.f32("b", self.norm.bias), self.norm.eps)
         wqkv = eng.weight("qkv", (a.to_q.weight, a.to_k.weight, a.to_v.weight), lambda q, k, v: torch.cat([q, k, v], 0))
         qkv = eng.linear(n.v, wqkv, None)
-        o = eng.empty(x.rows, C)
-        clips = x.n // T
-        per = T * x.hw
-        for c in range(clips):
-            s = slice(c * per, (c + 1) * per)
-            hip.temporal_attention(qkv[s, 0:C], qkv[s, C:2 * C], qkv[s, 2 * C:3 * C], o[s], T, x.hw, H, d, d ** -0.5)
+        sh = eng.shard
+        if sh is not None:
+            # frame-sharded clip: every frame attends to all T frames -> all-gather the q|k|v rows (T*hw x 3C, a few MB at
+            # the 8x8 level), run the (tiny) kernel on the whole clip, keep this rank's rows
+            if x.n != sh.F:
+                raise RuntimeError("sharded temporal attention expects one clip per segment")
+            full = sh.all_gather(qkv)
+            of = eng.empty(sh.T * x.hw, C)
+            hip.temporal_attention(full[:, 0:C], full[:, C:2 * C], full[:, 2 * C:3 * C], of, sh.T, x.hw, H, d, d ** -0.5)
             eng.launches += 1
+            o = of[sh.f0 * x.hw:sh.f1 * x.hw]
+        else:
+            o = eng.empty(x.rows, C)
+            clips = x.n // T
+            per = T * x.hw
+            for c in range(clips):
+                s = slice(c * per, (c + 1) * per)
+                hip.temporal_attention(qkv[s, 0:C], qkv[s, C:2 * C], qkv[s, 2 * C:3 * C], o[s], T, x.hw, H, d, d ** -0.5)
+                eng.launches += 1
         alpha = float(self.temporal_alpha.detach())
         wo = eng.weight("w", (a.to_out[0].weight,), lambda w: w)
         ov = None if out is None else out.v

@@ -212,6 +212,44 @@ def test_pipeline_small_end_to_end_vs_oracle(hip):
     assert record("e2e_small_frames", rel_l2(out, ref)) < 1e-2
 
 
+def test_pipeline_frame_sharded_matches_unsharded(hip):
+    """SURVEY §8(e), intra-segment frame sharding: the frames of ONE segment split over 2 / 4 ranks (halo exchange for the
+    temporal convs, all-gather for temporal attention and the guidance chain) reproduce the unsharded segment.  Only one
+    GPU is available to the tests, so every virtual rank runs in turn against a recorded full-clip trace
+    (parallel.ReplayComm), which also checks that what the rank WOULD send equals its slice of the full-clip tensors; the
+    torch.distributed transport itself is covered by the gloo tests in test_parallel_cpu.py."""
+    from mgld_vsr_amd import parallel
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    from oracle import flow as oflow
+    Tn, S, H, h = 4, 6, 128, 16
+    cfgs = model_configs(Tn, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                         struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                         vae_overrides=dict(ch=32, resolution=H), context_dim=64)
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=cfgs)
+    x = synth.synth_tensor("shard/x", (Tn, 3, H, H), 0.5).clamp(-1, 1)
+    noise = {"posterior": synth.synth_tensor("shard/np", (Tn, 4, h, h)), "x_T": synth.synth_tensor("shard/n0", (Tn, 4, h, h)),
+             "steps": torch.stack([synth.synth_tensor(f"shard/n{i}", (Tn, 4, h, h)) for i in range(S)])}
+    ff, fb = synth.smooth_flow("shard/ff", Tn - 1, h, h), synth.smooth_flow("shard/fb", Tn - 1, h, h)
+    fo, bo = oflow.forward_backward_consistency_check(fb, ff)
+    kw = dict(flows=(ff[None], fb[None]), masks=(fo[None, :, None], bo[None, :, None]), guidance_scale=-10.0, noise=noise,
+              return_latents=True, use_graph=False)
+    out0, lat0 = pipe.run_segment(x, **kw)
+    rec = parallel.RecordingComm()
+    out1, lat1 = pipe.run_segment(x, shard=parallel.FrameShard(Tn, 0, 1, rec), **kw)
+    assert len(rec.trace) > 0
+    assert rel_l2(out1, out0) < 1e-6 and rel_l2(lat1, lat0) < 1e-6       # same math through the halo-buffer code path
+    worst = 0.0
+    for world in (2, 4):
+        for r in range(world):
+            rp = parallel.ReplayComm(rec.trace)
+            sh = parallel.FrameShard(Tn, r, world, rp)
+            o, l = pipe.run_segment(x, shard=sh, gather=False, **kw)
+            assert rp.pos == len(rec.trace)                               # identical communication sequence
+            assert o.shape[0] == Tn // world
+            worst = max(worst, rp.worst, rel_l2(o, out0[sh.f0:sh.f1]), rel_l2(l, lat0[sh.f0:sh.f1]))
+    assert record("frame_sharded_vs_unsharded", worst) < 3e-3            # tile configs differ with M: fp16-level only
+
+
 def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
     """The shipped architecture at FULL width (935 M-param UNet, 52 M struct-cond encoder, full KL-VAE + video decoder),
     2 frames of 256x256 (latent 32x32), 4 guided DDPM steps, end to end vs the oracle (BASELINE configs[0] scaled to what

@@ -60,3 +60,83 @@ def test_segment_bounds_and_shards():
     got = sorted(sum((parallel.shard_segments(13, r, 4) for r in range(4)), []))
     assert got == list(range(13))
     assert parallel.shard_segments(3, 5, 8) == []
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# intra-segment frame sharding (parallel.FrameShard): halo exchange + all-gather over gloo, checked against the full clip
+# ----------------------------------------------------------------------------------------------------------------------
+def _tconv_full(x, w):
+    """3-tap conv over the frame axis with zero padding: x [T, hw, C], w [3, C, C]"""
+    T = x.shape[0]
+    z = torch.zeros_like(x[:1])
+    ext = torch.cat([z, x, z], 0)
+    return sum(ext[dt:dt + T] @ w[dt] for dt in range(3))
+
+
+def _shard_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mgld_vsr_amd import parallel
+    parallel.init(backend="gloo")
+    T, hw, C = 6, 5, 4
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(T, hw, C, generator=g)
+    w = torch.randn(3, C, C, generator=g)
+    sh = parallel.FrameShard(T, rank, world)
+    xl = sh.local(x).reshape(sh.F * hw, C).contiguous()
+    # temporal conv on a halo-extended copy, exactly as Engine.tconv3 lays it out
+    ext = torch.empty((sh.F + 2) * hw, C)
+    ext[hw:(sh.F + 1) * hw] = xl
+    sh.halo(xl, hw, ext[:hw], ext[(sh.F + 1) * hw:])
+    e3 = ext.reshape(sh.F + 2, hw, C)
+    yl = sum(e3[dt:dt + sh.F] @ w[dt] for dt in range(3))
+    y = sh.all_gather(yl.reshape(sh.F * hw, C)).reshape(T, hw, C)
+    ok_conv = torch.allclose(y, _tconv_full(x, w), atol=1e-5)
+    # all-gather keeps rank (= frame) order
+    ids = sh.all_gather(torch.arange(sh.f0, sh.f1, dtype=torch.float32).reshape(sh.F, 1))
+    ok_order = ids.flatten().tolist() == list(range(T))
+    ret[rank] = (bool(ok_conv), bool(ok_order), float(ext[:hw].abs().sum()), float(ext[(sh.F + 1) * hw:].abs().sum()))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_shard_halo_and_gather(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        ok_conv, ok_order, left, right = ret[r]
+        assert ok_conv and ok_order
+        assert (left == 0.0) == (r == 0)              # zero padding only at the two ends of the clip
+        assert (right == 0.0) == (r == world - 1)
+
+
+def test_frame_shard_replay_matches_recording():
+    """RecordingComm / ReplayComm (the single-GPU validation transport) reproduce what real ranks would exchange."""
+    sys.path.insert(0, ROOT)
+    from mgld_vsr_amd import parallel
+    T, hw, C = 4, 3, 2
+    x = torch.randn(T * hw, C)
+    rec = parallel.RecordingComm()
+    s1 = parallel.FrameShard(T, 0, 1, rec)
+    l, r = torch.ones(hw, C), torch.ones(hw, C)
+    s1.halo(x, hw, l, r)
+    assert float(l.abs().sum()) == 0 and float(r.abs().sum()) == 0
+    assert s1.all_gather(x) is x
+    for rank in range(2):
+        rp = parallel.ReplayComm(rec.trace)
+        s2 = parallel.FrameShard(T, rank, 2, rp)
+        xl = x[rank * 2 * hw:(rank + 1) * 2 * hw]
+        l, r = torch.empty(hw, C), torch.empty(hw, C)
+        s2.halo(xl, hw, l, r)
+        if rank == 0:
+            assert float(l.abs().sum()) == 0 and torch.equal(r, x[2 * hw:3 * hw])
+        else:
+            assert torch.equal(l, x[hw:2 * hw]) and float(r.abs().sum()) == 0
+        assert torch.equal(s2.all_gather(xl), x)
+        assert rp.worst == 0.0 and rp.pos == 2
+    with pytest.raises(ValueError):
+        parallel.FrameShard(5, 0, 2)
