@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--guidance", action="store_true", help="flow-guided latent warp on (configs[2]); default off (configs[1])")
     ap.add_argument("--tile", action="store_true", help="aggregation sampling over 64x64 latent tiles, overlap 32 (configs[3]: use with --size 1024)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (PMC profiling runs)")
+    ap.add_argument("--frame-shard", action="store_true",
+                    help="N>1: split the frames of ONE segment over the ranks (halo exchange / all-gather over RCCL, strong "
+                         "scaling of a single segment) instead of one segment per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
@@ -207,34 +210,44 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local)
     pipe = build_pipeline(args)
-    frames, noise, flows, masks = make_inputs(pipe, args, rank)
-
     from mgld_vsr_amd import parallel
-    # every rank owns its own segment (weak scaling): the reference's `seq_idx % n_gpus == select_idx` sharding
-    assert parallel.shard_segments(world, rank, world) == [rank]
+    shard = None
+    if args.frame_shard and world > 1:
+        # the frames of ONE segment over all ranks (second scheme): every rank builds the SAME clip
+        frames, noise, flows, masks = make_inputs(pipe, args, 0)
+        shard = parallel.FrameShard(args.frames, rank, world)
+    else:
+        frames, noise, flows, masks = make_inputs(pipe, args, rank)
+        # every rank owns its own segment (weak scaling): the reference's `seq_idx % n_gpus == select_idx` sharding
+        assert parallel.shard_segments(world, rank, world) == [rank]
+    kw = dict(flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH)
+    if shard is not None:
+        kw.update(shard=shard, gather=True)
 
     for _ in range(args.warmup):
-        pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH)
+        pipe.run_segment(frames, **kw)
     parallel.barrier()                       # barrier + torch.cuda.synchronize() on both sides of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH)
+        out = pipe.run_segment(frames, **kw)
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0)
     ok = bool(torch.isfinite(out).all())
     ms_per_step = 1e3 * dt / args.steps
-    fps = world * args.frames * args.steps / dt
+    segs = 1 if shard is not None else world
+    fps = segs * args.frames * args.steps / dt
     res = {
         "metric": "HR frames/sec at 512^2, 50 DDPM steps", "value": round(fps, 4), "unit": "HR frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "scaling": "strong" if shard is not None else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{args.frames}-frame {args.size}x{args.size} sequence (latent {args.size // 8}x{args.size // 8}x4), "
                                f"{args.ddpm_steps} DDPM steps, random-init SD-2.1 UNet + struct-cond encoder + KL-VAE encode x2 "
                                f"+ temporal video decoder + AdaIN, flow-guided warp {'on' if args.guidance else 'off'}{', aggregation sampling 64/32' if args.tile else ''}; "
-                               "one segment per GPU",
-                   "frames_per_segment": args.frames, "parallelism": f"segment-parallel x{world}", "finite": ok,
+                               + ("one segment, frames sharded over the GPUs" if shard is not None else "one segment per GPU"),
+                   "frames_per_segment": args.frames,
+                   "parallelism": f"frame-sharded x{world}" if shard is not None else f"segment-parallel x{world}", "finite": ok,
                    "reduced_width": bool(args.small)},
-        "sustained_tflops": round(world * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
+        "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
                                                           GFLOP_DEC_PER_FRAME) / 1e3 / (dt / args.steps), 1),
     }
     if rank == 0:

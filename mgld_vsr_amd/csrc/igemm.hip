@@ -617,7 +617,9 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   // tiles divide N exactly and fit three blocks per CU
   if ((N & 127) == 64 && N <= 448 && (int64_t)cdiv(M, 128) * (N / 64) * batch >= 512) { *cfg = 128064; return; }
   if (t128 >= 384) { *cfg = 128128; return; }
-  // too few 128x128 tiles for 256 CUs
+  // too few 128x128 tiles for 256 CUs.  Between 1 and 1.5 tiles per CU (e.g. M = 8192, N = 640) half-size tiles balance
+  // the CUs exactly as well as a 2-way K split (3 rounds of half the work) and need no reduce pass.
+  if (t128 >= 256) { *cfg = 64128; return; }
   if (batch == 1 && K >= 1536 && g_ws != nullptr) {
     static int target = -1;   // blocks to aim for (env MGLD_SPLITK_TARGET, tuning)
     if (target < 0) { const char* e = getenv("MGLD_SPLITK_TARGET"); target = e ? atoi(e) : 448; }

@@ -33,7 +33,8 @@ def h16(t):
 # igemm
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (100, 72, 40), (4096, 1280, 320), (512, 1280, 1280),
-                                   (77, 640, 1024), (33, 4, 320), (300, 32, 544), (64, 64, 8)])
+                                   (77, 640, 1024), (33, 4, 320), (300, 32, 544), (64, 64, 8), (8192, 640, 2560),
+                                   (16384, 320, 640)])
 def test_igemm_linear(hip, M, N, K):
     a, w, b = h16(rnd(M, K, seed=1)), h16(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
     ref = a.float() @ w.float().t() + b
@@ -44,7 +45,7 @@ def test_igemm_linear(hip, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 1280, 11520), (2048, 640, 5760), (300, 200, 2048), (64, 1280, 23040),
-                                   (8192, 640, 2560), (2048, 1280, 5120)])
+                                   (2048, 1280, 5120), (1000, 384, 4096)])
 def test_igemm_splitk(hip, M, N, K):
     """few output tiles + deep K -> split along K into fp32 slabs + reduce/epilogue kernel"""
     ws = hip._test_ws   # session-lifetime scratch registered by the `hip` fixture
@@ -70,7 +71,7 @@ def test_igemm_splitk(hip, M, N, K):
 def test_igemm_splitk_repeatable(hip):
     """the K slices are summed in a fixed order: back-to-back launches of the same problem (no host sync in between)
     give bit-identical results"""
-    M, N, K = 8192, 640, 2560
+    M, N, K = 2048, 1280, 5120
     a, w = h16(rnd(M, K, seed=5)).to(DEV), h16(rnd(N, K, seed=6, scale=K ** -0.5)).to(DEV)
     p = hip.MgldIGemm()
     p.M, p.N, p.K, p.batch = M, N, K, 1
