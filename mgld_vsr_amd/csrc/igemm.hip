@@ -538,6 +538,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MgldIGemm p, c
   }
 }
 
+int num_cus() {
+  static int v = 0;
+  if (!v) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n <= 0)
+      n = 256;
+    v = n;
+  }
+  return v;
+}
+
 float* g_ws = nullptr;     // split-K workspace (set by mgld_set_workspace; single-stream use)
 size_t g_ws_bytes = 0;
 
@@ -620,10 +632,20 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   // too few 128x128 tiles for 256 CUs.  Between 1 and 1.5 tiles per CU (e.g. M = 8192, N = 640) half-size tiles balance
   // the CUs exactly as well as a 2-way K split (3 rounds of half the work) and need no reduce pass.
   if (t128 >= 256) { *cfg = 64128; return; }
-  if (batch == 1 && K >= 1536 && g_ws != nullptr) {
-    static int target = -1;   // blocks to aim for (env MGLD_SPLITK_TARGET, tuning)
-    if (target < 0) { const char* e = getenv("MGLD_SPLITK_TARGET"); target = e ? atoi(e) : 448; }
-    int s = (int)((target + t128 - 1) / t128);
+  // Fewer 128x128 tiles than CUs: pick (tile, K split) by a small cost model calibrated on MI355X (us):
+  //   throughput term  rounds over 256 CUs x tile area x k-steps per block x 0.7 us (0.9 us when a CU holds a single block),
+  //   latency term     k-steps per block x 0.55 us (one block cannot go faster however small its tile),
+  //   split-K          + launch of the reduce pass + (s+1) fp32 passes over the M x N output at ~3.5 TB/s.
+  // shallow K (<= 48 k-steps): half / quarter tiles already give every CU a block and finish before a split + reduce would
+  if (K <= 48 * BK) {
+    const int64_t t64 = (int64_t)cdiv(M, 64) * cdiv(N, 64) * batch, t64x128s = (int64_t)cdiv(M, 64) * cdiv(N, 128) * batch;
+    if (t64 >= 2 * num_cus()) { *cfg = 64064; return; }
+    if (t64x128s >= num_cus()) { *cfg = 64128; return; }
+  }
+  static int use_model = -1;   // env MGLD_IGEMM_MODEL=1 (tuning): pick (tile, split) by the cost model below
+  if (use_model < 0) { const char* e = getenv("MGLD_IGEMM_MODEL"); use_model = e ? atoi(e) : 0; }
+  if (!use_model && batch == 1 && K >= 1536 && g_ws != nullptr) {
+    int s = (int)((448 + t128 - 1) / t128);
     const int smax = (int)(K / 512);
     if (s > smax) s = smax;
     if (s > 16) s = 16;
@@ -633,6 +655,40 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
       s = (int)((K + kc - 1) / kc);
       if (s >= 2) { *cfg = 128128; *splits = s; *kchunk = kc; return; }
     }
+  } else if (batch == 1 && K >= 1536 && g_ws != nullptr) {
+    const double nk = (double)cdiv(K, BK);
+    const int ncu = num_cus();
+    auto model = [&](int bm, int bn, double pen, int s) {
+      const double blocks = (double)cdiv(M, bm) * cdiv(N, bn) * s;
+      const double area = (bm * bn) / (128.0 * 128.0);
+      const double nkb = (double)cdiv((int64_t)nk, s);
+      const double tau = blocks >= 2.0 * ncu ? 0.7 : 0.9;
+      const double rounds = (double)cdiv((int64_t)blocks, ncu);
+      double t = rounds * area * pen * nkb * tau;
+      if (t < nkb * 0.55) t = nkb * 0.55;
+      t += 4.0;
+      if (s > 1) t += 4.0 + (s + 1) * (double)M * N * 4.0 / 3.5e6;
+      return t;
+    };
+    double best = model(64, 64, 1.25, 1);
+    int best_cfg = 64064, best_s = 1;
+    const double c1 = model(64, 128, 1.1, 1);
+    if (c1 <= best) { best = c1; best_cfg = 64128; }
+    int smax = (int)(K / 512);
+    if (smax > 16) smax = 16;
+    for (int s = 1; s <= smax; ++s) {
+      if (s > 1 && (size_t)s * M * N * sizeof(float) > g_ws_bytes) break;
+      const double c = model(128, 128, 1.0, s);
+      if (c < best) { best = c; best_cfg = 128128; best_s = s; }
+    }
+    if (best_s >= 2) {
+      int kc = (int)((K + best_s - 1) / best_s);
+      kc = (kc + BK - 1) / BK * BK;
+      const int s = (int)((K + kc - 1) / kc);
+      if (s >= 2) { *cfg = 128128; *splits = s; *kchunk = kc; return; }
+    }
+    *cfg = best_cfg;
+    return;
   }
   const int64_t t64x128 = (int64_t)cdiv(M, 64) * cdiv(N, 128) * batch;
   *cfg = (t64x128 >= 384) ? 64128 : 64064;

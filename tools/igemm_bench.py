@@ -26,6 +26,12 @@ SHAPES = [
     ("conv16 1280->1280", 1, 2048, 1280, 11520, 1280, 16, 0, 300),
     ("lin16 1280->1280", 0, 2048, 1280, 1280, 0, 0, 0, 1050),
     ("conv8 1280->1280", 1, 512, 1280, 11520, 1280, 8, 0, 550),
+    ("lin16 5120->1280", 0, 2048, 1280, 5120, 0, 0, 0, 250),
+    ("lin16 2560->1280", 0, 2048, 1280, 2560, 0, 0, 0, 100),
+    ("conv8 512->512", 1, 512, 512, 4608, 512, 8, 0, 400),
+    ("conv32 256->256", 1, 8192, 256, 2304, 256, 32, 0, 300),
+    ("conv64 256->128", 1, 32768, 128, 2304, 256, 64, 0, 250),
+    ("conv16 2560->1280", 1, 2048, 1280, 23040, 2560, 16, 0, 100),
     ("vae conv256 256->256", 1, 524288, 256, 2304, 256, 256, 0, 13),
     ("vae conv512 128->128", 1, 2097152, 128, 1152, 128, 512, 0, 13),
 ]
