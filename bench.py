@@ -89,6 +89,20 @@ def make_inputs(pipe, args, rank):
     return frames, noise, flows, masks
 
 
+def igemm_algo_bytes(p):
+    """algorithmic HBM bytes of one igemm launch: input activations once (not once per tap), weights, residual, output"""
+    b = max(1, p.batch)
+    if p.mode == 1:      # CONV3X3: frames * Hin * Win * Cin input elements
+        a_elems = (p.M // max(1, p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin
+    elif p.mode == 2:    # TCONV3
+        a_elems = p.M * p.Cin
+    else:
+        a_elems = p.M * p.K
+    n_out = p.N // 2 if p.act == 4 else p.N
+    out_b = 4 if p.out_f32 else 2
+    return b * (2.0 * a_elems + 2.0 * p.N * p.K + out_b * p.M * n_out + (2.0 * p.M * n_out if p.R else 0.0))
+
+
 def roofline(pipe, args, frames, noise, flows, masks):
     """Dominant kernel = the 128x128-tile MFMA implicit GEMM.  Collect every igemm problem of one full pass, then time
     each distinct problem of that tile config in isolation with hipEvents (10 back-to-back launches on the launch
@@ -102,7 +116,7 @@ def roofline(pipe, args, frames, noise, flows, masks):
     for p in log:
         cfg = hip.igemm_config(p)
         key = (cfg, p.mode, p.M, p.N, p.K, p.Cin, p.Hin, p.Win, p.stride, p.up2, p.act, max(1, p.batch), p.lda, p.ldc)
-        g = groups.setdefault(key, {"p": p, "count": 0, "flops": hip.igemm_flops(p), "cfg": cfg})
+        g = groups.setdefault(key, {"p": p, "count": 0, "flops": hip.igemm_flops(p), "cfg": cfg, "bytes": igemm_algo_bytes(p)})
         g["count"] += 1
     tot = {}
     e0, e1 = hip.Event(), hip.Event()
@@ -115,7 +129,8 @@ def roofline(pipe, args, frames, noise, flows, masks):
         e1.record()
         e1.sync()
         g["ms"] = e0.elapsed_ms(e1) / 10.0
-        t = tot.setdefault(g["cfg"], {"flops": 0.0, "ms": 0.0, "launches": 0})
+        t = tot.setdefault(g["cfg"], {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
+        t["bytes"] += g["bytes"] * g["count"]
         t["flops"] += g["flops"] * g["count"]
         t["ms"] += g["ms"] * g["count"]
         t["launches"] += g["count"]
@@ -147,6 +162,7 @@ def roofline(pipe, args, frames, noise, flows, masks):
     return {
         "bound": "mfma", "kernel": f"igemm_kernel<{dom_tile // 1000},{dom_tile % 1000}>" + (f" splitK x{dom_cfg // 1000000}" if dom_cfg >= 1000000 else ""), "achieved": round(achieved, 2),
         "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
+        "algorithmic_bytes": round(d["bytes"] / d["launches"]),   # per launch: every operand element moved once
         "launches_per_segment": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
         "kernel_ms_per_segment": round(d["ms"], 2),
         "all_igemm": {"tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "ms_per_segment": round(all_ms, 2),
