@@ -642,9 +642,8 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
     if (t64 >= 2 * num_cus()) { *cfg = 64064; return; }
     if (t64x128s >= num_cus()) { *cfg = 64128; return; }
   }
-  static int use_model = -1;   // env MGLD_IGEMM_MODEL=1 (tuning): pick (tile, split) by the cost model below
-  if (use_model < 0) { const char* e = getenv("MGLD_IGEMM_MODEL"); use_model = e ? atoi(e) : 0; }
-  if (!use_model && batch == 1 && K >= 1536 && g_ws != nullptr) {
+  // deep K, fewer 128x128 tiles than resident blocks: split K over grid.z (about 448 blocks in all), fp32 slabs + reduce pass
+  if (batch == 1 && K >= 1536 && g_ws != nullptr) {
     int s = (int)((448 + t128 - 1) / t128);
     const int smax = (int)(K / 512);
     if (s > smax) s = smax;
@@ -655,40 +654,6 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
       s = (int)((K + kc - 1) / kc);
       if (s >= 2) { *cfg = 128128; *splits = s; *kchunk = kc; return; }
     }
-  } else if (batch == 1 && K >= 1536 && g_ws != nullptr) {
-    const double nk = (double)cdiv(K, BK);
-    const int ncu = num_cus();
-    auto model = [&](int bm, int bn, double pen, int s) {
-      const double blocks = (double)cdiv(M, bm) * cdiv(N, bn) * s;
-      const double area = (bm * bn) / (128.0 * 128.0);
-      const double nkb = (double)cdiv((int64_t)nk, s);
-      const double tau = blocks >= 2.0 * ncu ? 0.7 : 0.9;
-      const double rounds = (double)cdiv((int64_t)blocks, ncu);
-      double t = rounds * area * pen * nkb * tau;
-      if (t < nkb * 0.55) t = nkb * 0.55;
-      t += 4.0;
-      if (s > 1) t += 4.0 + (s + 1) * (double)M * N * 4.0 / 3.5e6;
-      return t;
-    };
-    double best = model(64, 64, 1.25, 1);
-    int best_cfg = 64064, best_s = 1;
-    const double c1 = model(64, 128, 1.1, 1);
-    if (c1 <= best) { best = c1; best_cfg = 64128; }
-    int smax = (int)(K / 512);
-    if (smax > 16) smax = 16;
-    for (int s = 1; s <= smax; ++s) {
-      if (s > 1 && (size_t)s * M * N * sizeof(float) > g_ws_bytes) break;
-      const double c = model(128, 128, 1.0, s);
-      if (c < best) { best = c; best_cfg = 128128; best_s = s; }
-    }
-    if (best_s >= 2) {
-      int kc = (int)((K + best_s - 1) / best_s);
-      kc = (kc + BK - 1) / BK * BK;
-      const int s = (int)((K + kc - 1) / kc);
-      if (s >= 2) { *cfg = 128128; *splits = s; *kchunk = kc; return; }
-    }
-    *cfg = best_cfg;
-    return;
   }
   const int64_t t64x128 = (int64_t)cdiv(M, 64) * cdiv(N, 128) * batch;
   *cfg = (t64x128 >= 384) ? 64128 : 64064;
