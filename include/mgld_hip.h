@@ -221,6 +221,18 @@ int mgld_tile_accumulate(const float* tile, const float* wgt, float* acc, float*
 /* out = acc / cnt */
 int mgld_tile_normalize(const float* acc, const float* cnt, float* out, int64_t numel, void* stream);
 
+
+/* ---- K11: pre/post-processing on the device (oldcanvas_tile.py:349-357,384-397,523-543) -----------
+ * bicubic resize with torch.nn.functional.interpolate(mode="bicubic", align_corners=False) semantics (A = -0.75, border
+ * taps clamped, no antialias), fp32 planes [planes, h, w] -> [planes, oh, ow], result clamped to [lo, hi]
+ * (pass -inf/+inf for none): the x4 pre-upsampling of the LR frames and the /4 downscale fed to the flow network. */
+int mgld_resize_bicubic(const float* x, float* y, int planes, int h, int w, int oh, int ow, float lo, float hi, void* stream);
+/* F.pad(x, (0, ow-w, 0, oh-h), mode="reflect"): bottom / right reflect padding to the next multiple of 32 */
+int mgld_reflect_pad(const float* x, float* y, int planes, int h, int w, int oh, int ow, void* stream);
+/* [n,c,H,W] fp32 in [0,1] -> uint8 [n,h,w,c] of the top-left h x w window: (x*255).astype(uint8), i.e. truncation, as the
+ * reference writes its PNGs (oldcanvas_tile.py:532-543) */
+int mgld_to_uint8_hwc(const float* x, void* y, int n, int c, int H, int W, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -717,6 +717,98 @@ extern "C" int mgld_wavelet_reconstruction(const float* content, const float* st
   return mgld_check_launch("wavelet_reconstruction");
 }
 
+// ---- K11: host pre/post-processing moved to the device (oldcanvas_tile.py:349-357, 384-397, 523-543) ---------------
+namespace {
+
+// torch upsample_bicubic2d (align_corners=False, A=-0.75, no antialias): cubic-convolution weights of tap offsets -1..2
+__device__ __forceinline__ void cubic_w(float t, float* w) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x3 = 2.f - t, u = 1.f - t;
+  w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+  w[2] = ((A + 2.f) * u - (A + 3.f)) * u * u + 1.f;
+  w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int h,
+                                                      int w, int oh, int ow, float sy, float sx, float lo, float hi) {
+  const int64_t total = (int64_t)planes * oh * ow;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % ow);
+    const int oy = (int)((i / ow) % oh);
+    const int pl = (int)(i / ((int64_t)ow * oh));
+    const float fy = sy * (oy + 0.5f) - 0.5f, fx = sx * (ox + 0.5f) - 0.5f;
+    const float yf = floorf(fy), xf = floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - yf, wy);
+    cubic_w(fx - xf, wx);
+    const int iy = (int)yf, ix = (int)xf;
+    const float* p = x + (int64_t)pl * h * w;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int yy = min(max(iy - 1 + j, 0), h - 1);
+      const float* row = p + (int64_t)yy * w;
+      const float r = row[min(max(ix - 1, 0), w - 1)] * wx[0] + row[min(max(ix, 0), w - 1)] * wx[1] +
+                      row[min(max(ix + 1, 0), w - 1)] * wx[2] + row[min(max(ix + 2, 0), w - 1)] * wx[3];
+      acc += r * wy[j];
+    }
+    y[i] = fminf(fmaxf(acc, lo), hi);
+  }
+}
+
+// F.pad(mode="reflect") on the bottom / right edges (no edge repeat): index h+k reads h-2-k
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int h,
+                                                          int w, int oh, int ow) {
+  const int64_t total = (int64_t)planes * oh * ow;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const int pl = (int)(i / ((int64_t)ow * oh));
+    if (ox >= w) ox = 2 * (w - 1) - ox;
+    if (oy >= h) oy = 2 * (h - 1) - oy;
+    y[i] = x[((int64_t)pl * h + oy) * w + ox];
+  }
+}
+
+// [n,3,H,W] in [0,1] -> uint8 [n,h,w,3] (top-left crop); `(x * 255).astype(np.uint8)` of the reference = truncation
+__global__ __launch_bounds__(256) void to_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int n, int c,
+                                                    int H, int W, int h, int w) {
+  const int64_t total = (int64_t)n * h * w * c;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const int xx = (int)((i / c) % w);
+    const int yy = (int)((i / ((int64_t)c * w)) % h);
+    const int f = (int)(i / ((int64_t)c * w * h));
+    const float v = x[(((int64_t)f * c + ch) * H + yy) * W + xx] * 255.f;
+    y[i] = (unsigned char)(int)fminf(fmaxf(v, 0.f), 255.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int mgld_resize_bicubic(const float* x, float* y, int planes, int h, int w, int oh, int ow, float lo, float hi,
+                                   void* stream) {
+  MGLD_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "resize_bicubic: bad args");
+  hipLaunchKernelGGL(bicubic_kernel, dim3(egrid((int64_t)planes * oh * ow)), dim3(256), 0, S_(stream), x, y, planes, h, w, oh,
+                     ow, (float)h / (float)oh, (float)w / (float)ow, lo, hi);
+  return mgld_check_launch("resize_bicubic");
+}
+
+extern "C" int mgld_reflect_pad(const float* x, float* y, int planes, int h, int w, int oh, int ow, void* stream) {
+  MGLD_REQUIRE(x && y && planes > 0 && h > 1 && w > 1, "reflect_pad: bad args");
+  MGLD_REQUIRE(oh >= h && ow >= w && oh - h < h && ow - w < w, "reflect_pad: padding must be smaller than the image");
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(egrid((int64_t)planes * oh * ow)), dim3(256), 0, S_(stream), x, y, planes, h, w,
+                     oh, ow);
+  return mgld_check_launch("reflect_pad");
+}
+
+extern "C" int mgld_to_uint8_hwc(const float* x, void* y, int n, int c, int H, int W, int h, int w, void* stream) {
+  MGLD_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && h <= H && w <= W, "to_uint8_hwc: bad args");
+  hipLaunchKernelGGL(to_u8_kernel, dim3(egrid((int64_t)n * c * h * w)), dim3(256), 0, S_(stream), x, (unsigned char*)y, n, c,
+                     H, W, h, w);
+  return mgld_check_launch("to_uint8_hwc");
+}
+
 extern "C" int mgld_crop(const float* src, float* dst, int n, int c, int H, int W, int y0, int x0, int th, int tw, void* stream) {
   MGLD_REQUIRE(src && dst && n > 0 && c > 0, "crop: bad args");
   MGLD_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + th <= H && x0 + tw <= W && th > 0 && tw > 0, "crop: window out of range");

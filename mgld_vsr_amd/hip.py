@@ -60,6 +60,7 @@ EXPORTS = [
     "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
     "mgld_adain", "mgld_wavelet_reconstruction",
     "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize",
+    "mgld_resize_bicubic", "mgld_reflect_pad", "mgld_to_uint8_hwc",
 ]
 
 
@@ -427,3 +428,38 @@ def device_info(device=0):
     out = (C.c_int64 * 4)()
     _chk(lib().mgld_device_info(device, out), "device_info")
     return {"cus": out[0], "lds_per_cu": out[1], "clock_khz": out[2], "gfx": out[3]}
+
+
+# ---- K11: pre/post-processing on the device ------------------------------------------------------------------------
+def resize_bicubic(x, size, clamp=None):
+    """x [n,c,h,w] fp32 -> [n,c,oh,ow]; F.interpolate(mode="bicubic", align_corners=False) semantics (+ optional clamp)."""
+    _req_cuda(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    y = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+    lo, hi = (-float("inf"), float("inf")) if clamp is None else clamp
+    _chk(lib().mgld_resize_bicubic(_p(x), _p(y), n * c, h, w, oh, ow, C.c_float(lo), C.c_float(hi), stream_ptr()),
+         "resize_bicubic")
+    return y
+
+
+def reflect_pad(x, oh, ow):
+    """F.pad(x, (0, ow-w, 0, oh-h), mode="reflect") for x [n,c,h,w] fp32"""
+    _req_cuda(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+    _chk(lib().mgld_reflect_pad(_p(x), _p(y), n * c, h, w, oh, ow, stream_ptr()), "reflect_pad")
+    return y
+
+
+def to_uint8_hwc(x, h=None, w=None):
+    """x [n,c,H,W] fp32 in [0,1] -> uint8 [n,h,w,c] (top-left crop)"""
+    _req_cuda(x)
+    x = x.contiguous()
+    n, c, H, W = x.shape
+    h, w = h or H, w or W
+    y = torch.empty(n, h, w, c, dtype=torch.uint8, device=x.device)
+    _chk(lib().mgld_to_uint8_hwc(_p(x), _p(y), n, c, H, W, h, w, stream_ptr()), "to_uint8_hwc")
+    return y

@@ -101,19 +101,12 @@ def main():
             continue
         while len(paths) % opt.n_frames:             # repeat-last padding (:345-346)
             paths.append(paths[-1])
-        frames = []
-        for pth in paths:
-            im = read_image(pth)
-            size_min = min(im.shape[-2:])
-            up = max(512.0 / size_min, opt.upscale)  # (:349-357)
-            frames.append(F.interpolate(im, size=(int(im.shape[-2] * up), int(im.shape[-1] * up)), mode="bicubic"))
+        from mgld_vsr_amd import preproc
+        lr = [read_image(pth) for pth in paths]      # host: PNG decode only; everything else runs on the device
         os.makedirs(os.path.join(opt.outdir, seq), exist_ok=True)
-        for s0 in range(0, len(frames), opt.n_frames):
-            seg = torch.cat(frames[s0:s0 + opt.n_frames], 0)
-            ori_h, ori_w = seg.shape[-2:]
-            ph = 0 if ori_h % 32 == 0 else (ori_h // 32 + 1) * 32 - ori_h      # reflect-pad to /32 (:384-390)
-            pw = 0 if ori_w % 32 == 0 else (ori_w // 32 + 1) * 32 - ori_w
-            seg = F.pad(seg, (0, pw, 0, ph), mode="reflect").clamp(-1.0, 1.0)
+        for s0 in range(0, len(lr), opt.n_frames):
+            up = preproc.upsample_lr(torch.cat(lr[s0:s0 + opt.n_frames], 0), opt.upscale)   # (:349-357), clamped (:376)
+            seg, ori_h, ori_w = preproc.pad_to_32(up)                                         # reflect pad (:381-390)
             flows = masks = None
             if opt.flows_path:
                 fpath = os.path.join(opt.flows_path, seq, f"{s0 // opt.n_frames:04d}_flows.npy")
@@ -131,15 +124,17 @@ def main():
             h8, w8 = seg.shape[-2] // 8, seg.shape[-1] // 8
             tile = None if (h8 <= 64 and w8 <= 64) else (64, opt.tile_overlap)
             out = pipe.run_segment(seg, flows=flows, masks=masks, guidance_scale=opt.guidance_scale, tile=tile)
-            out = out[:, :, :ori_h, :ori_w].cpu()
+            size_min = min(lr[s0].shape[-2:])
+            up_scale = max(512.0 / size_min, opt.upscale)
+            if up_scale > opt.upscale:                # small inputs were upsampled further: back to the requested scale (:523-530)
+                from mgld_vsr_amd import hip
+                out = hip.resize_bicubic(out, (int(seg.shape[-2] * opt.upscale / up_scale), int(seg.shape[-1] * opt.upscale / up_scale)),
+                                         clamp=(0.0, 1.0))
+                ori_h, ori_w = min(ori_h, out.shape[-2]), min(ori_w, out.shape[-1])
+            arrs = preproc.to_png_payload(out, ori_h, ori_w)                                  # crop + uint8 (:532-543)
             from PIL import Image
-            for k in range(out.shape[0]):
-                idx = s0 + k
-                if idx >= len(set(paths)) and paths[idx] == paths[-1] and idx != len(paths) - 1:
-                    pass
-                arr = (out[k].permute(1, 2, 0).numpy() * 255.0).round().clip(0, 255).astype(np.uint8)
-                Image.fromarray(arr).save(os.path.join(opt.outdir, seq, os.path.basename(paths[idx])))
-
+            for k in range(arrs.shape[0]):
+                Image.fromarray(arrs[k]).save(os.path.join(opt.outdir, seq, os.path.basename(paths[s0 + k])))
 
 if __name__ == "__main__":
     main()

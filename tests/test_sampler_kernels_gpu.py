@@ -153,3 +153,35 @@ def test_tile_ops(hip):
     out = torch.empty_like(acc)
     hip.tile_normalize(acc, cnt, out)
     assert rel_l2(out.cpu(), racc / rcnt) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K11: pre/post-processing kernels vs the oracle restatement of the script's torch calls
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,h,w,upscale", [(2, 128, 128, 4.0), (1, 90, 160, 4.0), (2, 45, 64, 4.0), (1, 270, 480, 4.0)])
+def test_preproc_upsample_pad_flowinput(hip, T, h, w, upscale):
+    from mgld_vsr_amd import preproc
+    from oracle import preproc as opre
+    x = (torch.rand(T, 3, h, w, generator=torch.Generator().manual_seed(5)) * 2 - 1)
+    up = preproc.upsample_lr(x, upscale)
+    ref = opre.upsample_lr(x, upscale)
+    assert up.shape == ref.shape
+    assert float((up.cpu() - ref).abs().max()) < 2e-6          # same taps, same weights; only fma contraction differs
+    pad, oh, ow = preproc.pad_to_32(up)
+    rpad, roh, row = opre.pad_to_32(ref)
+    assert (oh, ow) == (roh, row) and pad.shape == rpad.shape
+    assert torch.equal(pad.cpu(), opre.pad_to_32(up.cpu())[0])  # pure data movement: bit-exact on the same input
+    fi = preproc.flow_input(pad)
+    assert float((fi.cpu() - opre.flow_input(pad.cpu())).abs().max()) < 2e-6
+
+
+def test_preproc_png_payload(hip):
+    from mgld_vsr_amd import preproc
+    from oracle import preproc as opre
+    g = torch.Generator().manual_seed(6)
+    out = torch.rand(2, 3, 96, 128, generator=g)
+    out[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 0.5, 254.9999 / 255.0])
+    got = preproc.to_png_payload(out.cuda(), 90, 120)
+    ref = opre.to_png_payload(out, 90, 120)
+    assert got.dtype == ref.dtype and got.shape == ref.shape == (2, 90, 120, 3)
+    assert (got == ref).all()                                   # integer payload: bit-exact
