@@ -208,8 +208,8 @@ def test_pipeline_small_end_to_end_vs_oracle(hip):
         _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
-    record("e2e_small_latent", rel_l2(lat, x0))
-    assert record("e2e_small_frames", rel_l2(out, ref)) < 1e-2
+    assert record("e2e_small_latent", rel_l2(lat, x0)) < 2e-3
+    assert record("e2e_small_frames", rel_l2(out, ref)) < 1e-3     # north_star: outputs within 1e-3 rel-L2 (measured 8.9e-4)
 
 
 def test_pipeline_frame_sharded_matches_unsharded(hip):
@@ -284,9 +284,9 @@ def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
         _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
-    record("e2e_full_latent", rel_l2(lat, x0))
+    assert record("e2e_full_latent", rel_l2(lat, x0)) < 2e-3
     record("e2e_full_decoder_only", rel_l2(vq.decode(x0.cuda() / 0.18215, [f.cuda() for f in fea]), dec))
-    assert record("e2e_full_frames", rel_l2(out, ref)) < 1e-2
+    assert record("e2e_full_frames", rel_l2(out, ref)) < 1e-3      # north_star: outputs within 1e-3 rel-L2 (measured 9.5e-4)
 
 
 def test_sample_small_50_steps_vs_oracle(hip):
