@@ -62,7 +62,9 @@ enum {
   MGLD_ACT_RELU = 1,
   MGLD_ACT_LRELU02 = 2,
   MGLD_ACT_SILU = 3,
-  MGLD_ACT_GEGLU = 4 /* W rows packed [32 value | 32 gate] per 64; output has N/2 columns: v*gelu(g) */
+  MGLD_ACT_GEGLU = 4, /* W rows packed [32 value | 32 gate] per 64; output has N/2 columns: v*gelu(g) */
+  MGLD_ACT_SIGMOID = 5,
+  MGLD_ACT_TANH = 6
 };
 
 typedef struct MgldIGemm {
@@ -95,7 +97,10 @@ typedef struct MgldIGemm {
   int32_t t_off;          /* TCONV3 on a frame-sharded clip: output frame f sits at position f + t_off of a clip of T
                              frames whose rows start t_off frames BEFORE `A` (A points at the first output frame inside a
                              halo-extended buffer); M = (#output frames)*HW.  0 = whole clips (M % (T*HW) == 0).       */
-  int32_t reserved0;
+  int32_t kh, kw;         /* CONV3X3 mode with a general kernel: kh x kw taps (1..15 each), K = kh*kw*Cin, W laid out
+                             [Cout][ky][kx][Cin]; 0,0 (or 3,3) = the 3x3 kernel.  Other sizes use the per-lane gather path
+                             (RAFT's 7x7, 1x5, 5x1 and strided 1x1 convolutions, raft_arch.py:216,383-389,430).         */
+  int32_t reserved1;
 } MgldIGemm;
 
 int mgld_igemm(const MgldIGemm* p, void* stream);
@@ -111,11 +116,12 @@ int mgld_set_workspace(void* ptr, int64_t bytes);
  * Replaces nn.GroupNorm / GroupNorm32 (diffusionmodules/util.py:214-216, model.py:80-81, attention.py:87-88).
  * mgld_gn_stats: one launch; per (frame, row chunk) the per-group (sum, sumsq) in fp64 ->
  *   gsums[frames][chunks = mgld_gn_chunks(rows)][groups][2] doubles.  The consumers below finish the reduction over
- *   chunks (fp64) in their prologue and derive mean / rstd themselves — no separate finalize launch.  groups <= 64.
+ *   chunks (fp64) in their prologue and derive mean / rstd themselves — no separate finalize launch.  groups <= 256.
  */
 int mgld_gn_chunks(int rows_per_frame);
 int mgld_gn_stats(const void* x, int frames, int rows_per_frame, int C, int ld, int groups, double* gsums, void* stream);
-/* y = [silu]((x-mean)*rstd*gamma+beta); x,y fp16 NHWC */
+/* y = act((x-mean)*rstd*gamma+beta); x,y fp16 NHWC; act: 0 none, 1 SiLU, 2 ReLU.  groups <= 256 (groups == C gives
+ * InstanceNorm2d, raft_arch.py:115-119,211) */
 int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta,
                   void* y, int ldy, int frames, int rows_per_frame, int C, int groups, int silu, void* stream);
 /* SPADE modulation + residual (spade.py:93-111, openaimodel.py:481-482):
@@ -232,6 +238,29 @@ int mgld_reflect_pad(const float* x, float* y, int planes, int h, int w, int oh,
 /* [n,c,H,W] fp32 in [0,1] -> uint8 [n,h,w,c] of the top-left h x w window: (x*255).astype(uint8), i.e. truncation, as the
  * reference writes its PNGs (oldcanvas_tile.py:532-543) */
 int mgld_to_uint8_hwc(const float* x, void* y, int n, int c, int H, int W, int h, int w, void* stream);
+
+
+/* ---- RAFT flow estimator pieces (basicsr/archs/raft_arch.py) ---------------------------------------
+ * The encoders / update block run on mgld_igemm (general kh x kw taps) and the norm kernels; these are the rest. */
+/* F.avg_pool2d(x, 2, stride=2) on fp32 planes [planes, h, w] -> [planes, h/2, w/2]  (correlation pyramid, :47-49) */
+int mgld_avgpool2(const float* x, float* y, int64_t planes, int h, int w, void* stream);
+/* CorrBlock.__call__ (:54-75): windowed bilinear lookup of the pyramid at coords [B,2,H,W] (pixel units, x then y);
+ * levels[l] = fp32 [B*H*W, hs[l], ws[l]]; out fp16 [B*H*W, ldo], column l*(2r+1)^2 + i*(2r+1) + j samples
+ * (cx/2^l + i - r, cy/2^l + j - r) with zeros outside (grid_sample, align_corners=True). */
+int mgld_corr_lookup(const float* const* levels, const int* hs, const int* ws, int nlev, const float* coords, int B, int H, int W,
+                     int radius, void* out, int ldo, void* stream);
+/* SepConvGRU arithmetic (:390-405), fp16 [M, *] views: rhx = cat([r*h, x]) from hx = cat([h, x]);  h = (1-z)*h + z*q */
+int mgld_gru_rh(const void* r, int ldr, const void* hx, int ldhx, void* rhx, int ldo, int64_t M, int Ch, int Cx, void* stream);
+int mgld_gru_gate(const void* z, int ldz, const void* q, int ldq, void* h, int ldh, int64_t M, int Ch, void* stream);
+/* coords1 += delta (fp32 NHWC [B*HW, ldd] columns 0,1; NULL = no update); flow = coords1 - coords0 (fp32 NCHW), also
+ * written as two fp16 columns at `mot` / `fin` (NULL to skip): the motion-feature tail and the flow-conv input (:444,:778-783) */
+int mgld_flow_update(float* coords1, const float* coords0, const float* delta, int ldd, float* flow, void* mot, int ldm, void* fin,
+                     int ldf, int B, int HW, void* stream);
+/* convex 8x upsampling (:720-731): mask fp16 NHWC [B*H*W, ldm >= 576] (already scaled by 0.25), flow fp32 [B,2,H,W] ->
+ * out fp32 [B,2,8H,8W] */
+int mgld_convex_upsample(const float* flow, const void* mask, int ldm, float* out, int B, int H, int W, void* stream);
+/* y = relu(a + b), fp16 [M, C] views (ResidualBlock tail, :138) */
+int mgld_add_relu(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C, void* stream);
 
 #ifdef __cplusplus
 }

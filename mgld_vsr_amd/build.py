@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgld_hip.so")
 STAMP = os.path.join(HERE, "csrc", ".build_stamp")
-SOURCES = ["runtime.hip", "igemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["runtime.hip", "igemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "raft.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 
 

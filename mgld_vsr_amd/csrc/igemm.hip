@@ -61,6 +61,8 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == MGLD_ACT_RELU) return fmaxf(x, 0.f);
   if (act == MGLD_ACT_LRELU02) return x > 0.f ? x : 0.2f * x;
   if (act == MGLD_ACT_SILU) return silu_f(x);
+  if (act == MGLD_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+  if (act == MGLD_ACT_TANH) return tanhf(x);
   return x;
 }
 
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
       const bool kval = kl < k_end;
       // branch-free: the offset is always computed, the pointer is SELECTED (out-of-range -> zero page)
       int ky = 0, kx = 0;
-      if constexpr (MODE == MGLD_MODE_CONV3X3) { ky = tap / 3; kx = tap - ky * 3; }
+      if constexpr (MODE == MGLD_MODE_CONV3X3) { const int kw = p.kw > 0 ? p.kw : 3; ky = tap / kw; kx = tap - ky * kw; }
       const int hlim = p.up2 ? 2 * p.Hin : p.Hin, wlim = p.up2 ? 2 * p.Win : p.Win, sh = p.up2 ? 1 : 0;
 #pragma unroll
       for (int j = 0; j < JA; ++j) {
@@ -586,6 +588,7 @@ void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
 inline bool fast_ok(const MgldIGemm* p) {
   if (p->K % BK) return false;
   if (p->mode == MGLD_MODE_LINEAR) return true;
+  if (p->mode == MGLD_MODE_CONV3X3 && p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;   // generic taps: per-lane path
   return (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2);
 }
 
@@ -683,7 +686,9 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   MGLD_REQUIRE((p->strideA & 7) == 0 && (p->strideW & 7) == 0, "igemm: batch strides must be multiples of 8");
   if (p->mode != MGLD_MODE_LINEAR) {
     MGLD_REQUIRE(p->Cin > 0 && (p->Cin & 7) == 0, "igemm: Cin must be a positive multiple of 8");
-    const int taps = (p->mode == MGLD_MODE_CONV3X3) ? 9 : 3;
+    if (p->mode == MGLD_MODE_CONV3X3 && p->kh > 0)
+      MGLD_REQUIRE(p->kw > 0 && p->kh <= 15 && p->kw <= 15 && !p->up2, "igemm: conv kernel size (generic taps: 1..15, no upsample fold)");
+    const int taps = (p->mode == MGLD_MODE_CONV3X3) ? (p->kh > 0 ? p->kh * p->kw : 9) : 3;
     MGLD_REQUIRE(p->K == taps * p->Cin, "igemm: K != taps*Cin");
     if (p->mode == MGLD_MODE_CONV3X3) {
       MGLD_REQUIRE(p->Hin > 0 && p->Win > 0 && p->Hout > 0 && p->Wout > 0, "igemm: conv geometry");
@@ -696,7 +701,8 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
     }
   }
   if (p->tap_inner)
-    MGLD_REQUIRE(p->mode != MGLD_MODE_LINEAR && (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2),
+    MGLD_REQUIRE(p->mode != MGLD_MODE_LINEAR && (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2) &&
+                     !(p->mode == MGLD_MODE_CONV3X3 && p->kh > 0 && !(p->kh == 3 && p->kw == 3)),
                  "igemm: tap_inner needs a gather mode with Cin % 64 == 0 and no upsample fold");
   if (p->rowvec) MGLD_REQUIRE(p->rows_per_frame > 0, "igemm: rows_per_frame");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");

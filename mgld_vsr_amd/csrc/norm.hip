@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
 
 // ---- (mean, rstd) of every group of one frame from the chunk sums, fp64 combine; result in LDS [groups][2].
 // Called by all 256 threads of a block; ends with a barrier.
-constexpr int GN_MAX_GROUPS = 64;
+constexpr int GN_MAX_GROUPS = 256;
 __device__ __forceinline__ void gn_group_stats(const double* __restrict__ gs, int chunks, int groups, int rows, int cg,
                                                float eps, float (*st)[2]) {
   const int tid = threadIdx.x;
@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
             float f = (float)d[u][j] * sa[j] + sb[j];
             if (SPADE) {
               f = f * (1.f + (float)gm[u][j]) + (float)bt[u][j] + (float)sk[u][j];
-            } else if (silu) {
+            } else if (silu == 1) {
               f = silu_f(f);
+            } else if (silu == 2) {
+              f = fmaxf(f, 0.f);
             }
             o[j] = (f16)f;
           }

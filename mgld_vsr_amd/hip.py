@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libmgld_hip.so")
 _lib = None
 
 MODE_LINEAR, MODE_CONV3X3, MODE_TCONV3 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SILU, ACT_GEGLU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4, 5, 6
 
 
 class MgldIGemm(C.Structure):
@@ -31,7 +31,7 @@ class MgldIGemm(C.Structure):
         ("alpha", C.c_float), ("beta", C.c_float),
         ("batch", C.c_int32), ("tap_inner", C.c_int32),
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
-        ("t_off", C.c_int32), ("reserved0", C.c_int32),
+        ("t_off", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -61,6 +61,8 @@ EXPORTS = [
     "mgld_adain", "mgld_wavelet_reconstruction",
     "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize",
     "mgld_resize_bicubic", "mgld_reflect_pad", "mgld_to_uint8_hwc",
+    "mgld_avgpool2", "mgld_corr_lookup", "mgld_gru_rh", "mgld_gru_gate", "mgld_flow_update", "mgld_convex_upsample",
+    "mgld_add_relu",
 ]
 
 
@@ -113,7 +115,7 @@ def _ld(t):
 
 def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None,
           act=ACT_NONE, alpha=1.0, beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0,
-          M=None, N=None, K=None, tap_inner=0, t_off=0):
+          M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None):
     """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h)."""
     _req_cuda(a, w, out)
     p = MgldIGemm()
@@ -136,6 +138,8 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
     p.batch = batch
     p.tap_inner = tap_inner
     p.t_off = t_off
+    if ksize is not None:
+        p.kh, p.kw = ksize
     p.strideA, p.strideW, p.strideC, p.strideR = strideA, strideW, strideC, strideR
     if mode == MODE_CONV3X3:
         p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = conv
@@ -195,7 +199,7 @@ def gn_stats(x, frames, rows, groups, gsums):
 def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu):
     _req_cuda(x, gsums, gamma, beta, y)
     _chk(lib().mgld_gn_apply(_p(x), _ld(x), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), _p(y), _ld(y), frames, rows,
-                             x.shape[1], groups, 1 if silu else 0, stream_ptr()), "gn_apply")
+                             x.shape[1], groups, int(silu), stream_ptr()), "gn_apply")
     return y
 
 
@@ -462,4 +466,62 @@ def to_uint8_hwc(x, h=None, w=None):
     h, w = h or H, w or W
     y = torch.empty(n, h, w, c, dtype=torch.uint8, device=x.device)
     _chk(lib().mgld_to_uint8_hwc(_p(x), _p(y), n, c, H, W, h, w, stream_ptr()), "to_uint8_hwc")
+    return y
+
+
+# ---- RAFT pieces ------------------------------------------------------------------------------------------------------
+def avgpool2(x):
+    """x fp32 [planes, h, w] -> [planes, h//2, w//2]"""
+    _req_cuda(x)
+    pl, h, w = x.shape
+    y = torch.empty(pl, h // 2, w // 2, dtype=torch.float32, device=x.device)
+    _chk(lib().mgld_avgpool2(_p(x), _p(y), C.c_int64(pl), h, w, stream_ptr()), "avgpool2")
+    return y
+
+
+def corr_lookup(levels, coords, radius, out):
+    """levels: list of fp32 [B*H*W, h_l, w_l]; coords fp32 [B,2,H,W]; out fp16 [B*H*W, >= nlev*(2r+1)^2]"""
+    _req_cuda(coords, out, *levels)
+    n = len(levels)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in levels])
+    hs = (C.c_int * n)(*[t.shape[1] for t in levels])
+    ws = (C.c_int * n)(*[t.shape[2] for t in levels])
+    B, _, H, W = coords.shape
+    _chk(lib().mgld_corr_lookup(ptrs, hs, ws, n, _p(coords), B, H, W, radius, _p(out), _ld(out), stream_ptr()), "corr_lookup")
+    return out
+
+
+def gru_rh(r, hx, rhx, Ch):
+    _req_cuda(r, hx, rhx)
+    _chk(lib().mgld_gru_rh(_p(r), _ld(r), _p(hx), _ld(hx), _p(rhx), _ld(rhx), C.c_int64(hx.shape[0]), Ch, hx.shape[1] - Ch,
+                           stream_ptr()), "gru_rh")
+    return rhx
+
+
+def gru_gate(z, q, h):
+    _req_cuda(z, q, h)
+    _chk(lib().mgld_gru_gate(_p(z), _ld(z), _p(q), _ld(q), _p(h), _ld(h), C.c_int64(h.shape[0]), h.shape[1], stream_ptr()), "gru_gate")
+    return h
+
+
+def flow_update(coords1, coords0, delta, flow, mot=None, fin=None):
+    _req_cuda(coords1, coords0, flow)
+    B, _, H, W = coords1.shape
+    _chk(lib().mgld_flow_update(_p(coords1), _p(coords0), _p(delta), _ld(delta) if delta is not None else 0, _p(flow),
+                                _p(mot), _ld(mot) if mot is not None else 0, _p(fin), _ld(fin) if fin is not None else 0, B,
+                                H * W, stream_ptr()), "flow_update")
+    return flow
+
+
+def convex_upsample(flow, mask):
+    _req_cuda(flow, mask)
+    B, _, H, W = flow.shape
+    out = torch.empty(B, 2, 8 * H, 8 * W, dtype=torch.float32, device=flow.device)
+    _chk(lib().mgld_convex_upsample(_p(flow), _p(mask), _ld(mask), _p(out), B, H, W, stream_ptr()), "convex_upsample")
+    return out
+
+
+def add_relu(a, b, y):
+    _req_cuda(a, b, y)
+    _chk(lib().mgld_add_relu(_p(a), _ld(a), _p(b), _ld(b), _p(y), _ld(y), C.c_int64(a.shape[0]), a.shape[1], stream_ptr()), "add_relu")
     return y

@@ -26,7 +26,11 @@ def synth_param(name, shape, salt="w"):
     n = int(np.prod(shape)) if len(shape) else 1
     v = g.standard_normal(n, dtype=np.float32).reshape(shape)
     leaf = name.rsplit(".", 1)[-1]
-    if leaf == "bias":
+    if leaf == "running_var":       # BatchNorm statistics (RAFT context encoder): strictly positive
+        v = 1.0 + 0.3 * np.abs(v)
+    elif leaf == "running_mean":
+        v *= 0.1
+    elif leaf == "bias":
         v *= 0.02
     elif len(shape) >= 2:
         fan_in = int(np.prod(shape[1:]))

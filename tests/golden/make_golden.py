@@ -262,6 +262,25 @@ def gen_sample(model, ddpm):
     save("g_sample", **out)
 
 
+def gen_raft():
+    """RAFT_SR ('normal') of the reference on synthetic weights: two 3-frame clips of 40x56 LR frames (padding path of
+    InputPadder exercised: 40 is a multiple of 8, 56 is; use 44x60 instead) -> compute_flow-style pairs, 4 iterations."""
+    ra = ref_import.ref("basicsr.archs.raft_arch")
+    net = ra.RAFT_SR(model="normal").eval()
+    synth.fill_module_(net, "raft")
+    h, w = 124, 132   # padded to 128x136 by InputPadder (both paddings exercised); 1/8 grid 16x17, pyramid down to 2x2
+    lrs = torch.sigmoid(synth.synth_tensor("raft/lr", (1, 3, 3, h, w), 1.5))
+    # smooth + textured content so that correlation has structure: low-pass the noise a little
+    lrs = torch.nn.functional.avg_pool2d(lrs.view(3, 3, h, w), 3, 1, 1).view(1, 3, 3, h, w)
+    a, b = lrs[:, :-1].reshape(-1, 3, h, w), lrs[:, 1:].reshape(-1, 3, h, w)
+    out = {}
+    for iters in (1, 4):
+        out[f"bwd{iters}"] = net(a, b, iters=iters)
+        out[f"fwd{iters}"] = net(b, a, iters=iters)
+    fmap = net.fnet([a, b])
+    save("g_raft", lrs=lrs, fmap1=fmap[0], cnet=net.cnet(a), names_shapes=names_shapes(net), **out)
+
+
 def gen_spliter():
     ui = ref_import.ref("scripts.util_image")
     out = {}
@@ -273,6 +292,11 @@ def gen_spliter():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # e.g. `make_golden.py raft`: regenerate selected fixtures only
+        for what in sys.argv[1:]:
+            globals()["gen_" + what]()
+        sys.exit(0)
+    gen_raft()
     gen_flow()
     gen_guidance()
     try:

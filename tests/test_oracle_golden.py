@@ -132,3 +132,23 @@ def test_gaussian_weights_golden():
     assert torch.equal(osamp.gaussian_weights(16, 16), g["gauss16"])
     assert torch.equal(osamp.gaussian_weights(64, 64), g["gauss64"])
     assert osamp.tile_origins(128, 128, 64, 32) == [(y, x) for x in (0, 32, 64) for y in (0, 32, 64)]
+
+
+def test_raft_golden():
+    """oracle/raft.py == the reference's RAFT_SR ('normal') on the same synthetic weights: encoders and 1- / 4-iteration
+    flows of both directions, on a 124x132 clip (InputPadder pads both axes)."""
+    from oracle import raft as oraft
+    g = G("g_raft")
+    sd = sd_from(g, "names_shapes", "raft")
+    lrs = g["lrs"]
+    n, t, c, h, w = lrs.shape
+    a, b = lrs[:, :-1].reshape(-1, c, h, w), lrs[:, 1:].reshape(-1, c, h, w)
+    with torch.no_grad():
+        f = oraft.encoder(sd, "fnet", torch.cat([a, b], 0), "instance")     # the fixture's encoder outputs: unpadded frames
+        assert rel_l2(f[:a.shape[0]], g["fmap1"]) < 1e-5
+        assert rel_l2(oraft.encoder(sd, "cnet", a, "batch"), g["cnet"]) < 1e-5
+        for iters in (1, 4):
+            assert rel_l2(oraft.raft_sr(sd, a, b, iters), g[f"bwd{iters}"]) < 1e-4
+            assert rel_l2(oraft.raft_sr(sd, b, a, iters), g[f"fwd{iters}"]) < 1e-4
+        ff, fb = oraft.compute_flow(sd, lrs, iters=1)
+        assert ff.shape == (1, t - 1, 2, h, w) and rel_l2(fb[0], g["bwd1"]) < 1e-4
