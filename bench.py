@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddpm-steps", type=int, default=50)
     ap.add_argument("--guidance", action="store_true", help="flow-guided latent warp on (configs[2]); default off (configs[1])")
+    ap.add_argument("--raft", action="store_true", help="with --guidance: estimate the flows with RAFT_SR inside the timed step")
     ap.add_argument("--tile", action="store_true", help="aggregation sampling over 64x64 latent tiles, overlap 32 (configs[3]: use with --size 1024)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (PMC profiling runs)")
     ap.add_argument("--frame-shard", action="store_true",
@@ -240,12 +241,17 @@ def main():
     if shard is not None:
         kw.update(shard=shard, gather=True)
 
+    def step():
+        if args.raft and args.guidance:
+            kw["flows"], kw["masks"] = pipe.estimate_flows(frames)
+        return pipe.run_segment(frames, **kw)
+
     for _ in range(args.warmup):
-        pipe.run_segment(frames, **kw)
+        step()
     parallel.barrier()                       # barrier + torch.cuda.synchronize() on both sides of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe.run_segment(frames, **kw)
+        out = step()
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0)
     ok = bool(torch.isfinite(out).all())

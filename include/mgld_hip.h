@@ -235,6 +235,8 @@ int mgld_tile_normalize(const float* acc, const float* cnt, float* out, int64_t 
 int mgld_resize_bicubic(const float* x, float* y, int planes, int h, int w, int oh, int ow, float lo, float hi, void* stream);
 /* F.pad(x, (0, ow-w, 0, oh-h), mode="reflect"): bottom / right reflect padding to the next multiple of 32 */
 int mgld_reflect_pad(const float* x, float* y, int planes, int h, int w, int oh, int ow, void* stream);
+/* F.pad(x, (pl, ow-w-pl, pt, oh-h-pt), mode="replicate") (RAFT InputPadder, raft_arch.py:27-28) */
+int mgld_replicate_pad(const float* x, float* y, int planes, int h, int w, int oh, int ow, int pt, int pl, void* stream);
 /* [n,c,H,W] fp32 in [0,1] -> uint8 [n,h,w,c] of the top-left h x w window: (x*255).astype(uint8), i.e. truncation, as the
  * reference writes its PNGs (oldcanvas_tile.py:532-543) */
 int mgld_to_uint8_hwc(const float* x, void* y, int n, int c, int H, int W, int h, int w, void* stream);

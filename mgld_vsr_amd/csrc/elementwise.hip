@@ -770,6 +770,18 @@ __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restric
   }
 }
 
+// F.pad(mode="replicate") by (pl, ow-w-pl) columns and (pt, oh-h-pt) rows (RAFT's InputPadder, raft_arch.py:27-28)
+__global__ __launch_bounds__(256) void replicate_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int h,
+                                                            int w, int oh, int ow, int pt, int pl) {
+  const int64_t total = (int64_t)planes * oh * ow;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const int pln = (int)(i / ((int64_t)ow * oh));
+    const int sx = min(max(ox - pl, 0), w - 1), sy = min(max(oy - pt, 0), h - 1);
+    y[i] = x[((int64_t)pln * h + sy) * w + sx];
+  }
+}
+
 // [n,3,H,W] in [0,1] -> uint8 [n,h,w,3] (top-left crop); `(x * 255).astype(np.uint8)` of the reference = truncation
 __global__ __launch_bounds__(256) void to_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int n, int c,
                                                     int H, int W, int h, int w) {
@@ -800,6 +812,14 @@ extern "C" int mgld_reflect_pad(const float* x, float* y, int planes, int h, int
   hipLaunchKernelGGL(reflect_pad_kernel, dim3(egrid((int64_t)planes * oh * ow)), dim3(256), 0, S_(stream), x, y, planes, h, w,
                      oh, ow);
   return mgld_check_launch("reflect_pad");
+}
+
+extern "C" int mgld_replicate_pad(const float* x, float* y, int planes, int h, int w, int oh, int ow, int pt, int pl,
+                                  void* stream) {
+  MGLD_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && pt >= 0 && pl >= 0 && oh >= h + pt && ow >= w + pl, "replicate_pad: bad args");
+  hipLaunchKernelGGL(replicate_pad_kernel, dim3(egrid((int64_t)planes * oh * ow)), dim3(256), 0, S_(stream), x, y, planes, h, w,
+                     oh, ow, pt, pl);
+  return mgld_check_launch("replicate_pad");
 }
 
 extern "C" int mgld_to_uint8_hwc(const float* x, void* y, int n, int c, int H, int W, int h, int w, void* stream) {

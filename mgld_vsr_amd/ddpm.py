@@ -204,8 +204,12 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 extract_into_tensor(sqrt_one_minus_alphas_cumprod.to(dev), t.to(dev), x_start.shape) * noise)
 
     def compute_flow(self, lrs):
-        """ddpm.py:3404-3429 — RAFT is SURVEY.md §8(f) 'next'; flows are inputs on this path."""
-        return self.flownet_model(lrs)
+        """ddpm.py:3404-3429: lrs [n,t,3,h,w] in [0,1] -> (flows_forward, flows_backward), each [n,t-1,2,h,w].  Both
+        directions go through the flow network (RAFT_SR, mgld_vsr_amd/raft.py) as one batch of frame pairs."""
+        from .raft import compute_flow
+        if getattr(self.flownet_model, "_engine", None) is None and hasattr(self.flownet_model, "set_engine"):
+            self.flownet_model.set_engine(self.engine())
+        return compute_flow(self.flownet_model, lrs)
 
     @torch.no_grad()
     def compute_temporal_condition_v4(self, flows, latents, masks):

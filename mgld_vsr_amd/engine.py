@@ -35,6 +35,15 @@ def pack_conv3x3(w, cin_pad=None, tap_inner=None):
     return out.reshape(cout, 9 * cp).contiguous()
 
 
+def pack_conv(w, cin_pad=None):
+    """[Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin_pad], K index = (ky*kw+kx)*Cin_pad + c (general-tap igemm layout)."""
+    cout, cin, kh, kw = w.shape
+    cp = cin_pad or ((cin + 7) // 8 * 8)
+    out = torch.zeros(cout, kh * kw, cp, dtype=w.dtype)
+    out[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    return out.reshape(cout, kh * kw * cp).contiguous()
+
+
 def pack_conv1x1(w, cin_pad=None):
     """[Cout, Cin, 1, 1] or [Cout, Cin, 1] or [Cout, Cin] -> [Cout, Cin_pad]."""
     cout, cin = w.shape[0], w.shape[1]
@@ -196,6 +205,21 @@ class Engine:
                   rows_per_frame=rows_per_frame or ho * wo, resid=None if resid is None else resid.v, act=act, alpha=alpha,
                   beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0),
                   tap_inner=1 if conv_tap_inner(cin, up2) else 0)   # must match pack_conv3x3(..., tap_inner) of wp
+        self.launches += 1
+        return out
+
+    def conv2d(self, x, wp, bias, cout, ksize, stride=1, pad=(0, 0), out=None, act=hip.ACT_NONE, alpha=1.0,
+               out_dtype=torch.float16):
+        """general kh x kw convolution (per-lane gather path of the igemm): wp from pack_conv, pad = (top, left)."""
+        kh, kw = ksize
+        ho = (x.h + 2 * pad[0] - kh) // stride + 1
+        wo = (x.w + 2 * pad[1] - kw) // stride + 1
+        if out is None:
+            out = Act(self.arena.alloc((x.n * ho * wo, cout), out_dtype), x.n, ho, wo)
+        cin = x.C
+        assert wp.shape[1] == kh * kw * cin, (wp.shape, kh, kw, cin)
+        hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, act=act, alpha=alpha, N=cout,
+                  conv=(cin, x.h, x.w, ho, wo, stride, pad[0], pad[1], 0), ksize=(kh, kw))
         self.launches += 1
         return out
 

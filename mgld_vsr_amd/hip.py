@@ -60,7 +60,7 @@ EXPORTS = [
     "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
     "mgld_adain", "mgld_wavelet_reconstruction",
     "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize",
-    "mgld_resize_bicubic", "mgld_reflect_pad", "mgld_to_uint8_hwc",
+    "mgld_resize_bicubic", "mgld_reflect_pad", "mgld_replicate_pad", "mgld_to_uint8_hwc",
     "mgld_avgpool2", "mgld_corr_lookup", "mgld_gru_rh", "mgld_gru_gate", "mgld_flow_update", "mgld_convex_upsample",
     "mgld_add_relu",
 ]
@@ -455,6 +455,17 @@ def reflect_pad(x, oh, ow):
     n, c, h, w = x.shape
     y = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
     _chk(lib().mgld_reflect_pad(_p(x), _p(y), n * c, h, w, oh, ow, stream_ptr()), "reflect_pad")
+    return y
+
+
+def replicate_pad(x, pad):
+    """F.pad(x, pad=(left, right, top, bottom), mode="replicate") for x [n,c,h,w] fp32"""
+    _req_cuda(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    l, r, t, b = pad
+    y = torch.empty(n, c, h + t + b, w + l + r, dtype=torch.float32, device=x.device)
+    _chk(lib().mgld_replicate_pad(_p(x), _p(y), n * c, h, w, h + t + b, w + l + r, t, l, stream_ptr()), "replicate_pad")
     return y
 
 

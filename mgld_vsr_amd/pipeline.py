@@ -68,6 +68,8 @@ class VSRPipeline:
             synth.fill_module_(self.model.structcond_stage_model, "structcond")
             synth.fill_module_(self.model.first_stage_model, "first_stage")
             synth.fill_module_(self.vq_model, "vae")
+            if hasattr(self.model.flownet_model, "fnet"):
+                synth.fill_module_(self.model.flownet_model, "raft")
         self._setup_schedule(ddpm_steps)
         self.chunk_bytes = chunk_bytes
 
@@ -97,6 +99,24 @@ class VSRPipeline:
                         self.vq_model):
                 sub.set_engine(self.model._engine)
         return self.model._engine
+
+    @torch.no_grad()
+    def estimate_flows(self, frames):
+        """Flow + occlusion inputs of the guidance from the frames themselves, as the script prepares them
+        (oldcanvas_tile.py:392-413): [0,1] quarter-resolution frames -> RAFT_SR both directions (compute_flow) -> resize to
+        the latent grid -> forward/backward consistency masks.  frames: [T,3,H,W] in [-1,1].  Returns (flows, masks) in
+        the layout run_segment / sample() take."""
+        from . import preproc
+        from .flowops import forward_backward_consistency_check, resize_flow
+        eng = self.engine()
+        x = frames.to(eng.device, torch.float32).contiguous()
+        H, W = x.shape[-2:]
+        lr = preproc.flow_input(x)
+        f_fwd, f_bwd = self.model.compute_flow(lr[None])                 # flows[0], flows[1] of the script
+        f0 = resize_flow(f_fwd[0], "shape", (H // 8, W // 8))
+        f1 = resize_flow(f_bwd[0], "shape", (H // 8, W // 8))
+        fo, bo = forward_backward_consistency_check(f1, f0)             # fwd_flow = flows[1], bwd_flow = flows[0] (:405-407)
+        return (f0[None], f1[None]), (fo[None, :, None], bo[None, :, None])
 
     @torch.no_grad()
     def run_segment(self, frames, flows=None, masks=None, guidance_scale=-10.0, noise=None, tile=None, use_graph=True,

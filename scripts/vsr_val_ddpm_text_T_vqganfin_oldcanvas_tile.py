@@ -119,8 +119,8 @@ def main():
                 # fwd_flow = flows[1] (true forward flow), bwd_flow = flows[0]  (oldcanvas_tile.py:405-409)
                 fo, bo = forward_backward_consistency_check(f_bwd, f_fwd)
                 flows, masks = (f_fwd[None], f_bwd[None]), (fo[None, :, None], bo[None, :, None])
-            else:
-                print(f"[{seq}] no flows given: motion guidance off for this segment")
+            else:                                      # as the reference: estimate them with RAFT_SR (:392-413)
+                flows, masks = pipe.estimate_flows(seg)
             h8, w8 = seg.shape[-2] // 8, seg.shape[-1] // 8
             tile = None if (h8 <= 64 and w8 <= 64) else (64, opt.tile_overlap)
             out = pipe.run_segment(seg, flows=flows, masks=masks, guidance_scale=opt.guidance_scale, tile=tile)

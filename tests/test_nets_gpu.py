@@ -11,6 +11,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -309,3 +310,50 @@ def test_sample_small_50_steps_vs_oracle(hip):
         ref = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, ctx, lat, xT, [noise[S - 1 - k] for k in range(S)], S,
                            guidance_scale=-10.0, flows=fl, masks=mk)
         assert record(f"sample50_small_{tag}", rel_l2(x0, ref)) < (1e-2 if fl is None else 5e-2)
+
+
+def test_raft_flow_vs_oracle(hip):
+    """RAFT_SR ('normal') on the HIP kernels vs the oracle restatement (itself pinned to the reference's
+    module by g_raft.npz): both directions of a 3-frame clip whose size needs InputPadder on both axes, 4 GRU iterations."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    from mgld_vsr_amd.raft import RAFT_SR, compute_flow
+    from oracle import raft as oraft
+    net = synth.fill_module_(RAFT_SR(model="normal"), "raft")
+    h, w = 124, 132
+    lrs = torch.sigmoid(synth.synth_tensor("raft/lr", (1, 3, 3, h, w), 1.5))
+    lrs = F.avg_pool2d(lrs.view(3, 3, h, w), 3, 1, 1).view(1, 3, 3, h, w)
+    ff, fb = compute_flow(net, lrs, iters=4)
+    assert ff.shape == (1, 2, 2, h, w) and bool(torch.isfinite(ff).all())
+    with torch.no_grad():
+        rf, rb = oraft.compute_flow(net.state_dict(), lrs, iters=4)
+    e = max(record("raft_flow_fwd", rel_l2(ff, rf)), record("raft_flow_bwd", rel_l2(fb, rb)))
+    # fp16 activations through the recurrent update (tolerance stated here: flows feed sub-pixel warps of 64x64 latents)
+    assert e < 5e-3
+    record("raft_flow_max_abs_px", float((ff.cpu() - rf).abs().max()))
+
+
+def test_pipeline_estimate_flows_vs_oracle(hip):
+    """the script's flow preparation (oldcanvas_tile.py:392-413) end to end: [0,1] quarter-resolution frames (bicubic kernel) ->
+    RAFT_SR both directions -> resize to the latent grid -> forward/backward consistency masks, vs the oracle chain."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    from oracle import flow as oflow
+    from oracle import preproc as opre
+    from oracle import raft as oraft
+    Tn, H = 3, 512
+    cfgs = model_configs(Tn, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                         struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                         vae_overrides=dict(ch=32, resolution=H), context_dim=64)
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=4, configs=cfgs)
+    x = F.avg_pool2d(synth.synth_tensor("flowprep/x", (Tn, 3, H, H), 0.8), 5, 1, 2).clamp(-1, 1)
+    (f0, f1), (fo, bo) = pipe.estimate_flows(x)
+    with torch.no_grad():
+        lr = opre.flow_input(x)
+        rf, rb = oraft.compute_flow(pipe.model.flownet_model.state_dict(), lr[None])
+        r0, r1 = oflow.resize_flow(rf[0], H // 8, H // 8), oflow.resize_flow(rb[0], H // 8, H // 8)
+        rfo, rbo = oflow.forward_backward_consistency_check(r1, r0)
+    assert f0.shape == (1, Tn - 1, 2, H // 8, H // 8) and fo.shape == (1, Tn - 1, 1, H // 8, H // 8)
+    assert max(record("flowprep_fwd", rel_l2(f0[0], r0)), record("flowprep_bwd", rel_l2(f1[0], r1))) < 5e-3
+    # the occlusion masks are thresholded (0/1): only pixels sitting on the threshold may flip
+    flips = float((fo[0, :, 0].cpu() != rfo).float().mean()) + float((bo[0, :, 0].cpu() != rbo).float().mean())
+    assert record("flowprep_mask_flip_fraction", flips) < 2e-2
