@@ -77,7 +77,9 @@ def wavelet_reconstruction(content_feat, style_feat):
 
 
 class ImageSpliterTh:
-    """scripts/util_image.py:686-769: pixel tiling with uniform-count averaging (host-side bookkeeping only)."""
+    """scripts/util_image.py:686-769: pixel tiling with uniform-count averaging.  Device-resident fp32 images are cropped,
+    accumulated and normalised by the C-ABI kernels (mgld_crop / mgld_tile_accumulate / mgld_tile_normalize); host tensors keep
+    the reference's tensor arithmetic (bookkeeping / tests)."""
 
     def __init__(self, im, pch_size, stride, sf=1):
         assert stride <= pch_size
@@ -111,7 +113,12 @@ class ImageSpliterTh:
             raise StopIteration()
         w_start = self.width_starts_list[self.num_pchs // len(self.height_starts_list)]
         h_start = self.height_starts_list[self.num_pchs % len(self.height_starts_list)]
-        pch = self.im_ori[:, :, h_start:h_start + self.pch_size, w_start:w_start + self.pch_size]
+        ph, pw = min(self.pch_size, self.im_ori.shape[2]), min(self.pch_size, self.im_ori.shape[3])
+        if self._on_device(self.im_ori):
+            pch = torch.empty(self.im_ori.shape[0], self.im_ori.shape[1], ph, pw, device=self.im_ori.device)
+            hip.crop(self.im_ori.contiguous(), pch, h_start, w_start)
+        else:
+            pch = self.im_ori[:, :, h_start:h_start + self.pch_size, w_start:w_start + self.pch_size]
         self.h_start, self.h_end = h_start * self.sf, (h_start + self.pch_size) * self.sf
         self.w_start, self.w_end = w_start * self.sf, (w_start + self.pch_size) * self.sf
         self.num_pchs += 1
@@ -122,9 +129,20 @@ class ImageSpliterTh:
             h_start, h_end, w_start, w_end = self.h_start, self.h_end, self.w_start, self.w_end
         else:
             h_start, h_end, w_start, w_end = index_infos
+        if self._on_device(self.im_res):
+            p = pch_res.to(self.im_res.device, torch.float32).contiguous()
+            ones = torch.ones(p.shape[2], p.shape[3], device=p.device)
+            hip.tile_accumulate(p, ones, self.im_res, self.pixel_count, h_start, w_start)
+            return
         self.im_res[:, :, h_start:h_end, w_start:w_end] += pch_res.to(self.im_res.device)
         self.pixel_count[:, :, h_start:h_end, w_start:w_end] += 1
 
     def gather(self):
+        if self._on_device(self.im_res):
+            return hip.tile_normalize(self.im_res, self.pixel_count, torch.empty_like(self.im_res))
         assert torch.all(self.pixel_count != 0)
         return self.im_res.div(self.pixel_count)
+
+    @staticmethod
+    def _on_device(t):
+        return t.is_cuda and t.dtype == torch.float32

@@ -120,7 +120,7 @@ class VSRPipeline:
 
     @torch.no_grad()
     def run_segment(self, frames, flows=None, masks=None, guidance_scale=-10.0, noise=None, tile=None, use_graph=True,
-                    return_latents=False, shard=None, gather=True):
+                    return_latents=False, shard=None, gather=True, clamp01=True):
         """frames: [T,3,H,W] in [-1,1] (the bicubically pre-upsampled LR segment, device or host);
         flows/masks as the reference passes them to sample(); noise: optional dict with 'posterior' [T,4,h,w],
         'x_T' [T,4,h,w], 'steps' [S,T,4,h,w].  Returns HR frames [T,3,H,W] in [0,1] on the device.
@@ -133,11 +133,12 @@ class VSRPipeline:
         eng.shard = shard
         try:
             return self._run_segment(eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents,
-                                     shard, gather)
+                                     shard, gather, clamp01)
         finally:
             eng.shard = None
 
-    def _run_segment(self, eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents, shard, gather):
+    def _run_segment(self, eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents, shard, gather,
+                     clamp01=True):
         m, vq = self.model, self.vq_model
         noise = dict(noise or {})
         if shard is not None:
@@ -177,7 +178,9 @@ class VSRPipeline:
             x_samples = adaptive_instance_normalization(x_samples, x)
         elif self.colorfix_type == "wavelet":
             x_samples = wavelet_reconstruction(x_samples, x)
-        out = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)
+        # clamp01=False: colour-fixed frames in [-1,1] as they are (the script's large-image branch averages overlapping
+        # patches BEFORE the final clamp, oldcanvas_tile.py:469-471)
+        out = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0) if clamp01 else x_samples
         if shard is not None and gather and shard.world > 1:
             out, samples = shard.all_gather(out), shard.all_gather(samples)
         return (out, samples) if return_latents else out

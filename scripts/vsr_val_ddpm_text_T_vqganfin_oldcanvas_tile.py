@@ -121,9 +121,25 @@ def main():
                 flows, masks = (f_fwd[None], f_bwd[None]), (fo[None, :, None], bo[None, :, None])
             else:                                      # as the reference: estimate them with RAFT_SR (:392-413)
                 flows, masks = pipe.estimate_flows(seg)
-            h8, w8 = seg.shape[-2] // 8, seg.shape[-1] // 8
-            tile = None if (h8 <= 64 and w8 <= 64) else (64, opt.tile_overlap)
-            out = pipe.run_segment(seg, flows=flows, masks=masks, guidance_scale=opt.guidance_scale, tile=tile)
+            def one(frames, fl, mk):
+                torch.manual_seed(opt.seed)                      # seed_everything(opt.seed) per (patch of a) segment (:430)
+                h8_, w8_ = frames.shape[-2] // 8, frames.shape[-1] // 8
+                tl = None if (h8_ <= 64 and w8_ <= 64) else (64, opt.tile_overlap)   # one 64x64 tile == plain sampling
+                return pipe.run_segment(frames, flows=fl, masks=mk, guidance_scale=opt.guidance_scale, tile=tl, clamp01=False)
+
+            if seg.shape[-2] > opt.vqgantile_size or seg.shape[-1] > opt.vqgantile_size:
+                # large frames: overlapping pixel patches through the WHOLE path, uniform-count blending (:418-471)
+                from scripts.util_image import ImageSpliterTh
+                ps, st = opt.vqgantile_size, opt.vqgantile_stride
+                im_sp = ImageSpliterTh(seg, ps, st, sf=1)
+                # flows [1,T-1,2,h,w] / masks [1,T-1,1,h,w] -> 4-D [T-1,c,h,w] for the latent-resolution spliters
+                aux = [ImageSpliterTh(t[0], ps // 8, st // 8, sf=1) for t in (flows[0], flows[1], masks[0], masks[1])]
+                for (pch, idx), (ff_, _), (fb_, _), (fo_, _), (bo_, _) in zip(im_sp, *aux):
+                    im_sp.update(one(pch, (ff_[None], fb_[None]), (fo_[None], bo_[None])), idx)
+                x_samples = im_sp.gather()
+            else:
+                x_samples = one(seg, flows, masks)
+            out = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)
             size_min = min(lr[s0].shape[-2:])
             up_scale = max(512.0 / size_min, opt.upscale)
             if up_scale > opt.upscale:                # small inputs were upsampled further: back to the requested scale (:523-530)

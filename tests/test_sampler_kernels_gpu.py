@@ -185,3 +185,19 @@ def test_preproc_png_payload(hip):
     ref = opre.to_png_payload(out, 90, 120)
     assert got.dtype == ref.dtype and got.shape == ref.shape == (2, 90, 120, 3)
     assert (got == ref).all()                                   # integer payload: bit-exact
+
+
+def test_image_spliter_device_matches_host(hip):
+    """scripts.util_image.ImageSpliterTh on device tensors (crop / accumulate / normalise kernels) == the reference's host
+    tensor arithmetic, for the large-frame branch of the script (960-pixel patches, stride 750)."""
+    from scripts.util_image import ImageSpliterTh
+    g = torch.Generator().manual_seed(11)
+    im = torch.randn(2, 3, 1024, 1100, generator=g)
+    host, dev = ImageSpliterTh(im, 960, 750, sf=1), ImageSpliterTh(im.cuda(), 960, 750, sf=1)
+    assert len(host) == len(dev) == 4
+    for (ph, ih), (pd, idd) in zip(host, dev):
+        assert ih == idd and torch.equal(pd.cpu(), ph)
+        res = ph * 0.5 + 0.25
+        host.update(res, ih)
+        dev.update(res.cuda(), idd)
+    assert torch.allclose(dev.gather().cpu(), host.gather(), atol=1e-6)
