@@ -26,9 +26,6 @@
 
 namespace {
 
-#ifndef MGLD_IGEMM_OPT_DEFAULT
-#define MGLD_IGEMM_OPT_DEFAULT 0
-#endif
 #ifndef MGLD_IGEMM_ABLATE
 #define MGLD_IGEMM_ABLATE 0   // timing-only ablation builds: 16 no W traffic, 32 no MFMA, 128 no compute, 256 no DMA, 512 no epilogue
 #endif
@@ -67,8 +64,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 }
 
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk,
-                                                                          int opt) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk) {
   constexpr int WAVES_N = BN / WN;
   constexpr int NW = (BM / WM) * (BN / WN);       // waves per block: 4 (256 threads) or 8 (512 threads)
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -83,18 +79,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  int tile_m = blockIdx.x, tile_n = blockIdx.y;
-  if (opt & 1) {
-    // XCD-aware 1-D tile order: block b lands on XCD b%8 (observed dispatch, speed only).  Each XCD gets a contiguous
-    // run of tiles swept n-fastest, so the n-tiles of one A row-panel hit that XCD's L2 back to back.
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int total = gridDim.x;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int q = total >> 3, r = total & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_m = lin / tiles_n;
-    tile_n = lin - tile_m * tiles_n;
-  }
+  const int tile_m = blockIdx.x, tile_n = blockIdx.y;
   const int bm0 = tile_m * BM;
   const int bn0 = tile_n * BN;
   const bool splitk = (ws != nullptr);
@@ -555,17 +540,6 @@ int num_cus() {
 float* g_ws = nullptr;     // split-K workspace (set by mgld_set_workspace; single-stream use)
 size_t g_ws_bytes = 0;
 
-// tuning switches (bitmask, env MGLD_IGEMM_OPT, read once): 1 = XCD-aware 1-D tile order, 2 = s_setprio around the
-// MFMA cluster, 4 = 256x128 tiles (8 waves) for large problems
-int igemm_opt() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MGLD_IGEMM_OPT");
-    v = e ? atoi(e) : MGLD_IGEMM_OPT_DEFAULT;
-  }
-  return v;
-}
-
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
 void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   constexpr int LDS = NST * (BM + BN) * ROWB;
@@ -576,12 +550,10 @@ void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
     attr_done = true;
   }
   constexpr int THREADS = 64 * (BM / WM) * (BN / WN);
-  const int opt = igemm_opt();
   const int gz = splits > 1 ? splits : (p->batch > 0 ? p->batch : 1);
   dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), gz);
-  if (opt & 1) grid = dim3(cdiv(p->M, BM) * cdiv(p->N, BN), 1, gz);
   hipLaunchKernelGGL((igemm_kernel<MODE, FAST, BM, BN, WM, WN, NST>), grid, dim3(THREADS), LDS, s, *p,
-                     splits > 1 ? g_ws : nullptr, kchunk, opt);
+                     splits > 1 ? g_ws : nullptr, kchunk);
 }
 
 // FAST: every 64-deep stage lies inside one tap and inside K (see the kernel)
@@ -627,7 +599,6 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   if (p->act == MGLD_ACT_GEGLU) { *cfg = (t128 >= 256 || M <= 64) ? 128128 : 64128; return; }
   if (N <= 32) { *cfg = 128032; return; }
   if (N <= 64) { *cfg = 128064; return; }
-  if ((igemm_opt() & 4) && (int64_t)cdiv(M, 256) * cdiv(N, 128) * batch >= 256 && N >= 128) { *cfg = 256128; return; }
   // N = 64 (mod 128), e.g. the 320-channel level: 128-wide tiles would idle a sixth of the MFMA work on padding, 64-wide
   // tiles divide N exactly and fit three blocks per CU
   if ((N & 127) == 64 && N <= 448 && (int64_t)cdiv(M, 128) * (N / 64) * batch >= 512) { *cfg = 128064; return; }
@@ -710,12 +681,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   int cfg, splits, kchunk;
   choose(p, &cfg, &splits, &kchunk);
   switch (cfg) {
-    case 256128:
-      if (igemm_opt() & 8) return launch_cfg<256, 128, 64, 64, 3>(p, s, 1, kchunk);
-      return launch_cfg<256, 128, 64, 64, 2>(p, s, 1, kchunk);
-    case 128128:
-      if (igemm_opt() & 8) return launch_cfg<128, 128, 64, 64, 3>(p, s, splits, kchunk);
-      return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
+    case 128128: return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
     case 64128: return launch_cfg<64, 128, 32, 64>(p, s, 1, kchunk);
     case 128032: return launch_cfg<128, 32, 32, 32>(p, s, 1, kchunk);
     case 128064: return launch_cfg<128, 64, 64, 32>(p, s, 1, kchunk);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Kernel-tuning microbench for the implicit-GEMM: times representative problems of the hot path (taken from the per-problem
-table bench.py dumps) in isolation with hipEvents.  `MGLD_IGEMM_OPT` (bitmask, read by the launcher) selects experimental
-variants.  Scratch tool — not part of the product path or the test suite."""
+table bench.py dumps) in isolation with hipEvents.  `MGLD_IGEMM_FORCE=<BM*1000+BN>` overrides the launcher's tile choice.
+Scratch tool — not part of the product path or the test suite."""
 import json
 import os
 import sys
@@ -75,7 +75,7 @@ def main():
         tot_ms += us * weight / 1e3
         rows.append((name, us, tf))
         print(f"{name:32s} M={M:8d} N={N:5d} K={K:6d}  {us:9.2f} us  {tf:7.1f} TF/s")
-    print(f"weighted total: {tot_ms:.1f} ms   (MGLD_IGEMM_OPT={os.environ.get('MGLD_IGEMM_OPT', '0')})")
+    print(f"weighted total: {tot_ms:.1f} ms   (MGLD_IGEMM_FORCE={os.environ.get('MGLD_IGEMM_FORCE', '-')})")
 
 
 if __name__ == "__main__":
