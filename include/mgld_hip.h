@@ -64,7 +64,8 @@ enum {
   MGLD_ACT_SILU = 3,
   MGLD_ACT_GEGLU = 4, /* W rows packed [32 value | 32 gate] per 64; output has N/2 columns: v*gelu(g) */
   MGLD_ACT_SIGMOID = 5,
-  MGLD_ACT_TANH = 6
+  MGLD_ACT_TANH = 6,
+  MGLD_ACT_GELU = 7   /* exact (erf) GELU: the text transformer's MLP (open_clip nn.GELU) */
 };
 
 typedef struct MgldIGemm {
@@ -158,6 +159,10 @@ int mgld_temporal_attention(const void* q, const void* k, const void* v, int ld,
                             int heads, int head_dim, float scale, void* stream);
 /* row softmax fp32 [rows, ld_s] -> fp16 [rows, ld_p] (VAE mid attention d=512, model.py:220-244) */
 int mgld_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, void* stream);
+/* same with a causal mask inside blocks of `causal_period` rows (column c of row r kept iff c <= r % period; 0 = none) and
+ * zero-filled pad columns [cols, cols_pad): the OpenCLIP text transformer's attention (modules.py:181-191) */
+int mgld_softmax_rows_masked(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, int cols_pad,
+                             int causal_period, void* stream);
 
 /* ---- small dense ops -----------------------------------------------------------------------------------------
  * y[m,n] = act_out( sum_k act_in(a[m,k]) * w[n,k] + b[n] ), M <= 16, fp32 a/y, fp16 w: weight-streaming GEMV

@@ -220,29 +220,32 @@ void flash_attn_kernel(const MgldAttn p) {
   }
 }
 
-// one block per row: fp32 logits -> fp16 probabilities
+// one block per row: fp32 logits -> fp16 probabilities.  period > 0: causal mask inside blocks of `period` rows (column c
+// of row r is kept iff c <= r % period: the text transformer's attn_mask); columns [cols, cols_pad) are written as zeros so
+// the probabilities can feed a GEMM whose K is padded to a multiple of 8.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t ld_s, f16* __restrict__ P,
-                                                           int64_t ld_p, int cols) {
+                                                           int64_t ld_p, int cols, int cols_pad, int period) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const float* s = S + row * ld_s;
   f16* o = P + row * ld_p;
   const int tid = threadIdx.x;
+  const int lim = period > 0 ? min(cols, (int)(row % period) + 1) : cols;   // columns [0, lim) take part
   float mx = -1e30f;
-  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, s[c]);
+  for (int c = tid; c < lim; c += 256) mx = fmaxf(mx, s[c]);
   mx = wave_max(mx);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float sum = 0.f;
-  for (int c = tid; c < cols; c += 256) sum += __expf(s[c] - mx);
+  for (int c = tid; c < lim; c += 256) sum += __expf(s[c] - mx);
   sum = wave_sum(sum);
   if ((tid & 63) == 0) red[tid >> 6] = sum;
   __syncthreads();
   sum = red[0] + red[1] + red[2] + red[3];
   const float inv = 1.f / sum;
-  for (int c = tid; c < cols; c += 256) o[c] = (f16)(__expf(s[c] - mx) * inv);
+  for (int c = tid; c < cols_pad; c += 256) o[c] = c < lim ? (f16)(__expf(s[c] - mx) * inv) : (f16)0.f;
 }
 
 }  // namespace
@@ -272,11 +275,15 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
   return mgld_check_launch("attention");
 }
 
-extern "C" int mgld_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols,
-                                 void* stream) {
-  MGLD_REQUIRE(S && P && rows > 0 && cols > 0, "softmax_rows: bad args");
+extern "C" int mgld_softmax_rows_masked(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, int cols_pad,
+                                        int causal_period, void* stream) {
+  MGLD_REQUIRE(S && P && rows > 0 && cols > 0 && cols_pad >= cols && cols_pad <= ld_p && causal_period >= 0, "softmax_rows: bad args");
   MGLD_REQUIRE(rows < (1ll << 31), "softmax_rows: too many rows");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, ld_s, (f16*)P, ld_p,
-                     cols);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, ld_s, (f16*)P, ld_p, cols,
+                     cols_pad, causal_period);
   return mgld_check_launch("softmax_rows");
+}
+
+extern "C" int mgld_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, void* stream) {
+  return mgld_softmax_rows_masked(S, ld_s, P, ld_p, rows, cols, cols, 0, stream);
 }

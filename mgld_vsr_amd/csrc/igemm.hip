@@ -60,6 +60,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == MGLD_ACT_SILU) return silu_f(x);
   if (act == MGLD_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-x));
   if (act == MGLD_ACT_TANH) return tanhf(x);
+  if (act == MGLD_ACT_GELU) return gelu_f(x);
   return x;
 }
 

@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libmgld_hip.so")
 _lib = None
 
 MODE_LINEAR, MODE_CONV3X3, MODE_TCONV3 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SILU, ACT_GEGLU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4, 5, 6
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SILU, ACT_GEGLU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class MgldIGemm(C.Structure):
@@ -53,7 +53,7 @@ EXPORTS = [
     "mgld_graph_begin", "mgld_graph_end", "mgld_graph_launch", "mgld_graph_destroy",
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
     "mgld_igemm", "mgld_igemm_config", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_layernorm",
-    "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows",
+    "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
     "mgld_linear_small", "mgld_timestep_embedding",
     "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
     "mgld_ddpm_step", "mgld_flow_warp", "mgld_guidance", "mgld_guidance_loss", "mgld_step_advance",
@@ -243,6 +243,13 @@ def softmax_rows(S, P, rows, cols):
     _req_cuda(S, P)
     _chk(lib().mgld_softmax_rows(_p(S), C.c_int64(S.stride(0)), _p(P), C.c_int64(P.stride(0)), C.c_int64(rows), cols,
                                  stream_ptr()), "softmax_rows")
+    return P
+
+
+def softmax_rows_masked(S, P, rows, cols, cols_pad, causal_period):
+    _req_cuda(S, P)
+    _chk(lib().mgld_softmax_rows_masked(_p(S), C.c_int64(S.stride(0)), _p(P), C.c_int64(P.stride(0)), C.c_int64(rows), cols,
+                                        cols_pad, causal_period, stream_ptr()), "softmax_rows_masked")
     return P
 
 

@@ -96,7 +96,7 @@ class VSRPipeline:
         if self.model._engine is None:
             self.model._engine = Engine(chunk_bytes=self.chunk_bytes)
             for sub in (self.model.model.diffusion_model, self.model.structcond_stage_model, self.model.first_stage_model,
-                        self.vq_model):
+                        self.vq_model, self.model.cond_stage_model, self.model.flownet_model):
                 sub.set_engine(self.model._engine)
         return self.model._engine
 

@@ -1,0 +1,41 @@
+"""TEST INFRASTRUCTURE — CPU fp32 restatement of FrozenOpenCLIPEmbedder.encode_with_transformer
+(ldm/modules/encoders/modules.py:181-199) over open_clip's text-transformer state_dict.
+
+PARITY UNPINNED against the reference's dependency: `open_clip` (open_clip_torch, imported at modules.py:6, un-vendored) is
+not installed in this image, so the reference class cannot be instantiated to produce golden vectors.  The restatement follows
+open_clip's published text tower — token embedding + positional embedding, pre-LN residual blocks
+x += MHA(ln_1(x), causal mask); x += c_proj(GELU(c_fc(ln_2(x)))), ln_final — and uses
+torch.nn.functional.multi_head_attention_forward, the function nn.MultiheadAttention (open_clip's `attn`) itself calls.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package."""
+import torch
+import torch.nn.functional as F
+
+
+def build_attention_mask(n_ctx):
+    """open_clip: additive causal mask, -inf above the diagonal"""
+    mask = torch.empty(n_ctx, n_ctx)
+    mask.fill_(float("-inf"))
+    mask.triu_(1)
+    return mask
+
+
+def encode_with_transformer(sd, tokens, heads, layer_idx=1, pre="model."):
+    """sd: state_dict of the embedder (`model.*` keys); tokens [n, n_ctx] long -> [n, n_ctx, width]"""
+    x = sd[pre + "token_embedding.weight"][tokens] + sd[pre + "positional_embedding"]          # :182-183
+    x = x.permute(1, 0, 2)                                                                       # NLD -> LND (:184)
+    n_layers = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith(pre + "transformer.resblocks."))
+    mask = build_attention_mask(tokens.shape[1])
+    W = x.shape[-1]
+    for i in range(n_layers - layer_idx):                                                        # :190-193 (penultimate: skip the last)
+        b = f"{pre}transformer.resblocks.{i}."
+        h = F.layer_norm(x, (W,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
+        a, _ = F.multi_head_attention_forward(h, h, h, W, heads, sd[b + "attn.in_proj_weight"], sd[b + "attn.in_proj_bias"], None, None,
+                                              False, 0.0, sd[b + "attn.out_proj.weight"], sd[b + "attn.out_proj.bias"], training=False,
+                                              need_weights=False, attn_mask=mask)
+        x = x + a
+        h = F.layer_norm(x, (W,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
+        h = F.linear(F.gelu(F.linear(h, sd[b + "mlp.c_fc.weight"], sd[b + "mlp.c_fc.bias"])), sd[b + "mlp.c_proj.weight"],
+                     sd[b + "mlp.c_proj.bias"])
+        x = x + h
+    x = x.permute(1, 0, 2)                                                                       # :186
+    return F.layer_norm(x, (W,), sd[pre + "ln_final.weight"], sd[pre + "ln_final.bias"], 1e-5)  # :187

@@ -161,3 +161,32 @@ def test_product_path_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_text_oracle_matches_module_forward():
+    """oracle/text.py vs the same tower evaluated through its nn modules the way open_clip's ResidualAttentionBlock does
+    (x += attn(ln_1(x), attn_mask); x += mlp(ln_2(x))).  open_clip itself is not installed: parity against the reference's
+    dependency is unpinned (see oracle/text.py); this pins the functional restatement to torch's own MultiheadAttention."""
+    import torch
+    from mgld_vsr_amd import synth
+    from mgld_vsr_amd.text import FrozenOpenCLIPEmbedder
+    from oracle import text as otext
+    emb = FrozenOpenCLIPEmbedder(layer="penultimate", context_dim=64, build_tower=True, heads=2, layers=3, vocab_size=100)
+    synth.fill_module_(emb, "clip")
+    toks = emb.tokenize(["", ""])
+    toks[1, 2:6] = torch.tensor([5, 17, 3, 99])
+    m = emb.model
+    with torch.no_grad():
+        x = (m.token_embedding(toks) + m.positional_embedding).permute(1, 0, 2)
+        mask = otext.build_attention_mask(77)
+        for blk in list(m.transformer.resblocks)[:-1]:
+            h = blk.ln_1(x)
+            x = x + blk.attn(h, h, h, need_weights=False, attn_mask=mask)[0]
+            x = x + blk.mlp(blk.ln_2(x))
+        ref = m.ln_final(x.permute(1, 0, 2))
+        got = otext.encode_with_transformer(emb.state_dict(), toks, heads=2, layer_idx=1)
+    assert torch.allclose(got, ref, atol=1e-5)
+    keys = set(emb.state_dict())
+    assert {"model.token_embedding.weight", "model.positional_embedding", "model.transformer.resblocks.0.attn.in_proj_weight",
+            "model.transformer.resblocks.2.mlp.c_proj.bias", "model.ln_final.weight", "model.text_projection",
+            "model.logit_scale"} <= keys

@@ -357,3 +357,23 @@ def test_pipeline_estimate_flows_vs_oracle(hip):
     # the occlusion masks are thresholded (0/1): only pixels sitting on the threshold may flip
     flips = float((fo[0, :, 0].cpu() != rfo).float().mean()) + float((bo[0, :, 0].cpu() != rbo).float().mean())
     assert record("flowprep_mask_flip_fraction", flips) < 2e-2
+
+
+def test_text_tower_vs_oracle(hip):
+    """the OpenCLIP-layout text transformer on the HIP kernels (LayerNorm, igemm + GELU / residual epilogues,
+    fp32 logits + causal row softmax) vs the oracle restatement; reduced width, empty prompt, 'penultimate' layer as shipped."""
+    from mgld_vsr_amd.text import FrozenOpenCLIPEmbedder
+    from oracle import text as otext
+    emb = FrozenOpenCLIPEmbedder(layer="penultimate", context_dim=128, build_tower=True, heads=2, layers=4, vocab_size=512)
+    synth.fill_module_(emb, "clip")
+    with torch.no_grad():
+        emb.model.positional_embedding.mul_(10.0)              # synthetic 1-D-style init is tiny: give the embeddings some scale
+        emb.model.token_embedding.weight.mul_(10.0)
+    toks = emb.tokenize(["", ""])
+    assert toks.shape == (2, 77) and toks[0, :3].tolist() == [510, 511, 0]
+    out = emb([""])
+    ref = otext.encode_with_transformer(emb.state_dict(), toks[:1], heads=2, layer_idx=1)
+    assert out.shape == (1, 77, 128)
+    assert record("text_tower", rel_l2(out, ref)) < 3e-3
+    with pytest.raises(NotImplementedError):
+        emb(["a photo"])
