@@ -66,6 +66,9 @@ def parse():
     p.add_argument("--vqgantile_stride", type=int, default=750)
     p.add_argument("--vqgantile_size", type=int, default=960)
     p.add_argument("--guidance_scale", type=float, default=-10.0)
+    p.add_argument("--latent-dir", type=str, default=None,
+                   help="also dump the sampled latents, one <frame>.npy [4,h,w] per frame (what vsr_val_ddpm_text_T_vqganfin_w_latent.py"
+                        ":389-397 writes for the stage-2 VAE-decoder training); frames that fit one patch only")
     return p.parse_args()
 
 
@@ -121,11 +124,16 @@ def main():
                 flows, masks = (f_fwd[None], f_bwd[None]), (fo[None, :, None], bo[None, :, None])
             else:                                      # as the reference: estimate them with RAFT_SR (:392-413)
                 flows, masks = pipe.estimate_flows(seg)
+            latents = []
+
             def one(frames, fl, mk):
                 torch.manual_seed(opt.seed)                      # seed_everything(opt.seed) per (patch of a) segment (:430)
                 h8_, w8_ = frames.shape[-2] // 8, frames.shape[-1] // 8
                 tl = None if (h8_ <= 64 and w8_ <= 64) else (64, opt.tile_overlap)   # one 64x64 tile == plain sampling
-                return pipe.run_segment(frames, flows=fl, masks=mk, guidance_scale=opt.guidance_scale, tile=tl, clamp01=False)
+                out_, lat_ = pipe.run_segment(frames, flows=fl, masks=mk, guidance_scale=opt.guidance_scale, tile=tl, clamp01=False,
+                                              return_latents=True)
+                latents.append(lat_)
+                return out_
 
             if seg.shape[-2] > opt.vqgantile_size or seg.shape[-1] > opt.vqgantile_size:
                 # large frames: overlapping pixel patches through the WHOLE path, uniform-count blending (:418-471)
@@ -151,6 +159,13 @@ def main():
             from PIL import Image
             for k in range(arrs.shape[0]):
                 Image.fromarray(arrs[k]).save(os.path.join(opt.outdir, seq, os.path.basename(paths[s0 + k])))
+            if opt.latent_dir and len(latents) == 1:             # w_latent.py:389-397
+                os.makedirs(os.path.join(opt.latent_dir, seq), exist_ok=True)
+                lat = latents[0].cpu().numpy()
+                for k in range(lat.shape[0]):
+                    base = os.path.splitext(os.path.basename(paths[s0 + k]))[0]
+                    with open(os.path.join(opt.latent_dir, seq, base + ".npy"), "wb") as fh:
+                        np.save(fh, lat[k])
 
 if __name__ == "__main__":
     main()

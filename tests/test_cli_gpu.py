@@ -23,7 +23,8 @@ def test_cli_runs_on_png_sequence(tmp_path):
         Image.fromarray((im * 255).astype(np.uint8)).save(seq / f"{i:03d}.png")
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py"), "--seqs-path",
-           str(tmp_path / "seqs"), "--outdir", str(out), "--ddpm_steps", "2", "--n_frames", "2"]
+           str(tmp_path / "seqs"), "--outdir", str(out), "--ddpm_steps", "2", "--n_frames", "2", "--latent-dir",
+           str(tmp_path / "lat")]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -33,3 +34,5 @@ def test_cli_runs_on_png_sequence(tmp_path):
         im = np.asarray(Image.open(out / "clip0" / f))
         assert im.shape == (560, 736, 3) and im.dtype == np.uint8
         assert im.std() > 1.0                                  # not a constant image
+    lat = np.load(tmp_path / "lat" / "clip0" / "001.npy")
+    assert lat.shape == (4, 576 // 8, 768 // 8) and np.isfinite(lat).all()      # 560 x 736 reflect-padded to 576 x 768 (both sides grow)
