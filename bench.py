@@ -272,6 +272,9 @@ def main():
         "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
                                                           GFLOP_DEC_PER_FRAME) / 1e3 / (dt / args.steps), 1),
     }
+    # whole-segment algorithmic FLOP rate against the dense fp16 MFMA peak of the GPUs in use (the path is compute-bound:
+    # ~55 TFLOP per HR frame against ~0.15 TB of algorithmic HBM traffic)
+    res["sustained_frac_of_mfma_peak"] = round(res["sustained_tflops"] / (PEAK_FP16_TFLOPS * world), 4)
     if rank == 0:
         if not args.no_roofline:
             res["roofline"] = roofline(pipe, args, frames, noise, flows, masks)
