@@ -233,6 +233,11 @@ int mgld_tile_accumulate(const float* tile, const float* wgt, float* acc, float*
 int mgld_tile_normalize(const float* acc, const float* cnt, float* out, int64_t numel, void* stream);
 
 
+/* dst[0:bytes_per_step) = src[step*bytes_per_step : ...) with `step` read from device memory at run time: selects the
+ * current DDPM step's slice of a tensor precomputed for the whole schedule (the struct-cond features, which depend on the
+ * timestep but not on the sample) inside a replayed hipGraph.  bytes_per_step % 16 == 0, 16-byte aligned pointers. */
+int mgld_copy_step(const void* src, void* dst, int64_t bytes_per_step, const int32_t* step_idx, void* stream);
+
 /* ---- K11: pre/post-processing on the device (oldcanvas_tile.py:349-357,384-397,523-543) -----------
  * bicubic resize with torch.nn.functional.interpolate(mode="bicubic", align_corners=False) semantics (A = -0.75, border
  * taps clamped, no antialias), fp32 planes [planes, h, w] -> [planes, oh, ow], result clamped to [lo, hi]

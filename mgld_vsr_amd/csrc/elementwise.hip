@@ -717,6 +717,22 @@ extern "C" int mgld_wavelet_reconstruction(const float* content, const float* st
   return mgld_check_launch("wavelet_reconstruction");
 }
 
+// dst[0 : n16) <- src[step * n16 : (step + 1) * n16)   (16-byte words); `step` is read from device memory so the launch is
+// identical on every replay of a captured step (per-step slices of tensors that were precomputed for the whole schedule)
+__global__ __launch_bounds__(256) void copy_step_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                        const int* __restrict__ step_idx) {
+  const uint4* s = src + (int64_t)step_idx[0] * n16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = s[i];
+}
+
+extern "C" int mgld_copy_step(const void* src, void* dst, int64_t bytes_per_step, const int32_t* step_idx, void* stream) {
+  MGLD_REQUIRE(src && dst && step_idx && bytes_per_step > 0 && (bytes_per_step & 15) == 0, "copy_step: bad args");
+  MGLD_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "copy_step: 16-byte alignment");
+  const int64_t n16 = bytes_per_step >> 4;
+  hipLaunchKernelGGL(copy_step_kernel, dim3(egrid(n16)), dim3(256), 0, S_(stream), (const uint4*)src, (uint4*)dst, n16, step_idx);
+  return mgld_check_launch("copy_step");
+}
+
 // ---- K11: host pre/post-processing moved to the device (oldcanvas_tile.py:349-357, 384-397, 523-543) ---------------
 namespace {
 

@@ -59,7 +59,7 @@ EXPORTS = [
     "mgld_ddpm_step", "mgld_flow_warp", "mgld_guidance", "mgld_guidance_loss", "mgld_step_advance",
     "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
     "mgld_adain", "mgld_wavelet_reconstruction",
-    "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize",
+    "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize", "mgld_copy_step",
     "mgld_resize_bicubic", "mgld_reflect_pad", "mgld_replicate_pad", "mgld_to_uint8_hwc",
     "mgld_avgpool2", "mgld_corr_lookup", "mgld_gru_rh", "mgld_gru_gate", "mgld_flow_update", "mgld_convex_upsample",
     "mgld_add_relu",
@@ -386,6 +386,15 @@ def tile_accumulate(tile, wgt, acc, cnt, y0, x0):
     n, c, H, W = acc.shape
     _chk(lib().mgld_tile_accumulate(_p(tile), _p(wgt), _p(acc), _p(cnt), n, c, H, W, y0, x0, tile.shape[2], tile.shape[3],
                                     stream_ptr()), "tile_accumulate")
+
+
+def copy_step(src_all, dst, step_idx):
+    """dst <- src_all[step_idx[0]] (device-side index); src_all [S, ...], dst shaped like one slice"""
+    _req_cuda(src_all, dst, step_idx)
+    nbytes = dst.numel() * dst.element_size()
+    assert src_all[0].numel() * src_all.element_size() == nbytes and src_all.is_contiguous() and dst.is_contiguous()
+    _chk(lib().mgld_copy_step(_p(src_all), _p(dst), C.c_int64(nbytes), _p(step_idx), stream_ptr()), "copy_step")
+    return dst
 
 
 def tile_normalize(acc, cnt, out):

@@ -676,8 +676,8 @@ class InflatedEncoderUNetModelWT(nn.Module, _TimeEmbedMixin):
         """x: Act [n,h,w,8] -> dict str(width) -> Act [n,r,r,out_channels]."""
         emb = self._time_embedding(eng, tvals)
 
-        def erpf(a):
-            return a.hw if emb_rows is not None else a.rows
+        def erpf(a):   # rows sharing one embedding row: all (None), one frame (1), or emb_rows consecutive frames
+            return a.hw * int(emb_rows) if emb_rows is not None else a.rows
         results = []
         h = x
         for blk in self.input_blocks:
