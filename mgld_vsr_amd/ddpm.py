@@ -12,6 +12,8 @@ noise slice) are read on the device through a step index that the graph itself d
 """
 from contextlib import contextmanager
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -102,7 +104,9 @@ class LatentDiffusionVSRTextWT(nn.Module):
         self.configs = None
         self._engine = None
         self._stream = None
-        self.precompute_structcond = True   # struct-cond features of all steps in batched passes before the loop (see below)
+        # struct-cond features of all steps in batched passes before the loop (see _precompute_structcond); MGLD_SC_PRECOMPUTE=0
+        # keeps the encoder inside every step (rocprofv3 --pmc passes, A/B timing)
+        self.precompute_structcond = os.environ.get("MGLD_SC_PRECOMPUTE", "1") != "0"
         self._graph = None
         self._graph_key = None
         if ckpt_path is not None:

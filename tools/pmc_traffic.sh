@@ -2,6 +2,7 @@
 # trace only) over one eager segment of the default bench workload.  Writes gpurun_out/pmc_traffic.json; copy to profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+export MGLD_SC_PRECOMPUTE=0   # rocprofv3 --pmc segfaults on the batched struct-cond passes; per-launch traffic of the kernel is unaffected
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_$c.log 2>&1
