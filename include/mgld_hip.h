@@ -129,7 +129,11 @@ int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const 
  * y = skip + ((h-mean)*rstd*gamma+beta) * (1+gb[:, 0:C]) + gb[:, C:2C]          */
 int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, const float* gamma, const float* beta,
                      const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
-                     int frames, int rows_per_frame, int C, int groups, void* stream);
+                     int frames, int rows_per_frame, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
+                     void* stream);
+/* gb_step_idx != NULL: `gb` is a table holding the modulation of EVERY schedule step (it depends on the struct-cond features
+ * only, not on the sample); the kernel reads slice gb + gb_step_idx[0]*gb_step_stride (elements), the index living in device
+ * memory so a captured step replays unchanged. */
 /* LayerNorm over C per token (attention.py:125,427-429), eps 1e-5 */
 int mgld_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
                    int rows, int C, float eps, void* stream);

@@ -113,10 +113,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
                                                        int chunks, float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const f16* __restrict__ gb, int ldgb,
                                                        const f16* __restrict__ skip, int ldskip, f16* __restrict__ y, int ldy,
-                                                       int rows_per_frame, int C, int groups, int silu, int Cb) {
+                                                       int rows_per_frame, int C, int groups, int silu, int Cb,
+                                                       const int* __restrict__ step_idx, int64_t gb_step_stride) {
   // grid (row chunks, frames).  A thread owns ONE 8-channel vector column for all its rows, so the per-channel scale /
   // shift (rstd*gamma, beta - mean*rstd*gamma) are computed once into registers and the row loop is load-fma-store.
   __shared__ float st[GN_MAX_GROUPS][2];
+  if (SPADE && step_idx) gb += (int64_t)step_idx[0] * gb_step_stride;   // gamma/beta table hoisted out of the step (see ddpm.py)
   const int c_off = blockIdx.z * Cb;            // this block's channel window [c_off, c_off + Cb)
   const int NV = min(Cb, C - c_off) >> 3;
   const int cg = C / groups;
@@ -282,13 +284,15 @@ extern "C" int mgld_gn_apply(const void* x, int ldx, const double* gsums, float 
   int Cb;
   const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
   hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, gsums,
-                     mgld_gn_chunks(rows), eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb);
+                     mgld_gn_chunks(rows), eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb,
+                     nullptr, (int64_t)0);
   return mgld_check_launch("gn_apply");
 }
 
 extern "C" int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, const float* gamma,
                                 const float* beta, const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
-                                int frames, int rows, int C, int groups, void* stream) {
+                                int frames, int rows, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
+                                void* stream) {
   MGLD_REQUIRE(h && gsums && gamma && beta && gb && skip && y, "spade_apply: null pointer");
   MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0 &&
                    groups <= GN_MAX_GROUPS,
@@ -297,7 +301,7 @@ extern "C" int mgld_spade_apply(const void* h, int ldh, const double* gsums, flo
   const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
   hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)h, ldh, gsums,
                      mgld_gn_chunks(rows), eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy,
-                     rows, C, groups, 0, Cb);
+                     rows, C, groups, 0, Cb, gb_step_idx, gb_step_stride);
   return mgld_check_launch("spade_apply");
 }
 

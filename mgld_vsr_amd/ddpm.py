@@ -322,10 +322,50 @@ class LatentDiffusionVSRTextWT(nn.Module):
         st["sc_step"] = {key: (torch.empty_like(t[0]), dims[key]) for key, t in tables.items()}
         st["sc_frames"] = n
 
+    SPADE_TABLE_BUDGET = 16 << 30   # bytes of HBM the hoisted SPADE gamma/beta tables may take (288 GB per GPU)
+
+    def _precompute_spade(self, eng, st, S):
+        """The SPADE modulation of a ResBlockDual, [gamma|beta] = conv(relu(conv(struct_cond))) (spade.py:93-104,
+        openaimodel.py:481-482), depends on the struct-cond features only — like them it is known for every step before
+        sampling.  For the low-resolution blocks (<= 32x32 latents, where the in-step convolutions are small and
+        latency-bound) it is evaluated here in batched passes into per-block tables [S, frames*h*w, 2C]; the step's
+        spade_apply then indexes the table by the device-side step counter.  Called after the first (eager) step, which
+        records the struct-cond scale each block reads.  Tables are taken smallest-resolution first within the budget."""
+        from .unet import ResBlockDual
+        if "sc_tables" not in st:
+            return
+        n = st["sc_frames"]
+        blocks = [m for m in self.model.diffusion_model.modules() if isinstance(m, ResBlockDual) and getattr(m, "_sc_key", None)]
+        cand = []
+        for blk in blocks:
+            fh, fw = st["sc_step"][blk._sc_key][1]
+            if fh * fw <= 1024:
+                cand.append((fh * fw, blk))
+        cand.sort(key=lambda t: t[0])
+        tables, used = {}, 0
+        for hw, blk in cand:
+            nbytes = S * n * hw * 2 * blk.out_channels * 2
+            if used + nbytes > self.SPADE_TABLE_BUDGET:
+                break
+            used += nbytes
+            tables[id(blk)] = (blk, torch.empty((S, n * hw, 2 * blk.out_channels), dtype=torch.float16, device=eng.device))
+        if not tables:
+            return
+        for c0 in range(0, S, self.STRUCTCOND_CHUNK):
+            k = min(self.STRUCTCOND_CHUNK, S - c0)
+            eng.reset()
+            for blk, tab in tables.values():
+                src = st["sc_tables"][blk._sc_key]
+                fh, fw = st["sc_step"][blk._sc_key][1]
+                seg = Act(src[c0:c0 + k].view(k * n * fh * fw, src.shape[2]), k * n, fh, fw)
+                gb = blk.spade_modulation(eng, seg)
+                hip.copy2d(gb.v, tab[c0:c0 + k].view(gb.rows, gb.C))
+        st["spade"] = {key: (tab, tab.shape[1] * tab.shape[2], st["step_idx"]) for key, (blk, tab) in tables.items()}
+
     def _structcond_of_step(self, eng, st, lat_act):
         if "sc_tables" not in st:
             return self.structcond_stage_model.run(eng, lat_act, st["tvals"], None)
-        out = {}
+        out = {"__spade__": st["spade"]} if "spade" in st else {}
         for key, tab in st["sc_tables"].items():
             buf, (fh, fw) = st["sc_step"][key]
             hip.copy_step(tab, buf, st["step_idx"])
@@ -445,6 +485,8 @@ class LatentDiffusionVSRTextWT(nn.Module):
             intermediates = [x.clone()]
             graph = None
             for k, i in enumerate(reversed(range(S))):
+                if k == 1 and self.precompute_structcond and S > 1 and os.environ.get("MGLD_SPADE_PRECOMPUTE", "1") != "0":
+                    self._precompute_spade(eng, st, S)          # after the eager first step (it records the block scales)
                 if k == 0 or not use_graph:
                     self._step_body(eng, st)
                 else:

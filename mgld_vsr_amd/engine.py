@@ -280,11 +280,12 @@ class Engine:
     def groupnorm(self, x, gamma, beta, eps, silu, out=None):
         return self.gn_apply(x, self.gn_stats(x, eps), gamma, beta, silu, out)
 
-    def spade_apply(self, h, stats, gamma, beta, gb, skip, out=None):
+    def spade_apply(self, h, stats, gamma, beta, gb, skip, out=None, step_idx=None, step_stride=0):
         if out is None:
             out = self.act(h.n, h.h, h.w, h.C)
         gsums, eps = stats
-        hip.spade_apply(h.v, gsums, eps, gamma, beta, gb.v, skip.v, out.v, h.n, h.hw, self.GROUPS)
+        hip.spade_apply(h.v, gsums, eps, gamma, beta, gb.v if isinstance(gb, Act) else gb, skip.v, out.v, h.n, h.hw, self.GROUPS,
+                        step_idx, step_stride)
         self.launches += 1
         return out
 

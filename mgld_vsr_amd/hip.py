@@ -203,10 +203,13 @@ def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu):
     return y
 
 
-def spade_apply(h, gsums, eps, gamma, beta, gb, skip, y, frames, rows, groups):
+def spade_apply(h, gsums, eps, gamma, beta, gb, skip, y, frames, rows, groups, step_idx=None, step_stride=0):
+    """gb: [frames*rows, 2C] modulation, or (step_idx given) the first slice of a per-step table with `step_stride` elements
+    between consecutive steps"""
     _req_cuda(h, gsums, gamma, beta, gb, skip, y)
     _chk(lib().mgld_spade_apply(_p(h), _ld(h), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip),
-                                _ld(skip), _p(y), _ld(y), frames, rows, h.shape[1], groups, stream_ptr()), "spade_apply")
+                                _ld(skip), _p(y), _ld(y), frames, rows, h.shape[1], groups, _p(step_idx), C.c_int64(step_stride),
+                                stream_ptr()), "spade_apply")
     return y
 
 

@@ -133,16 +133,25 @@ class ResBlockDual(ResBlock):
         conv2 = self.out_layers[3]
         h = eng.conv3x3(t, eng.weight("c3", (conv2.weight,), pack_conv3x3), eng.f32("b", conv2.bias), self.out_channels)
         sp = self.spade
-        seg = struct_cond[str(h.w)]
+        self._sc_key = str(h.w)                      # which struct-cond scale this block reads (recorded for the hoisting pass)
+        stats = eng.gn_stats(h, sp.param_free_norm.eps)
+        skip = self._skip(eng, x)
+        g, b = eng.f32("g", sp.param_free_norm.weight), eng.f32("b", sp.param_free_norm.bias)
+        hoisted = struct_cond.get("__spade__", {}).get(id(self)) if isinstance(struct_cond, dict) else None
+        if hoisted is not None:                       # gamma/beta of every step precomputed (ddpm._precompute_spade)
+            table, stride, step_idx = hoisted
+            return eng.spade_apply(h, stats, g, b, table[0], skip, out=out, step_idx=step_idx, step_stride=stride)
+        gb = self.spade_modulation(eng, struct_cond[self._sc_key])
+        return eng.spade_apply(h, stats, g, b, gb, skip, out=out)
+
+    def spade_modulation(self, eng, seg):
+        """[gamma | beta] = conv(relu(conv(seg))) (spade.py:93-104): a function of the struct-cond features only"""
+        sp = self.spade
         actv = eng.conv3x3(seg, eng.weight("c3", (sp.mlp_shared[0].weight,), pack_conv3x3), eng.f32("b", sp.mlp_shared[0].bias),
                            128, act=hip.ACT_RELU)
         wgb = eng.weight("c3gb", (sp.mlp_gamma.weight, sp.mlp_beta.weight), lambda g, b: pack_conv3x3(torch.cat([g, b], 0)))
         bgb = eng.weight("bgb", (sp.mlp_gamma.bias, sp.mlp_beta.bias), lambda g, b: torch.cat([g, b], 0), torch.float32)
-        gb = eng.conv3x3(actv, wgb, bgb, 2 * self.out_channels)
-        stats = eng.gn_stats(h, sp.param_free_norm.eps)
-        skip = self._skip(eng, x)
-        return eng.spade_apply(h, stats, eng.f32("g", sp.param_free_norm.weight), eng.f32("b", sp.param_free_norm.bias), gb,
-                               skip, out=out)
+        return eng.conv3x3(actv, wgb, bgb, 2 * self.out_channels)
 
 
 class QKVAttentionLegacy(nn.Module):
