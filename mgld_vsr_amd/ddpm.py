@@ -296,6 +296,10 @@ class LatentDiffusionVSRTextWT(nn.Module):
     # ---- struct-cond features: a function of (LR latent, timestep) only, NOT of the sample ---------------------------
     STRUCTCOND_CHUNK = 10   # schedule steps evaluated per batched encoder pass (one time-embedding row each; <= 16)
 
+    def _sc_chunk(self, n_frames):
+        """schedule steps per batched pass: at most STRUCTCOND_CHUNK and about 96 frames (bounds the arena of a pass)"""
+        return max(1, min(self.STRUCTCOND_CHUNK, 96 // max(1, n_frames)))
+
     def _precompute_structcond(self, eng, st, lat_act, S):
         """The reference evaluates structcond_stage_model(lat, t) inside every step (ddpm.py:4344-4350); its inputs are
         the constant LR latent and the step's timestep, so all S evaluations are known before sampling starts.  They are
@@ -305,8 +309,9 @@ class LatentDiffusionVSRTextWT(nn.Module):
         sc_net = self.structcond_stage_model
         n, rows = lat_act.n, lat_act.rows
         tables, dims = {}, {}
-        for c0 in range(0, S, self.STRUCTCOND_CHUNK):
-            k = min(self.STRUCTCOND_CHUNK, S - c0)
+        chunk = self._sc_chunk(n)
+        for c0 in range(0, S, chunk):
+            k = min(chunk, S - c0)
             eng.reset()
             tv = st["coef"][c0:c0 + k, 6].contiguous()                      # network timesteps of schedule indices c0..c0+k-1
             x = eng.arena.alloc((k * rows, lat_act.C), torch.float16)
@@ -351,8 +356,9 @@ class LatentDiffusionVSRTextWT(nn.Module):
             tables[id(blk)] = (blk, torch.empty((S, n * hw, 2 * blk.out_channels), dtype=torch.float16, device=eng.device))
         if not tables:
             return
-        for c0 in range(0, S, self.STRUCTCOND_CHUNK):
-            k = min(self.STRUCTCOND_CHUNK, S - c0)
+        chunk = self._sc_chunk(n)
+        for c0 in range(0, S, chunk):
+            k = min(chunk, S - c0)
             eng.reset()
             for blk, tab in tables.values():
                 src = st["sc_tables"][blk._sc_key]
