@@ -227,7 +227,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
   }
 }
 
-inline int rows_per_chunk_for(int rows) { return rows <= 64 ? rows : (cdiv(rows, 256) > 64 ? cdiv(rows, 256) : 64); }
+// rows per stats chunk.  Every apply block re-reads chunks x groups x 16 B of sums, so few chunks for the (many) latent-size
+// tensors: <= 16 chunks up to 4096 rows; the big VAE planes keep 256 chunks (their stats kernel needs the row parallelism).
+inline int rows_per_chunk_for(int rows) {
+  if (rows <= 64) return rows;
+  if (rows <= 4096) return cdiv(rows, 16) > 64 ? cdiv(rows, 16) : 64;
+  return cdiv(rows, 256) > 64 ? cdiv(rows, 256) : 64;
+}
 
 }  // namespace
 
