@@ -197,6 +197,9 @@ class RAFT_SR(nn.Module):
             ref, sup = hip.replicate_pad(ref, pad), hip.replicate_pad(sup, pad)
         H, W = ref.shape[-2:]
         H8, W8 = H // 8, W // 8
+        if min(H8, W8) < 2 ** (self.corr_levels - 1):
+            # the reference fails here too (F.avg_pool2d: "Output size is too small" while building the 4-level pyramid)
+            raise ValueError(f"RAFT needs frames of at least {8 * 2 ** (self.corr_levels - 1)} px per side, got {ht}x{wd}")
         hw, M = H8 * W8, N * H8 * W8
 
         # feature / context encoders
