@@ -385,7 +385,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   // per output row, residual rows read the same way.  (Wave-local: no block barrier except the one releasing the stages.)
   __syncthreads();
   if constexpr (ABL & 512) return;  // ablation build (timing only): no epilogue
-  const bool geglu = (!splitk) && (p.act == MGLD_ACT_GEGLU);
+  static_assert(WN == 64 || WN == 32, "wave tile width");
+  const bool geglu = (WN == 64) && (!splitk) && (p.act == MGLD_ACT_GEGLU);   // value/gate pairing needs 64-column wave tiles
   constexpr int LDW = WN + 4;                       // patch row stride (floats): 16-B aligned, conflict-free b128
   float* patch = (float*)smem + wave * (32 * LDW);
   const int Nout = splitk ? N : (geglu ? N / 2 : N);
@@ -682,7 +683,12 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   int cfg, splits, kchunk;
   choose(p, &cfg, &splits, &kchunk);
   switch (cfg) {
-    case 128128: return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
+    // 128x128: eight waves of 64x32 (two blocks = 16 waves per CU) measured ~3 % faster end to end than four of 64x64:
+    // more waves in flight to cover the barrier / DMA waits outweigh the 1.5x fragment loads per MFMA
+    // (GEGLU pairs value / gate columns inside one wave's 64-column tile and keeps the 4-wave form.)
+    case 128128:
+      if (p->act == MGLD_ACT_GEGLU) return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
+      return launch_cfg<128, 128, 64, 32>(p, s, splits, kchunk);
     case 64128: return launch_cfg<64, 128, 32, 64>(p, s, 1, kchunk);
     case 128032: return launch_cfg<128, 32, 32, 32>(p, s, 1, kchunk);
     case 128064: return launch_cfg<128, 64, 64, 32>(p, s, 1, kchunk);

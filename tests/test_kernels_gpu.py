@@ -34,7 +34,7 @@ def h16(t):
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (100, 72, 40), (4096, 1280, 320), (512, 1280, 1280),
                                    (77, 640, 1024), (33, 4, 320), (300, 32, 544), (64, 64, 8), (8192, 640, 2560),
-                                   (16384, 320, 640)])
+                                   (16384, 320, 640), (16384, 1280, 320)])   # the last: >= 384 tiles -> 128x128, 8 waves
 def test_igemm_linear(hip, M, N, K):
     a, w, b = h16(rnd(M, K, seed=1)), h16(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
     ref = a.float() @ w.float().t() + b
@@ -117,6 +117,23 @@ def test_igemm_strided_epilogues(hip):
     assert rel_l2(o32.cpu(), F.relu(a.cpu().float() @ w.cpu().float().t())) < 1e-5
 
 
+def test_igemm_epilogues_large_tiles(hip):
+    """the fused epilogue (per-row bias, residual with alpha/beta, SiLU, per-frame rowvec) on the 128x128 tile configuration
+    (>= 384 tiles), which the small cases above never select"""
+    M, N, K, rpf = 32768, 256, 128, 4096
+    a = h16(rnd(M, K, seed=40)).to(DEV)
+    w = h16(rnd(N, K, seed=41, scale=K ** -0.5)).to(DEV)
+    r = h16(rnd(M, N, seed=42)).to(DEV)
+    b, rv = rnd(N, seed=43).to(DEV), rnd(M // rpf, N, seed=44).to(DEV)
+    out = torch.empty(M, N, dtype=torch.half, device=DEV)
+    hip.igemm(a, w, out, bias=b, rowvec=rv, rows_per_frame=rpf, resid=r, act=hip.ACT_SILU, alpha=0.6, beta=1.4)
+    p = hip.MgldIGemm()
+    p.M, p.N, p.K, p.batch = M, N, K, 1
+    assert hip.igemm_config(p) == 128128
+    ref = 0.6 * F.silu(a.cpu().float() @ w.cpu().float().t() + b.cpu() + rv.cpu().repeat_interleave(rpf, 0)) + 1.4 * r.cpu().float()
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+
+
 def test_igemm_batched_nt(hip):
     # V^T projection: per-frame out[C, tokens] = Wv[C, Cin] @ x_f[tokens, Cin]^T  (A shared, W strided)
     Fr, tokens, Cin, Cc = 3, 200, 64, 128
@@ -129,8 +146,8 @@ def test_igemm_batched_nt(hip):
     assert rel_l2(out.cpu().float().reshape(Fr, Cc, tp)[:, :, :tokens], ref) < 1e-3
 
 
-def test_igemm_geglu(hip):
-    M, dim, inner = 300, 64, 256
+@pytest.mark.parametrize("M,dim,inner", [(300, 64, 256), (4096, 128, 512), (32768, 320, 1280)])   # 64x128 and 128x128 tile paths
+def test_igemm_geglu(hip, M, dim, inner):
     a = h16(rnd(M, dim, seed=10)).to(DEV)
     w = h16(rnd(2 * inner, dim, seed=11, scale=dim ** -0.5))
     b = rnd(2 * inner, seed=12)
@@ -182,7 +199,8 @@ def test_igemm_conv3x3(hip, n, cin, cout, h, w, stride, pads, up2):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,stride", [(2, 128, 96, 16, 16, 1), (1, 320, 320, 24, 16, 1), (2, 64, 64, 16, 16, 2),
-                                                   (8, 1280, 256, 8, 8, 1)])
+                                                   (8, 1280, 256, 8, 8, 1),
+                                                   (4, 320, 640, 64, 64, 1)])   # 640 tiles: the 128x128 DMA-path config
 def test_igemm_conv3x3_tap_inner(hip, n, cin, cout, h, w, stride):
     """(64-channel block, tap, channel) K order — the layout the engine packs whenever Cin % 64 == 0"""
     from mgld_vsr_amd.engine import pack_conv3x3
