@@ -607,7 +607,7 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   if (t128 >= 384) { *cfg = 128128; return; }
   // too few 128x128 tiles for 256 CUs.  Between 1 and 1.5 tiles per CU (e.g. M = 8192, N = 640) half-size tiles balance
   // the CUs exactly as well as a 2-way K split (3 rounds of half the work) and need no reduce pass.
-  if (t128 >= 256) { *cfg = 64128; return; }
+  if (t128 >= 256) { *cfg = (t128 % num_cus() == 0) ? 128128 : 64128; return; }   // exactly one tile per CU: keep the big tile
   // Fewer 128x128 tiles than CUs: pick (tile, K split) by a small cost model calibrated on MI355X (us):
   //   throughput term  rounds over 256 CUs x tile area x k-steps per block x 0.7 us (0.9 us when a CU holds a single block),
   //   latency term     k-steps per block x 0.55 us (one block cannot go faster however small its tile),
