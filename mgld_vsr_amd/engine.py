@@ -186,6 +186,13 @@ class Engine:
         self._wcache[key] = dev
         return dev
 
+    def const(self, key, fn):
+        """device constant built once per engine (e.g. identity affine vectors): fn() -> tensor or tuple of tensors"""
+        hit = self._wcache.get(("const", key))
+        if hit is None:
+            hit = self._wcache[("const", key)] = fn()
+        return hit
+
     def f32(self, tag, p):
         return self.weight(tag, (p,), lambda t: t, torch.float32)
 

@@ -8,7 +8,7 @@ import copy
 import numpy as np
 import torch
 
-from . import hip, synth
+from . import synth
 from .ddpm import space_timesteps
 from .flowops import adaptive_instance_normalization, wavelet_reconstruction
 from .util import instantiate_from_config

@@ -103,12 +103,7 @@ class BasicEncoder(nn.Module):
 
 
 def _affine_identity(eng, C):
-    key = ("in_affine", C)
-    hit = eng._wcache.get(key)
-    if hit is None:
-        hit = (torch.ones(C, device=eng.device), torch.zeros(C, device=eng.device))
-        eng._wcache[key] = hit
-    return hit
+    return eng.const(("in_affine", C), lambda: (torch.ones(C, device=eng.device), torch.zeros(C, device=eng.device)))
 
 
 class BasicMotionEncoder(nn.Module):

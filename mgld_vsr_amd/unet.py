@@ -12,7 +12,6 @@ token-major (NHWC) fp16 activations:
   * all 22+ emb_layers projections are ONE weight-streaming GEMV per step (they share SiLU(emb));
   * cross-attention K / V^T of the (constant) text context are computed once and cached.
 """
-import math
 
 import torch
 import torch.nn as nn

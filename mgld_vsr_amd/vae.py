@@ -10,12 +10,11 @@ MI355X notes: every 3x3 conv is the MFMA implicit GEMM on NHWC; the dense block'
 growing buffer; the asymmetric (0,1,0,1) pad of the encoder downsample and the nearest-2x upsample are folded into
 the conv gather; the single-head d=512 mid attention runs as two batched GEMMs around an fp32 row softmax.
 """
-import numpy as np
 import torch
 import torch.nn as nn
 
 from . import hip
-from .engine import Act, Engine, pack_conv1x1, pack_conv3x3, pack_tconv3
+from .engine import Act, Engine, pack_conv1x1, pack_conv3x3
 from .unet import SpatialTemporalConv, _meta_module
 
 

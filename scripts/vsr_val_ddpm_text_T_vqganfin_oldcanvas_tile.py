@@ -14,13 +14,11 @@ Differences that are deliberate (SURVEY.md §3.1 "known defects", §8(f)):
 """
 import argparse
 import glob
-import math
 import os
 import sys
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
