@@ -201,3 +201,75 @@ def test_image_spliter_device_matches_host(hip):
         host.update(res, ih)
         dev.update(res.cuda(), idd)
     assert torch.allclose(dev.gather().cpu(), host.gather(), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# direct checks of the smaller C-ABI entry points added for RAFT / the text tower / the hoisted tables
+# ------------------------------------------------------------------------------------------------------------------
+def test_copy_step_selects_slice(hip):
+    tab = torch.randn(7, 33, 16, generator=torch.Generator().manual_seed(1)).half().cuda()
+    dst = torch.empty(33, 16, dtype=torch.half, device="cuda")
+    for i in (0, 3, 6):
+        hip.copy_step(tab, dst, torch.tensor([i], dtype=torch.int32, device="cuda"))
+        assert torch.equal(dst, tab[i])
+
+
+def test_replicate_pad_and_avgpool(hip):
+    x = torch.randn(2, 3, 13, 17, generator=torch.Generator().manual_seed(2))
+    pad = (2, 1, 0, 3)
+    assert torch.equal(hip.replicate_pad(x.cuda(), pad).cpu(), F.pad(x, pad, mode="replicate"))
+    p = torch.randn(10, 9, 14, generator=torch.Generator().manual_seed(3))
+    assert torch.allclose(hip.avgpool2(p.cuda()).cpu(), F.avg_pool2d(p[:, None], 2, stride=2)[:, 0], atol=1e-6)
+
+
+def test_softmax_rows_masked(hip):
+    L, Lp, H = 77, 80, 3
+    S = torch.randn(H * L, L, generator=torch.Generator().manual_seed(4)) * 3
+    P = torch.full((H * L, Lp), 7.0, dtype=torch.half, device="cuda")
+    hip.softmax_rows_masked(S.cuda(), P, H * L, L, Lp, L)
+    mask = torch.full((L, L), float("-inf")).triu_(1)
+    ref = torch.softmax(S.view(H, L, L) + mask, dim=-1).view(H * L, L)
+    assert float((P[:, :L].cpu().float() - ref).abs().max()) < 1e-3
+    assert float(P[:, L:].abs().max()) == 0.0                      # K padding columns are zero-filled
+
+
+def test_corr_lookup_and_convex_upsample_vs_oracle(hip):
+    from oracle import raft as oraft
+    g = torch.Generator().manual_seed(5)
+    B, D, H, W = 2, 32, 16, 20
+    f1, f2 = torch.randn(B, D, H, W, generator=g), torch.randn(B, D, H, W, generator=g)
+    cb = oraft.CorrBlock(f1, f2, num_levels=4, radius=4)
+    coords = oraft.coords_grid(B, H, W) + torch.randn(B, 2, H, W, generator=g) * 2.5
+    ref = cb(coords)                                                                  # [B, 324, H, W]
+    levels = [p[:, 0].contiguous().cuda() for p in cb.pyramid]                        # [B*H*W, h_l, w_l]
+    out = torch.zeros(B * H * W, 328, dtype=torch.half, device="cuda")
+    hip.corr_lookup(levels, coords.cuda().contiguous(), 4, out)
+    got = out[:, :324].float().cpu().view(B, H, W, 324).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 1e-3                                                    # fp16 storage of the looked-up values
+    flow = torch.randn(B, 2, H, W, generator=g)
+    mask = torch.randn(B, 576, H, W, generator=g)
+    up = hip.convex_upsample(flow.cuda().contiguous(), mask.permute(0, 2, 3, 1).reshape(B * H * W, 576).half().cuda().contiguous())
+    assert rel_l2(up.cpu(), oraft.upsample_flow(flow, mask.half().float())) < 1e-5
+
+
+def test_gru_and_flow_update_kernels(hip):
+    g = torch.Generator().manual_seed(6)
+    M, Ch, Cx = 300, 128, 256
+    hx = torch.randn(M, Ch + Cx, generator=g).half().cuda()
+    r, z, q = (torch.rand(M, Ch, generator=g).half().cuda() for _ in range(3))
+    rhx = torch.empty_like(hx)
+    hip.gru_rh(r, hx, rhx, Ch)
+    assert torch.allclose(rhx[:, :Ch].float(), (r.float() * hx[:, :Ch].float()), atol=2e-3) and torch.equal(rhx[:, Ch:], hx[:, Ch:])
+    h0 = hx[:, :Ch].float().clone()
+    hip.gru_gate(z, q, hx[:, :Ch])
+    assert torch.allclose(hx[:, :Ch].float(), (1 - z.float()) * h0 + z.float() * q.float(), atol=2e-3)
+    B, H, W = 2, 5, 6
+    c0 = torch.randn(B, 2, H, W, generator=g).cuda()
+    c1 = c0 + 1.0
+    d = torch.randn(B * H * W, 8, generator=g).cuda()
+    flow = torch.empty_like(c0)
+    mot = torch.zeros(B * H * W, 8, dtype=torch.half, device="cuda")
+    c1_ref = c1 + d[:, :2].reshape(B, H, W, 2).permute(0, 3, 1, 2)
+    hip.flow_update(c1, c0, d[:, :2], flow, mot=mot[:, 6:8])
+    assert torch.allclose(c1, c1_ref) and torch.allclose(flow, c1_ref - c0)
+    assert torch.allclose(mot[:, 6:8].float(), flow.permute(0, 2, 3, 1).reshape(-1, 2), atol=5e-3)
