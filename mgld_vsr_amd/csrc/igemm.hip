@@ -27,7 +27,7 @@
 namespace {
 
 #ifndef MGLD_IGEMM_ABLATE
-#define MGLD_IGEMM_ABLATE 0   // timing-only ablation builds: 16 no W traffic, 32 no MFMA, 128 no compute, 256 no DMA, 512 no epilogue
+#define MGLD_IGEMM_ABLATE 0   // timing-only ablation builds: 8 no A traffic (conv), 16 no W traffic, 32 no MFMA, 128 no compute, 256 no DMA, 512 no epilogue
 #endif
 constexpr int ABL = MGLD_IGEMM_ABLATE;
 
@@ -62,6 +62,126 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == MGLD_ACT_TANH) return tanhf(x);
   if (act == MGLD_ACT_GELU) return gelu_f(x);
   return x;
+}
+
+// ---- shared tile epilogue (used by igemm_kernel and conv3p_kernel) ---------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restrict__ ws, const bool splitk, const int kz, const int bz,
+                                              const int bm0, const int bn0, const int wm, const int wn, const int wave,
+                                              const int lane, f32x16 (&acc)[WN / 32][WM / 32], char* smem) {
+  constexpr int MI = WM / 32, NI = WN / 32;
+  const int M = p.M, N = p.N;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // D[i = n_local][j = m_local]: a lane holds ONE output row (m = lane&31) and 4-channel groups of it, i.e. the natural
+  // store would be 8-byte pieces scattered over 32 rows.  Instead every wave transposes its 32-row slices through its own
+  // LDS patch (fp32, bias/activation already applied) and writes whole row segments: 8 lanes x 16 B = 128 B contiguous
+  // per output row, residual rows read the same way.  (Wave-local: no block barrier except the one releasing the stages.)
+  __syncthreads();
+  if constexpr (ABL & 512) return;  // ablation build (timing only): no epilogue
+  static_assert(WN == 64 || WN == 32, "wave tile width");
+  const bool geglu = (WN == 64) && (!splitk) && (p.act == MGLD_ACT_GEGLU);   // value/gate pairing needs 64-column wave tiles
+  constexpr int LDW = WN + 4;                       // patch row stride (floats): 16-B aligned, conflict-free b128
+  float* patch = (float*)smem + wave * (32 * LDW);
+  const int Nout = splitk ? N : (geglu ? N / 2 : N);
+  const int wcols = geglu ? WN / 2 : WN;            // output columns this wave produces
+  const int ncol0 = geglu ? (bn0 + wn * WN) / 2 : bn0 + wn * WN;
+  const int64_t cbase = splitk ? (int64_t)kz * M * N : (int64_t)bz * p.strideC;
+  const int ldo = splitk ? N : p.ldc;
+  const bool of32 = splitk || p.out_f32;
+  const f16* __restrict__ R = (!splitk && p.R) ? (const f16*)p.R + (int64_t)bz * p.strideR : nullptr;
+  const int act = splitk ? MGLD_ACT_NONE : p.act;
+  const float alpha = splitk ? 1.f : p.alpha;
+  char* outp = splitk ? (char*)ws : (char*)p.C;
+  const int lpr = wcols >> 3;                       // lanes per output row (8 columns each)
+  const int rpi = 64 / lpr;                         // rows per wave pass
+  const int prow = lane / lpr, pcv = (lane - prow * lpr) * 8;
+  const int n = ncol0 + pcv;                        // this lane's 8 output columns [n, n+8)
+  const bool full = (n + 8 <= Nout);
+  // per-lane column constants (same for every row): bias of the 8 columns (value and gate halves for GEGLU)
+  float bcol[8], bgate[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bcol[j] = 0.f; bgate[j] = 0.f; }
+  if (!splitk && p.bias) {
+    const int nb = geglu ? bn0 + wn * WN + pcv : n;   // packed row index of the value half
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (nb + j < N) bcol[j] = p.bias[nb + j];
+      if (geglu && nb + 32 + j < N) bgate[j] = p.bias[nb + 32 + j];
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    // ---- phase 1: raw accumulators -> patch[row = l31][col] ----
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        *(f32x4*)(patch + l31 * LDW + ni * 32 + rg * 8 + lhi * 4) =
+            f32x4{acc[ni][mi][rg * 4], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+    // ---- phase 2: patch rows -> epilogue math -> global, 8 columns (16 B of fp16 / 32 B of fp32) per lane ----
+    for (int r0 = 0; r0 < 32; r0 += rpi) {
+      const int row = r0 + prow;
+      const int m = bm0 + wm * WM + mi * 32 + row;
+      if (row < 32 && m < M && n < Nout) {
+        const f32x4 a0 = *(const f32x4*)(patch + row * LDW + pcv);
+        const f32x4 a1 = *(const f32x4*)(patch + row * LDW + pcv + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (geglu) {
+          const f32x4 g0 = *(const f32x4*)(patch + row * LDW + 32 + pcv);
+          const f32x4 g1 = *(const f32x4*)(patch + row * LDW + 32 + pcv + 4);
+          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (v[j] + bcol[j]) * gelu_f(g[j] + bgate[j]) * alpha;
+        } else if (!splitk) {
+          const float bm = p.bias_m ? p.bias_m[m] : 0.f;
+          float rvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (p.rowvec) {
+            const float* rv = p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec + n;
+            if (full && ((((uintptr_t)rv) & 15) == 0)) {
+              const f32x4 r0v = *(const f32x4*)rv, r1v = *(const f32x4*)(rv + 4);
+              rvv[0] = r0v[0]; rvv[1] = r0v[1]; rvv[2] = r0v[2]; rvv[3] = r0v[3];
+              rvv[4] = r1v[0]; rvv[5] = r1v[1]; rvv[6] = r1v[2]; rvv[7] = r1v[3];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) if (n + j < Nout) rvv[j] = rv[j];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bm + bcol[j] + rvv[j], act) * alpha;
+        }
+        if (R) {
+          const f16* rp = R + (int64_t)m * p.ldr + n;
+          if (full && ((((uintptr_t)rp) & 15) == 0)) {
+            const f16x8 rr = *(const f16x8*)rp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += p.beta * (float)rr[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * (float)rp[j];
+          }
+        }
+        if (of32) {
+          float* cp = (float*)outp + cbase + (int64_t)m * ldo + n;
+          if (full && ((((uintptr_t)cp) & 15) == 0)) {
+            *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = v[j];
+          }
+        } else {
+          f16* cp = (f16*)outp + cbase + (int64_t)m * ldo + n;
+          if (full && ((((uintptr_t)cp) & 15) == 0)) {
+            *(f16x8*)cp = f16x8{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j];
+          }
+        }
+      }
+    }
+  }
+
 }
 
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
@@ -231,6 +351,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
         const unsigned tbit = 1u << u_tap;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
+          if constexpr (ABL & 8) continue;   // (ablation build bit 8: skip the activation-tile traffic)
           const char* src = (fa_mask[j] & tbit) ? fa_ptr[j] + soff : zero;
           glds16(src, sbase + j * (NW * 1024));
         }
@@ -378,116 +499,185 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     }
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------------------
-  // D[i = n_local][j = m_local]: a lane holds ONE output row (m = lane&31) and 4-channel groups of it, i.e. the natural
-  // store would be 8-byte pieces scattered over 32 rows.  Instead every wave transposes its 32-row slices through its own
-  // LDS patch (fp32, bias/activation already applied) and writes whole row segments: 8 lanes x 16 B = 128 B contiguous
-  // per output row, residual rows read the same way.  (Wave-local: no block barrier except the one releasing the stages.)
-  __syncthreads();
-  if constexpr (ABL & 512) return;  // ablation build (timing only): no epilogue
-  static_assert(WN == 64 || WN == 32, "wave tile width");
-  const bool geglu = (WN == 64) && (!splitk) && (p.act == MGLD_ACT_GEGLU);   // value/gate pairing needs 64-column wave tiles
-  constexpr int LDW = WN + 4;                       // patch row stride (floats): 16-B aligned, conflict-free b128
-  float* patch = (float*)smem + wave * (32 * LDW);
-  const int Nout = splitk ? N : (geglu ? N / 2 : N);
-  const int wcols = geglu ? WN / 2 : WN;            // output columns this wave produces
-  const int ncol0 = geglu ? (bn0 + wn * WN) / 2 : bn0 + wn * WN;
-  const int64_t cbase = splitk ? (int64_t)kz * M * N : (int64_t)bz * p.strideC;
-  const int ldo = splitk ? N : p.ldc;
-  const bool of32 = splitk || p.out_f32;
-  const f16* __restrict__ R = (!splitk && p.R) ? (const f16*)p.R + (int64_t)bz * p.strideR : nullptr;
-  const int act = splitk ? MGLD_ACT_NONE : p.act;
-  const float alpha = splitk ? 1.f : p.alpha;
-  char* outp = splitk ? (char*)ws : (char*)p.C;
-  const int lpr = wcols >> 3;                       // lanes per output row (8 columns each)
-  const int rpi = 64 / lpr;                         // rows per wave pass
-  const int prow = lane / lpr, pcv = (lane - prow * lpr) * 8;
-  const int n = ncol0 + pcv;                        // this lane's 8 output columns [n, n+8)
-  const bool full = (n + 8 <= Nout);
-  // per-lane column constants (same for every row): bias of the 8 columns (value and gate halves for GEGLU)
-  float bcol[8], bgate[8];
+  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, bm0, bn0, wm, wn, wave, lane, acc, smem);
+}
+
+// ---- conv3p: 3x3 / stride 1 / pad 1 conv with the activation PATCH staged once per 32 input channels -----------------
+// The im2col form above re-fetches every input pixel nine times (once per tap) through the LDS-DMA path, and that path —
+// not the matrix pipe — bounds the kernel (ablation: DMA alone ~75 % of the full time, activations the larger share).
+// Here a tile of BM consecutive output pixels (inside one frame) stages the contiguous raster range of input pixels
+// [m0 - W - 1, m0 + BM + W + 1) ONCE per 32-channel slice (64-B LDS rows) and all nine taps read their fragments from it:
+// tap (dy, dx) of output pixel i is patch row i + (dy+1)*W + (dx+1).  Rows outside the frame are zero-filled by the DMA
+// (zero page), the x = 0 / x = W-1 wrap of the dx = -1 / +1 taps is removed per lane by redirecting the fragment read to
+// a 64-B zero row.  Weights stream as before, one kernel row (3 taps x 32 channels) per stage, double buffered; the next
+// patch arrives piecewise during the three stages of the current one.  K order: (32-channel slice, dy, dx, c).
+constexpr int PB = 64;   // bytes per LDS row (32 fp16 channels)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(const MgldIGemm p, float* __restrict__ ws, int hchunk) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int NW = (BM / WM) * (BN / WN);
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int BSUB = BN * PB;                 // one tap's weight sub-tile [BN][32 ch]
+  constexpr int B_BYTES = 3 * BSUB;             // weight stage: the three taps of one kernel row
+  constexpr int NPB = 3 * BN / 16;              // 1-KiB DMA pieces per weight stage
+  constexpr int BSLOTS = (NPB + NW - 1) / NW;
+  static_assert(NW == 8, "eight waves per block");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const bool splitk = (ws != nullptr);
+  const int kz = splitk ? blockIdx.z : 0;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const f16* __restrict__ A = (const f16*)p.A;
+  const f16* __restrict__ W = (const f16*)p.W;
+  const int N = p.N, Cin = p.Cin, Wd = p.Win, HW = p.Hin * p.Win;
+  const int PR = BM + 2 * Wd + 2;               // patch rows
+  const int NPA = (PR + 15) >> 4;               // 1-KiB pieces (16 rows) per patch; <= 3 * NW
+  const int a_bytes = NPA * 1024;
+  const int b_base = 2 * a_bytes;
+  const int z_off = b_base + 2 * B_BYTES;       // 64-B zero row
+  const int nh = Cin >> 5;
+  const int h0 = splitk ? kz * hchunk : 0;
+  const int h1 = splitk ? min(nh, h0 + hchunk) : nh;
+  const char* zero = (const char*)g_zero_page;
+
+  if (tid < 16) *(unsigned*)(smem + z_off + tid * 4) = 0u;
+
+  // ---- DMA assignment: activation piece q = s*NW + wave (slot s is issued during stage s of the previous slice) ----
+  const char* fa_ptr[3];
+  unsigned fa_step[3];
+  {
+    const int frame_lo = (bm0 / HW) * HW, frame_hi = frame_lo + HW;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { bcol[j] = 0.f; bgate[j] = 0.f; }
-  if (!splitk && p.bias) {
-    const int nb = geglu ? bn0 + wn * WN + pcv : n;   // packed row index of the value half
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (nb + j < N) bcol[j] = p.bias[nb + j];
-      if (geglu && nb + 32 + j < N) bgate[j] = p.bias[nb + 32 + j];
+    for (int s = 0; s < 3; ++s) {
+      const int j = (s * NW + wave) * 16 + (lane >> 2);
+      const int g = bm0 - (Wd + 1) + j;
+      const bool ok = (j < PR) && (g >= frame_lo) && (g < frame_hi);
+      const int cl = (lane & 3) ^ ((j >> 2) & 3);
+      fa_ptr[s] = ok ? (const char*)(A + (int64_t)g * p.lda + h0 * 32 + cl * 8) : zero;
+      fa_step[s] = ok ? 64u : 0u;
     }
   }
+  // weight piece b = k*NW + wave: tap column dxi = b / (BN/16), rows (b % (BN/16))*16 .. +16
+  const char* fw_ptr[BSLOTS];
+  bool fw_ok[BSLOTS];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    // ---- phase 1: raw accumulators -> patch[row = l31][col] ----
+  for (int k = 0; k < BSLOTS; ++k) {
+    const int b = k * NW + wave;
+    const int dxi = b / (BN / 16), rb = b - dxi * (BN / 16);
+    const int row = rb * 16 + (lane >> 2);
+    const int n = bn0 + row;
+    const int cl = (lane & 3) ^ ((row >> 2) & 3);
+    fw_ok[k] = (n < N) && (b < NPB);
+    const int64_t koff = p.tap_inner ? (int64_t)dxi * 64 : (int64_t)dxi * Cin;
+    fw_ptr[k] = (const char*)(W + (int64_t)(fw_ok[k] ? n : 0) * p.ldw + koff + cl * 8);
+  }
+  auto issue_b = [&](const int buf, const int h, const int dyi) {
+    if constexpr (ABL & 16) return;
+    const int64_t soff = p.tap_inner ? ((int64_t)(h >> 1) * 576 + dyi * 192 + (h & 1) * 32) : ((int64_t)dyi * 3 * Cin + h * 32);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-        *(f32x4*)(patch + l31 * LDW + ni * 32 + rg * 8 + lhi * 4) =
-            f32x4{acc[ni][mi][rg * 4], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
-    // ---- phase 2: patch rows -> epilogue math -> global, 8 columns (16 B of fp16 / 32 B of fp32) per lane ----
-    for (int r0 = 0; r0 < 32; r0 += rpi) {
-      const int row = r0 + prow;
-      const int m = bm0 + wm * WM + mi * 32 + row;
-      if (row < 32 && m < M && n < Nout) {
-        const f32x4 a0 = *(const f32x4*)(patch + row * LDW + pcv);
-        const f32x4 a1 = *(const f32x4*)(patch + row * LDW + pcv + 4);
-        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        if (geglu) {
-          const f32x4 g0 = *(const f32x4*)(patch + row * LDW + 32 + pcv);
-          const f32x4 g1 = *(const f32x4*)(patch + row * LDW + 32 + pcv + 4);
-          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (v[j] + bcol[j]) * gelu_f(g[j] + bgate[j]) * alpha;
-        } else if (!splitk) {
-          const float bm = p.bias_m ? p.bias_m[m] : 0.f;
-          float rvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (p.rowvec) {
-            const float* rv = p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec + n;
-            if (full && ((((uintptr_t)rv) & 15) == 0)) {
-              const f32x4 r0v = *(const f32x4*)rv, r1v = *(const f32x4*)(rv + 4);
-              rvv[0] = r0v[0]; rvv[1] = r0v[1]; rvv[2] = r0v[2]; rvv[3] = r0v[3];
-              rvv[4] = r1v[0]; rvv[5] = r1v[1]; rvv[6] = r1v[2]; rvv[7] = r1v[3];
-            } else {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) if (n + j < Nout) rvv[j] = rv[j];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bm + bcol[j] + rvv[j], act) * alpha;
-        }
-        if (R) {
-          const f16* rp = R + (int64_t)m * p.ldr + n;
-          if (full && ((((uintptr_t)rp) & 15) == 0)) {
-            const f16x8 rr = *(const f16x8*)rp;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += p.beta * (float)rr[j];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * (float)rp[j];
-          }
-        }
-        if (of32) {
-          float* cp = (float*)outp + cbase + (int64_t)m * ldo + n;
-          if (full && ((((uintptr_t)cp) & 15) == 0)) {
-            *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
-            *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = v[j];
-          }
-        } else {
-          f16* cp = (f16*)outp + cbase + (int64_t)m * ldo + n;
-          if (full && ((((uintptr_t)cp) & 15) == 0)) {
-            *(f16x8*)cp = f16x8{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j];
-          }
-        }
+    for (int k = 0; k < BSLOTS; ++k) {
+      const int b = k * NW + wave;
+      if (b < NPB) {
+        const char* src = fw_ok[k] ? fw_ptr[k] + soff * 2 : zero;
+        glds16(src, smem + b_base + buf * B_BYTES + b * 1024);
       }
     }
+  };
+#define MGLD_ISSUE_A(S, PAR)                                                     \
+  if ((S) * NW + wave < NPA) {                                                   \
+    if constexpr (!(ABL & 8)) glds16(fa_ptr[S], smem + (PAR) * a_bytes + ((S) * NW + wave) * 1024); \
+    fa_ptr[S] += fa_step[S];                                                     \
   }
+
+  // ---- fragment addresses (byte offsets from smem) ----
+  int a_off[MI][3];     // stage dy = -1, patch buffer 0; -1 = this lane's tap lies across the image edge
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int i = wm * WM + mi * 32 + l31;
+    const int x = (bm0 + i) % Wd;
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int j = i + dxi;
+      const bool ok = !(dxi == 0 && x == 0) && !(dxi == 2 && x == Wd - 1);
+      a_off[mi][dxi] = ok ? j * PB + ((lhi ^ ((j >> 2) & 3)) << 4) : -1;
+    }
+  }
+  int w_off[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int r = wn * WN + ni * 32 + l31;
+    w_off[ni] = r * PB + ((lhi ^ ((r >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  // prologue: the whole first patch + the first weight stage
+  if (h0 < h1) {
+    MGLD_ISSUE_A(0, 0)
+    MGLD_ISSUE_A(1, 0)
+    MGLD_ISSUE_A(2, 0)
+    issue_b(0, h0, 0);
+  }
+  int cur = 0;
+  for (int h = h0; h < h1; ++h) {
+    const int pa = (h - h0) & 1;
+    const bool more = (h + 1 < h1);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s < 2) issue_b(cur ^ 1, h, s + 1);
+      else if (more) issue_b(cur ^ 1, h + 1, 0);
+      if (more) {
+        if (s == 0) { MGLD_ISSUE_A(0, pa ^ 1) }
+        if (s == 1) { MGLD_ISSUE_A(1, pa ^ 1) }
+        if (s == 2) { MGLD_ISSUE_A(2, pa ^ 1) }
+      }
+      if constexpr (ABL & 128) { cur ^= 1; continue; }
+      const int add = s * Wd * PB + pa * a_bytes;            // W % 16 == 0 keeps the swizzle key of a shifted row
+      int aaddr[MI][3];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) aaddr[mi][dxi] = a_off[mi][dxi] >= 0 ? a_off[mi][dxi] + add : z_off;
+      const int bb = b_base + cur * B_BYTES;
+      f16x8 fa[2][MI], fw[2][NI];
+      auto load = [&](const int u, const int set) {
+        const int dxi = u >> 1, kx = (u & 1) << 5;           // second 16-channel step: logical chunk ^ 2 = byte offset ^ 32
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[set][mi] = *(const f16x8*)(smem + (aaddr[mi][dxi] ^ kx));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fw[set][ni] = *(const f16x8*)(smem + bb + dxi * BSUB + (w_off[ni] ^ kx));
+      };
+      load(0, 0);
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        if (u + 1 < 6) load(u + 1, (u + 1) & 1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u & 1][ni], fa[u & 1][mi], acc[ni][mi], 0, 0, 0);
+      }
+      cur ^= 1;
+    }
+  }
+#undef MGLD_ISSUE_A
+  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, 0, bm0, bn0, wm, wn, wave, lane, acc, smem);
 }
 
 // split-K finish: out = alpha*act(sum_z ws[z] + bias + bias_m + rowvec) + beta*R.  One thread per 4 columns.
@@ -635,6 +825,57 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
   *cfg = (t64x128 >= 384) ? 64128 : 64064;
 }
 
+// ---- conv3p launch plan -------------------------------------------------------------------------------------------
+constexpr int C3P_BM = 128;
+inline int conv3p_lds(int Win, int BN) { return 2 * ((C3P_BM + 2 * Win + 2 + 15) >> 4) * 1024 + 2 * 3 * BN * PB + 64; }
+
+// true when the problem takes the patch kernel; *bn = weight tile rows, *splits / *hchunk = K split in 32-channel slices
+bool conv3p_plan(const MgldIGemm* p, int* bn, int* splits, int* hchunk) {
+  static int knob = -1, fsplit = -1;   // env MGLD_CONV3P: 0 = off, 64 / 128 = force the weight tile; MGLD_CONV3P_SPLITS (tuning)
+  if (knob < 0) { const char* e = getenv("MGLD_CONV3P"); knob = e ? atoi(e) : 1; }
+  if (fsplit < 0) { const char* e = getenv("MGLD_CONV3P_SPLITS"); fsplit = e ? atoi(e) : 0; }
+  if (!knob || p->mode != MGLD_MODE_CONV3X3) return false;
+  if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
+  if (p->stride != 1 || p->up2 || p->pad_t != 1 || p->pad_l != 1 || p->Hin != p->Hout || p->Win != p->Wout) return false;
+  if ((p->Win & 15) || p->Win > 64 || (p->Hin * p->Win) % C3P_BM) return false;
+  if ((p->Cin & 31) || (p->tap_inner && (p->Cin & 63)) || p->batch > 1 || p->N <= 32 || p->act == MGLD_ACT_GEGLU) return false;
+  const int N = p->N;
+  int BN = (N <= 64 || ((N & 127) == 64 && N <= 448) || p->Win > 32) ? 64 : 128;   // W = 64: the 128-row stage pair would not leave room for two blocks per CU
+  if (knob == 64 || knob == 128) BN = knob;
+  const int lds = conv3p_lds(p->Win, BN);
+  if (lds > 160 * 1024) return false;
+  const int64_t tiles = (int64_t)(p->M / C3P_BM) * cdiv(N, BN);
+  const int slots = num_cus() * ((160 * 1024) / lds);
+  const int nh = p->Cin >> 5;
+  int s = fsplit > 0 ? fsplit : (int)(slots / tiles);
+  if (s > nh / 4) s = nh / 4;
+  if (s > 16) s = 16;
+  if (s < 2 || g_ws == nullptr || (size_t)s * p->M * N * sizeof(float) > g_ws_bytes) s = 1;
+  int hc = (nh + s - 1) / s;
+  s = (nh + hc - 1) / hc;
+  *bn = BN; *splits = s; *hchunk = hc;
+  return true;
+}
+
+template <int BN, int WM, int WN>
+int launch_conv3p(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
+  const int lds = conv3p_lds(p->Win, BN);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv3p_kernel<C3P_BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  dim3 grid(p->M / C3P_BM, cdiv(p->N, BN), splits > 1 ? splits : 1);
+  hipLaunchKernelGGL((conv3p_kernel<C3P_BM, BN, WM, WN>), grid, dim3(512), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk);
+  if (splits > 1) {
+    const int64_t total = (int64_t)p->M * ((p->N + 3) >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, *p, g_ws, splits);
+  }
+  return mgld_check_launch("igemm(conv3p)");
+}
+
 }  // namespace
 
 extern "C" int mgld_set_workspace(void* ptr, int64_t bytes) {
@@ -647,6 +888,7 @@ extern "C" int mgld_set_workspace(void* ptr, int64_t bytes) {
 extern "C" int mgld_igemm_config(const MgldIGemm* p) {
   if (!p) return 0;
   int cfg, splits, kchunk;
+  if (conv3p_plan(p, &cfg, &splits, &kchunk)) return 300000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // patch conv
   choose(p, &cfg, &splits, &kchunk);
   return cfg + (splits > 1 ? splits * 1000000 : 0);
 }
@@ -681,6 +923,8 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;
+  if (conv3p_plan(p, &cfg, &splits, &kchunk))
+    return cfg == 64 ? launch_conv3p<64, 32, 32>(p, s, splits, kchunk) : launch_conv3p<128, 64, 32>(p, s, splits, kchunk);
   choose(p, &cfg, &splits, &kchunk);
   switch (cfg) {
     // 128x128: eight waves of 64x32 (two blocks = 16 waves per CU) measured ~3 % faster end to end than four of 64x64:
