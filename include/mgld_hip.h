@@ -93,7 +93,13 @@ typedef struct MgldIGemm {
   int32_t batch;          /* grid.z batches (>=1)                                           */
   int32_t tap_inner;      /* CONV3X3/TCONV3 with Cin % 64 == 0 and no upsample fold: 1 = the K axis of W is ordered
                              (64-channel block, tap, channel) instead of (tap, Cin): all taps of one channel block are
-                             consumed back to back, so the shifted re-reads of the input hit L1/L2                  */
+                             consumed back to back, so the shifted re-reads of the input hit L1/L2.
+                             2 = CONV3X3 problems the patch-staged kernel takes (3x3, stride 1, pad 1, same size,
+                             Win % 16 == 0, Win <= 64, Hin*Win % 128 == 0, Cin % 32 == 0, N > 32, no batch; query with
+                             mgld_igemm_config: code % 1000000 >= 300000): W is tiled [ceil(N/64)][Cin/32][3 kernel rows]
+                             [4 groups of 16 rows][3 kernel columns][16 rows][32 channels] (rows past N zero; within a
+                             16x32 tile the 16-byte slot c of row r holds channels 8*(c ^ ((r>>2)&3)) .. +8, the LDS
+                             image), so each 1-KiB DMA piece is one linear read; ldw unused */
   int64_t strideA, strideW, strideC, strideR; /* element strides between batches            */
   int32_t t_off;          /* TCONV3 on a frame-sharded clip: output frame f sits at position f + t_off of a clip of T
                              frames whose rows start t_off frames BEFORE `A` (A points at the first output frame inside a

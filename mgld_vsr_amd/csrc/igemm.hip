@@ -27,7 +27,7 @@
 namespace {
 
 #ifndef MGLD_IGEMM_ABLATE
-#define MGLD_IGEMM_ABLATE 0   // timing-only ablation builds: 8 no A traffic (conv), 16 no W traffic, 32 no MFMA, 128 no compute, 256 no DMA, 512 no epilogue
+#define MGLD_IGEMM_ABLATE 0   // timing-only ablation builds: 1 / 2 conv3p contiguous A / W pieces, 8 no A traffic (conv), 16 no W traffic, 32 no MFMA, 128 no compute, 256 no DMA, 512 no epilogue
 #endif
 constexpr int ABL = MGLD_IGEMM_ABLATE;
 
@@ -563,6 +563,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
       const int cl = (lane & 3) ^ ((j >> 2) & 3);
       fa_ptr[s] = ok ? (const char*)(A + (int64_t)g * p.lda + h0 * 32 + cl * 8) : zero;
       fa_step[s] = ok ? 64u : 0u;
+      if constexpr (ABL & 1) {   // (ablation build bit 1: same byte count from perfectly contiguous addresses — wrong data)
+        fa_ptr[s] = (const char*)A + ((int64_t)(bm0 / BM) * 24 + s * NW + wave) * 1024 + lane * 16;
+        fa_step[s] = 0u;
+      }
     }
   }
   // weight piece b = k*NW + wave: tap column dxi = b / (BN/16), rows (b % (BN/16))*16 .. +16
@@ -575,18 +579,29 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
     const int row = rb * 16 + (lane >> 2);
     const int n = bn0 + row;
     const int cl = (lane & 3) ^ ((row >> 2) & 3);
-    fw_ok[k] = (n < N) && (b < NPB);
-    const int64_t koff = p.tap_inner ? (int64_t)dxi * 64 : (int64_t)dxi * Cin;
-    fw_ptr[k] = (const char*)(W + (int64_t)(fw_ok[k] ? n : 0) * p.ldw + koff + cl * 8);
+    if (p.tap_inner == 2) {   // tiled weights [N/64][Cin/32][3 dy][4 row groups][3 dx][16 rows x 32 ch in LDS-image order]:
+      // every DMA piece is one linear 1-KiB read and the 12 pieces of a (64 rows, slice, kernel row) stage are contiguous
+      const int g64 = (bn0 >> 6) + (rb >> 2);
+      fw_ok[k] = (g64 * 64 < ((N + 63) & ~63)) && (b < NPB);
+      fw_ptr[k] = (const char*)(W + (((int64_t)g64 * nh * 3 * 4 + (rb & 3)) * 3 + dxi) * 512 + lane * 8);
+    } else {
+      fw_ok[k] = (n < N) && (b < NPB);
+      const int64_t koff = p.tap_inner ? (int64_t)dxi * 64 : (int64_t)dxi * Cin;
+      fw_ptr[k] = (const char*)(W + (int64_t)(fw_ok[k] ? n : 0) * p.ldw + koff + cl * 8);
+    }
   }
   auto issue_b = [&](const int buf, const int h, const int dyi) {
     if constexpr (ABL & 16) return;
-    const int64_t soff = p.tap_inner ? ((int64_t)(h >> 1) * 576 + dyi * 192 + (h & 1) * 32) : ((int64_t)dyi * 3 * Cin + h * 32);
+    const int64_t soff = p.tap_inner == 2 ? (int64_t)(h * 3 + dyi) * (12 * 512)
+                         : p.tap_inner    ? ((int64_t)(h >> 1) * 576 + dyi * 192 + (h & 1) * 32)
+                                          : ((int64_t)dyi * 3 * Cin + h * 32);
 #pragma unroll
     for (int k = 0; k < BSLOTS; ++k) {
       const int b = k * NW + wave;
       if (b < NPB) {
         const char* src = fw_ok[k] ? fw_ptr[k] + soff * 2 : zero;
+        if constexpr (ABL & 2)   // (ablation build bit 2: contiguous weight pieces — wrong data)
+          src = (const char*)W + ((int64_t)((h * 3 + dyi) * (N / BN) + bn0 / BN) * NPB + b) * 1024 + lane * 16;
         glds16(src, smem + b_base + buf * B_BYTES + b * 1024);
       }
     }
@@ -625,7 +640,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  // prologue: the whole first patch + the first weight stage
+  // prologue: the whole first patch + the first weight stage.  (A third weight buffer — two stages in flight behind a
+  // counted vmcnt — measured no faster and costs a resident block at W = 32.)
   if (h0 < h1) {
     MGLD_ISSUE_A(0, 0)
     MGLD_ISSUE_A(1, 0)
@@ -640,13 +656,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
     for (int s = 0; s < 3; ++s) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (s < 2) issue_b(cur ^ 1, h, s + 1);
-      else if (more) issue_b(cur ^ 1, h + 1, 0);
       if (more) {
         if (s == 0) { MGLD_ISSUE_A(0, pa ^ 1) }
         if (s == 1) { MGLD_ISSUE_A(1, pa ^ 1) }
         if (s == 2) { MGLD_ISSUE_A(2, pa ^ 1) }
       }
+      if (s < 2) issue_b(cur ^ 1, h, s + 1);
+      else if (more) issue_b(cur ^ 1, h + 1, 0);
       if constexpr (ABL & 128) { cur ^= 1; continue; }
       const int add = s * Wd * PB + pa * a_bytes;            // W % 16 == 0 keeps the swizzle key of a shifted row
       int aaddr[MI][3];
@@ -838,9 +854,11 @@ bool conv3p_plan(const MgldIGemm* p, int* bn, int* splits, int* hchunk) {
   if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
   if (p->stride != 1 || p->up2 || p->pad_t != 1 || p->pad_l != 1 || p->Hin != p->Hout || p->Win != p->Wout) return false;
   if ((p->Win & 15) || p->Win > 64 || (p->Hin * p->Win) % C3P_BM) return false;
-  if ((p->Cin & 31) || (p->tap_inner && (p->Cin & 63)) || p->batch > 1 || p->N <= 32 || p->act == MGLD_ACT_GEGLU) return false;
+  if ((p->Cin & 31) || (p->tap_inner == 1 && (p->Cin & 63)) || p->batch > 1 || p->N <= 32 || p->act == MGLD_ACT_GEGLU) return false;
   const int N = p->N;
-  int BN = (N <= 64 || ((N & 127) == 64 && N <= 448) || p->Win > 32) ? 64 : 128;   // W = 64: the 128-row stage pair would not leave room for two blocks per CU
+  // 64 weight rows: W = 64 (a 128-row stage pair would not leave LDS for two blocks per CU), W = 32 (three blocks per CU
+  // instead of two: measured faster), and N = 64 (mod 128); 128 rows at W = 16
+  int BN = (N <= 64 || ((N & 127) == 64 && N <= 448) || p->Win >= 32) ? 64 : 128;
   if (knob == 64 || knob == 128) BN = knob;
   const int lds = conv3p_lds(p->Win, BN);
   if (lds > 160 * 1024) return false;
@@ -915,7 +933,10 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
       else MGLD_REQUIRE(p->M % p->HW == 0 && p->M / p->HW + p->t_off <= p->T, "igemm: sharded tconv frames exceed the clip");
     }
   }
-  if (p->tap_inner)
+  if (p->tap_inner == 2) {
+    int c_, s_, h_;
+    MGLD_REQUIRE(conv3p_plan(p, &c_, &s_, &h_), "igemm: tiled conv weights (tap_inner = 2) need a problem the patch conv takes");
+  } else if (p->tap_inner)
     MGLD_REQUIRE(p->mode != MGLD_MODE_LINEAR && (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2) &&
                      !(p->mode == MGLD_MODE_CONV3X3 && p->kh > 0 && !(p->kh == 3 && p->kw == 3)),
                  "igemm: tap_inner needs a gather mode with Cin % 64 == 0 and no upsample fold");

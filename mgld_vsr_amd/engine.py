@@ -35,6 +35,28 @@ def pack_conv3x3(w, cin_pad=None, tap_inner=None):
     return out.reshape(cout, 9 * cp).contiguous()
 
 
+def tile_conv3p(wp, cin, tap_inner):
+    """[N, 9*Cin] packed conv weights (either K order of pack_conv3x3) -> the patch kernel's tiled layout
+    [N64/64][Cin/32][3 dy][4 row groups][3 dx][16 rows][32 ch] as a [., 32] tensor (include/mgld_hip.h, tap_inner = 2); rows
+    padded with zeros to a multiple of 64."""
+    n = wp.shape[0]
+    if tap_inner:
+        w3 = wp.reshape(n, cin // 64, 9, 64).permute(0, 2, 1, 3).reshape(n, 9, cin)
+    else:
+        w3 = wp.reshape(n, 9, cin)
+    n64 = (n + 63) // 64 * 64
+    if n64 != n:
+        w3 = torch.cat([w3, w3.new_zeros(n64 - n, 9, cin)], 0)
+    # [g64, rb 4, row 16, dy 3, dx 3, slice, chunk 4, 8] -> [g64, slice, dy, rb, dx, row, chunk, 8]
+    t = w3.reshape(n64 // 64, 4, 16, 3, 3, cin // 32, 4, 8).permute(0, 5, 3, 1, 4, 2, 6, 7).contiguous()
+    # LDS-image order: 16-B slot c of tile row r holds logical chunk c ^ ((r >> 2) & 3) (the kernel's bank swizzle), so a DMA
+    # piece is read lane-linearly
+    rows = torch.arange(16, device=t.device)
+    src = torch.arange(4, device=t.device)[None, :] ^ ((rows >> 2) & 3)[:, None]                 # [16, 4]
+    t = torch.gather(t, 6, src[None, None, None, None, None, :, :, None].expand(*t.shape))
+    return t.reshape(-1, 32)
+
+
 def pack_conv(w, cin_pad=None):
     """[Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin_pad], K index = (ky*kw+kx)*Cin_pad + c (general-tap igemm layout)."""
     cout, cin, kh, kw = w.shape
@@ -154,6 +176,7 @@ class Engine:
         self.device = torch.device(device)
         self.arena = Arena(self.device, chunk_bytes)
         self._wcache = {}
+        self._c3p_geo, self._c3p_w = {}, {}     # patch-conv applicability per geometry / tiled weights per packed tensor
         self.launches = 0
         self.shard = None   # parallel.FrameShard when the frames of one segment are split over ranks
         # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
@@ -208,12 +231,35 @@ class Engine:
             out = Act(self.arena.alloc((x.n * ho * wo, cout), out_dtype), x.n, ho, wo)
         cin = x.C
         assert wp.shape[1] == 9 * cin, (wp.shape, cin)
+        tap_inner = 1 if conv_tap_inner(cin, up2) else 0          # must match pack_conv3x3(..., tap_inner) of wp
+        kw = {}
+        if stride == 1 and not up2 and tuple(pad) == (1, 1) and (ho, wo) == (hin, win):
+            wt = self._conv3p_tiled(wp, x.n, cin, cout, hin, win, tap_inner)
+            if wt is not None:
+                wp, tap_inner, kw = wt, 2, dict(N=cout, K=9 * cin)
         hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec,
                   rows_per_frame=rows_per_frame or ho * wo, resid=None if resid is None else resid.v, act=act, alpha=alpha,
-                  beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0),
-                  tap_inner=1 if conv_tap_inner(cin, up2) else 0)   # must match pack_conv3x3(..., tap_inner) of wp
+                  beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0), tap_inner=tap_inner, **kw)
         self.launches += 1
         return out
+
+    def _conv3p_tiled(self, wp, frames, cin, cout, h, w, tap_inner):
+        """weights of a convolution the library's patch kernel takes, re-laid as [N/16][Cin/32][9][16][32] so that every
+        1-KiB DMA piece of a weight stage is contiguous (include/mgld_hip.h, tap_inner = 2).  Built once per weight tensor on
+        first use (eager pass); None = keep the [N, K] layout."""
+        geo = (cin, cout, h, w)
+        ok = self._c3p_geo.get(geo)
+        if ok is None:
+            ok = self._c3p_geo[geo] = bool(hip.conv3p_applies(frames, cin, cout, h, w))
+        if not ok:
+            return None
+        key = (wp.data_ptr(), tap_inner)
+        hit = self._c3p_w.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            hit = self._c3p_w[key] = (tile_conv3p(wp, cin, tap_inner), wp)     # (keeps wp alive: the key is its address)
+        return hit[0]
 
     def conv2d(self, x, wp, bias, cout, ksize, stride=1, pad=(0, 0), out=None, act=hip.ACT_NONE, alpha=1.0,
                out_dtype=torch.float16):

@@ -151,6 +151,15 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
     return out
 
 
+def conv3p_applies(frames, cin, cout, h, w):
+    """does the launcher route this 3x3 / stride 1 / pad 1 convolution to the patch-staged kernel (which can take the tiled
+    weight layout, tap_inner = 2)?  Asks the library's own planner (mgld_igemm_config), no launch."""
+    p = MgldIGemm()
+    p.mode, p.M, p.N, p.K, p.batch = MODE_CONV3X3, frames * h * w, cout, 9 * cin, 1
+    p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, 1, 1, 1, 0
+    return igemm_config(p) % 1000000 >= 300000
+
+
 IGEMM_LOG = None   # bench.py sets this to a list to collect the igemm problems of one pass (roofline bookkeeping)
 
 

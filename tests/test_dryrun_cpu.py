@@ -82,6 +82,7 @@ def dry(monkeypatch):
     for name in ["gn_stats", "gn_apply", "spade_apply", "layernorm", "temporal_attention", "softmax_rows", "linear_small",
                  "timestep_embedding", "nchw_to_nhwc", "nhwc_to_nchw", "copy2d", "axpby"]:
         monkeypatch.setattr(hip, name, generic(name))
+    monkeypatch.setattr(hip, "conv3p_applies", lambda *a: False)   # (a planner query into the library: keep the [N, K] weights)
     monkeypatch.setattr(hip, "lib", lambda: None)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     eng = E.Engine(device="cpu", chunk_bytes=64 << 20)

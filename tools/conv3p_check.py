@@ -9,7 +9,7 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mgld_vsr_amd import hip  # noqa: E402
-from mgld_vsr_amd.engine import pack_conv3x3  # noqa: E402
+from mgld_vsr_amd.engine import pack_conv3x3, tile_conv3p  # noqa: E402
 
 DEV = "cuda"
 
@@ -58,13 +58,19 @@ def main():
         hip.IGEMM_LOG = []
         hip.igemm(xt, wk, out, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=1 if ti else 0, **kw)
         torch.cuda.synchronize()
+        assert hip.conv3p_applies(n, cin, cout, h, w)
+        out2 = torch.empty_like(out)
+        hip.igemm(xt, tile_conv3p(wk, cin, ti), out2, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=(cin, h, w, h, w, 1, 1, 1, 0),
+                  tap_inner=2, N=cout, K=9 * cin, **kw)
+        torch.cuda.synchronize()
+        same = torch.equal(out, out2)
         cfg = hip.igemm_config(hip.IGEMM_LOG[0])
         hip.IGEMM_LOG = None
         o = out.cpu().float().reshape(n, h, w, cout).permute(0, 3, 1, 2)
         e = rel(o, ref)
-        ok = e < 1e-3
+        ok = e < 1e-3 and same
         bad += not ok
-        print(f"n={n} cin={cin} cout={cout} {h}x{w} tap_inner={ti} epi={epi} cfg={cfg} rel_l2={e:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+        print(f"n={n} cin={cin} cout={cout} {h}x{w} tap_inner={ti} epi={epi} cfg={cfg} rel_l2={e:.2e} tiled_identical={same} {'ok' if ok else 'FAIL'}", flush=True)
     print("FAILED" if bad else "ALL OK")
     return 1 if bad else 0
 

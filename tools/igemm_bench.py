@@ -57,8 +57,14 @@ def main():
         out = torch.empty(M, N // 2 if act == 4 else N, dtype=torch.half, device=dev)
         bias = torch.randn(N, device=dev)
 
+        tiled = (mode == 1 and os.environ.get("MGLD_BENCH_TILED", "1") == "1" and H <= 64 and hip.conv3p_applies(M // (H * H), Cin, N, H, H))
+        if tiled:   # weight values are random anyway: any [.., 32] tensor of the right size is a valid tiled layout
+            w = (torch.randn((N + 63) // 64 * 64 * 9 * Cin // 32, 32, device=dev) * K ** -0.5).half()
+
         def launch():
-            if mode == 1:
+            if tiled:
+                hip.igemm(a, w, out, mode=1, bias=bias, conv=(Cin, H, H, H, H, 1, 1, 1, 0), tap_inner=2, N=N, K=K)
+            elif mode == 1:
                 hip.igemm(a, w, out, mode=1, bias=bias, conv=(Cin, H, H, H, H, 1, 1, 1, 0),
                           tap_inner=int(os.environ.get("MGLD_TAP_INNER", "1")) if Cin % 64 == 0 else 0)
             else:
