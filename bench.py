@@ -152,16 +152,18 @@ def roofline(pipe, args, frames, noise, flows, masks):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
             pm = json.load(fh)
-        if f"<{dom_tile // 1000},{dom_tile % 1000}>" in pm.get("kernel", ""):
+        if dom_tile < 300000 and f"<{dom_tile // 1000},{dom_tile % 1000}>" in pm.get("kernel", ""):
             traffic = round(pm["hbm_bytes_per_launch"])
     except Exception:
         traffic = None
     d = tot[dom_cfg]
+    # launcher config codes (mgld_igemm_config): 300000 + BN = the patch-staged 3x3 conv (128 pixels x BN channels per block)
+    kname = f"conv3p_kernel<128,{dom_tile - 300000}>" if dom_tile >= 300000 else f"igemm_kernel<{dom_tile // 1000},{dom_tile % 1000}>"
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     all_flops = sum(t["flops"] for t in tot.values())
     all_ms = sum(t["ms"] for t in tot.values())
     return {
-        "bound": "mfma", "kernel": f"igemm_kernel<{dom_tile // 1000},{dom_tile % 1000}>" + (f" splitK x{dom_cfg // 1000000}" if dom_cfg >= 1000000 else ""), "achieved": round(achieved, 2),
+        "bound": "mfma", "kernel": kname + (f" splitK x{dom_cfg // 1000000}" if dom_cfg >= 1000000 else ""), "achieved": round(achieved, 2),
         "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
         "algorithmic_bytes": round(d["bytes"] / d["launches"]),   # per launch: every operand element moved once
         "launches_per_segment": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),

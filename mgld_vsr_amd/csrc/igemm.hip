@@ -530,7 +530,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  // Workgroups are dealt round-robin to the 8 XCDs in linear-id order.  Give each XCD runs of consecutive weight tiles
+  // of ONE pixel tile, so the patch is fetched into that XCD's L2 once and the other N/BN - 1 blocks hit it there
+  // (-4 % on the 640 -> 320 convs of the 64x64 level, neutral elsewhere).
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if ((gridDim.x & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    tile_m = xcd + 8 * (j / (int)gridDim.y);
+    tile_n = j % (int)gridDim.y;
+  }
+  const int bm0 = tile_m * BM, bn0 = tile_n * BN;
   const bool splitk = (ws != nullptr);
   const int kz = splitk ? blockIdx.z : 0;
   const int l31 = lane & 31, lhi = lane >> 5;

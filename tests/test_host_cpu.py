@@ -142,6 +142,31 @@ def test_weight_packing():
     assert torch.equal(bp[32:64], bg[64:96])
 
 
+def test_conv3p_tiled_weight_layout():
+    """tile_conv3p: element (n, tap, c) of either [N, K] order lands where include/mgld_hip.h (tap_inner = 2) says:
+    [N/64][Cin/32][dy][16-row group][dx][row][16-byte slot ^ ((row >> 2) & 3)][8]; rows past N are zero"""
+    from mgld_vsr_amd.engine import pack_conv3x3, tile_conv3p
+    n_out, cin = 96, 128
+    w = torch.randn(n_out, cin, 3, 3)
+    nh = cin // 32
+    for ti in (False, True):
+        wp = pack_conv3x3(w, tap_inner=ti)
+        t = tile_conv3p(wp, cin, ti).reshape(-1)
+        assert t.numel() == 128 * 9 * cin
+        g = torch.Generator().manual_seed(0)
+        for _ in range(500):
+            n, tap, c = (int(torch.randint(0, hi, (1,), generator=g)) for hi in (n_out, 9, cin))
+            g64, rb, row = n // 64, (n % 64) // 16, n % 16
+            h, cc = c // 32, c % 32
+            dy, dx = tap // 3, tap % 3
+            slot = (cc // 8) ^ ((row >> 2) & 3)
+            piece = (((g64 * nh + h) * 3 + dy) * 4 + rb) * 3 + dx
+            assert t[piece * 512 + row * 32 + slot * 8 + cc % 8] == w[n, c, dy, dx]
+        # rows 96..127 of the second 64-row group are padding
+        tz = t.reshape(2, nh, 3, 4, 3, 16, 32)
+        assert float(tz[1, :, :, 2:].abs().max()) == 0
+
+
 def test_spliter_starts():
     from scripts.util_image import ImageSpliterTh
     sp = ImageSpliterTh(torch.zeros(1, 1, 1024, 1032), 960, 750, sf=1)

@@ -216,6 +216,63 @@ def test_igemm_conv3x3_tap_inner(hip, n, cin, cout, h, w, stride):
     assert rel_l2(_from_tok(out.cpu().float(), n, ho, wo), ref) < 1e-3
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,ti,epi", [
+    (2, 128, 96, 16, 16, False, 0),      # 128 weight rows per block, (tap, Cin) K order, N not a multiple of the tile
+    (4, 320, 640, 64, 64, True, 0),      # W = 64: 64 weight rows per block, 2 blocks per CU
+    (8, 640, 640, 32, 32, True, 1),      # W = 32, residual + SiLU epilogue
+    (8, 1280, 1280, 16, 16, True, 2),    # W = 16: split along the channel slices (fp32 slabs + reduce), per-frame row vector
+    (3, 96, 64, 16, 16, False, 2),       # Cin a multiple of 32 only, strided (concat-slice) input
+    (1, 320, 320, 24, 16, True, 0),      # non-square frame
+    (2, 2560, 1280, 16, 16, True, 0),    # deepest K of the UNet
+    (1, 32, 40, 16, 16, False, 0)])      # single slice, ragged N
+def test_igemm_conv3x3_patch(hip, n, cin, cout, h, w, ti, epi):
+    """the patch-staged 3x3 conv (stride 1, pad 1, W in {16, 32, 64}): both [N, K] weight orders and the tiled layout
+    (tap_inner = 2) the engine feeds it; the tiled launch must be bit-identical to the [N, K] launch"""
+    from mgld_vsr_amd.engine import pack_conv3x3, tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    x = h16(rnd(n, cin, h, w, seed=70))
+    wt = h16(rnd(cout, cin, 3, 3, seed=71, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=72)
+    ref = F.conv2d(x.float(), wt.float(), b, padding=1)
+    wk = (pack_conv3x3(wt, tap_inner=True) if ti else wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()).to(DEV)
+    xt = _to_tok(x).to(DEV)
+    kw = {}
+    if epi == 1:
+        r = h16(rnd(n * h * w, cout, seed=73))
+        kw = dict(resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+        ref = 0.5 * F.silu(ref) + 2.0 * _from_tok(r.float(), n, h, w)
+    elif epi == 2:
+        emb = rnd(n, cout, seed=74)
+        kw = dict(rowvec=emb.to(DEV), rows_per_frame=h * w)
+        ref = ref + emb[:, :, None, None]
+        big = torch.zeros(n * h * w, cin + 64, dtype=torch.half, device=DEV)
+        big[:, 32:32 + cin] = xt
+        xt = big[:, 32:32 + cin]
+    assert hip.conv3p_applies(n, cin, cout, h, w)
+    conv = (cin, h, w, h, w, 1, 1, 1, 0)
+    out = torch.empty(n * h * w, cout, dtype=torch.half, device=DEV)
+    hip.igemm(xt, wk, out, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=conv, tap_inner=1 if ti else 0, **kw)
+    out2 = torch.empty_like(out)
+    hip.igemm(xt, tile_conv3p(wk, cin, ti), out2, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=conv, tap_inner=2, N=cout,
+              K=9 * cin, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
+    assert torch.equal(out, out2)
+
+
+def test_igemm_tiled_weights_rejected_off_the_patch_path(hip):
+    """tap_inner = 2 is only defined for problems the patch kernel takes: anything else must fail loudly"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    n, cin, cout, h, w = 1, 64, 64, 8, 8            # W = 8: im2col path
+    assert not hip.conv3p_applies(n, cin, cout, h, w)
+    x = _to_tok(h16(rnd(n, cin, h, w, seed=75))).to(DEV)
+    wk = h16(rnd(cout, 9 * cin, seed=76)).to(DEV)
+    out = torch.empty(n * h * w, cout, dtype=torch.half, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip.igemm(x, tile_conv3p(wk, cin, False), out, mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=2,
+                  N=cout, K=9 * cin)
+
+
 def test_igemm_conv_rowvec(hip):
     n, cin, cout, h, w = 3, 32, 64, 8, 8
     x = h16(rnd(n, cin, h, w, seed=23))
