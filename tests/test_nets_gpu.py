@@ -217,6 +217,43 @@ def test_pipeline_small_end_to_end_vs_oracle(hip):
     assert record("e2e_small_frames", rel_l2(out, ref)) < 1.3e-3
 
 
+def test_pipeline_single_frame_vs_oracle(hip):
+    """BASELINE configs[0] as a parity case: ONE 128x128 LR frame (pre-upsampled 4x to 512x512, latent 64x64), 4 DDPM steps,
+    no flows (a one-frame clip has no temporal neighbours: Conv3d / temporal attention over T = 1, guidance off); reduced
+    network width so the oracle side stays at a few seconds."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    from oracle import colorfix as ocf
+    from oracle import schedule as osched
+    Tn, S, H, h = 1, 4, 512, 64
+    cfgs = model_configs(Tn, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                         struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                         vae_overrides=dict(ch=32, resolution=H), context_dim=64)
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=cfgs)
+    x = synth.synth_tensor("one/x", (Tn, 3, H, H), 0.5).clamp(-1, 1)
+    noise = {"posterior": synth.synth_tensor("one/np", (Tn, 4, h, h)), "x_T": synth.synth_tensor("one/n0", (Tn, 4, h, h)),
+             "steps": torch.stack([synth.synth_tensor(f"one/n{i}", (Tn, 4, h, h)) for i in range(S)])}
+    out, lat = pipe.run_segment(x, noise=noise, return_latents=True)
+    assert out.shape == (Tn, 3, H, H) and bool(torch.isfinite(out).all())
+    m, vq = pipe.model, pipe.vq_model
+    dd = cfgs[1]["params"]["ddconfig"]
+    with torch.no_grad():
+        mean, logvar, _ = onets.vae_moments(m.first_stage_model.state_dict(), dd, x)
+        init = 0.18215 * (mean + torch.exp(0.5 * logvar) * noise["posterior"])
+        full, _, _ = osched.respaced_schedule(S)
+        tt = torch.full((Tn,), 999, dtype=torch.long)
+        xT = osched.q_sample_respace(init, tt, full["sqrt_alphas_cumprod"], full["sqrt_one_minus_alphas_cumprod"], noise["x_T"])
+        ucfg, scfg = cfgs[0]["params"]["unet_config"]["params"], cfgs[0]["params"]["structcond_stage_config"]["params"]
+        ctx = synth.synth_tensor("ctx", (1, 77, 64))
+        x0 = osamp.sample(m.model.diffusion_model.state_dict(), ucfg, m.structcond_stage_model.state_dict(), scfg, ctx, init,
+                          xT, [noise["steps"][S - 1 - k] for k in range(S)], S)
+        _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
+        dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
+        ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
+    assert record("e2e_single_frame_latent", rel_l2(lat, x0)) < 3e-3
+    assert record("e2e_single_frame_frames", rel_l2(out, ref)) < 2e-3
+
+
 def test_pipeline_frame_sharded_matches_unsharded(hip):
     """SURVEY §8(e), intra-segment frame sharding: the frames of ONE segment split over 2 / 4 ranks (halo exchange for the
     temporal convs, all-gather for temporal attention and the guidance chain) reproduce the unsharded segment.  Only one
