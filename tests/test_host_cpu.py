@@ -167,6 +167,35 @@ def test_conv3p_tiled_weight_layout():
         assert float(tz[1, :, :, 2:].abs().max()) == 0
 
 
+def test_conv3p_planner_routes_the_unet_convolutions():
+    """mgld_igemm_config is host logic (no launch): which 3x3 convolutions take the patch-staged kernel, and with how many
+    weight rows per block.  Code = 300000 + rows (+ splits * 1e6 once a split-K workspace is registered, which needs a GPU)."""
+    from mgld_vsr_amd import hip
+    hip.lib()
+
+    def code(frames, cin, cout, h, w, stride=1, up2=0, pad=1, batch=1, tap_inner=0):
+        p = hip.MgldIGemm()
+        p.mode, p.M, p.N, p.K, p.batch, p.tap_inner = hip.MODE_CONV3X3, frames * h * w, cout, 9 * cin, batch, tap_inner
+        p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, stride, pad, pad, up2
+        return hip.igemm_config(p) % 1000000
+
+    assert code(8, 320, 320, 64, 64) == 300064          # W = 64: 64 weight rows (two blocks per CU)
+    assert code(8, 640, 640, 32, 32, tap_inner=1) == 300064
+    assert code(8, 1280, 1280, 16, 16) == 300128        # W = 16: 128 rows
+    assert code(8, 1280, 320, 16, 16) == 300064         # N = 64 (mod 128)
+    assert hip.conv3p_applies(8, 512, 512, 64, 64) and hip.conv3p_applies(1, 32, 40, 16, 16)
+    for args, kw in [((8, 1280, 1280, 8, 8), {}),                  # W = 8: H*W < 128 pixels per frame
+                     ((8, 256, 256, 128, 128), {}),                # W > 64
+                     ((8, 320, 320, 64, 64), dict(stride=2)),
+                     ((8, 320, 320, 64, 64), dict(up2=1)),
+                     ((8, 320, 320, 64, 64), dict(pad=0)),
+                     ((8, 320, 4, 64, 64), {}),                    # N <= 32: the 128x32 im2col tile
+                     ((8, 328, 320, 64, 64), {}),                  # Cin % 32 != 0
+                     ((8, 96, 64, 16, 16), dict(tap_inner=1))]:    # (64-block, tap, c) order needs Cin % 64 == 0
+        assert code(*args, **kw) < 300000, (args, kw)
+    assert not hip.conv3p_applies(8, 1280, 1280, 8, 8)
+
+
 def test_spliter_starts():
     from scripts.util_image import ImageSpliterTh
     sp = ImageSpliterTh(torch.zeros(1, 1, 1024, 1032), 960, 750, sf=1)
