@@ -281,6 +281,28 @@ def gen_raft():
     save("g_raft", lrs=lrs, fmap1=fmap[0], cnet=net.cnet(a), names_shapes=names_shapes(net), **out)
 
 
+def gen_text_hf():
+    """Text tower pin.  open_clip (FrozenOpenCLIPEmbedder's dependency, modules.py:12) is not installed here, but transformers'
+    CLIPTextModel — the class the reference's FrozenCLIPEmbedder binds (modules.py:7, :207) and an independent published
+    implementation of the same text tower (token + position embedding, pre-LN causal blocks, exact GELU, final LayerNorm) —
+    is: a tiny random-weight instance gives the expected `last` and `penultimate` (hidden_states[-2] -> final_layer_norm,
+    the FrozenOpenCLIPEmbedder layer='penultimate' semantics, modules.py:181-199) outputs."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    cfg = CLIPTextConfig(vocab_size=100, hidden_size=64, intermediate_size=256, num_hidden_layers=3, num_attention_heads=4,
+                         max_position_embeddings=77, hidden_act="gelu", bos_token_id=98, eos_token_id=99, pad_token_id=0)
+    m = CLIPTextModel(cfg).eval()
+    synth.fill_module_(m, "text_hf")
+    tokens = torch.zeros(2, 77, dtype=torch.long)
+    tokens[0, 0], tokens[0, 1] = 98, 99                                  # the empty prompt: [SOT, EOT, 0...]
+    g = torch.Generator().manual_seed(7)
+    tokens[1, 0] = 98
+    tokens[1, 1:40] = torch.randint(1, 98, (39,), generator=g)
+    tokens[1, 40] = 99
+    out = m(input_ids=tokens, output_hidden_states=True)
+    pen = m.final_layer_norm(out.hidden_states[-2])          # (transformers 5.x: CLIPTextModel owns the tower directly)
+    save("g_text_hf", tokens=tokens, last=out.last_hidden_state, penultimate=pen, names_shapes=names_shapes(m))
+
+
 def gen_spliter():
     ui = ref_import.ref("scripts.util_image")
     out = {}

@@ -219,8 +219,9 @@ def test_product_path_never_imports_oracle():
 
 def test_text_oracle_matches_module_forward():
     """oracle/text.py vs the same tower evaluated through its nn modules the way open_clip's ResidualAttentionBlock does
-    (x += attn(ln_1(x), attn_mask); x += mlp(ln_2(x))).  open_clip itself is not installed: parity against the reference's
-    dependency is unpinned (see oracle/text.py); this pins the functional restatement to torch's own MultiheadAttention."""
+    (x += attn(ln_1(x), attn_mask); x += mlp(ln_2(x))).  open_clip itself is not installed (oracle/text.py): this pins the
+    functional restatement to torch's own MultiheadAttention, tests/test_oracle_golden.py::test_text_tower_golden pins it to
+    transformers' CLIPTextModel."""
     import torch
     from mgld_vsr_amd import synth
     from mgld_vsr_amd.text import FrozenOpenCLIPEmbedder

@@ -152,3 +152,32 @@ def test_raft_golden():
             assert rel_l2(oraft.raft_sr(sd, b, a, iters), g[f"fwd{iters}"]) < 1e-4
         ff, fb = oraft.compute_flow(sd, lrs, iters=1)
         assert ff.shape == (1, t - 1, 2, h, w) and rel_l2(fb[0], g["bwd1"]) < 1e-4
+
+
+def _openclip_names_from_hf(hf, heads_unused=None):
+    """HF CLIPTextModel parameter names -> open_clip text-tower names (what FrozenOpenCLIPEmbedder's checkpoint holds)"""
+    sd = {"model.token_embedding.weight": hf["embeddings.token_embedding.weight"],
+          "model.positional_embedding": hf["embeddings.position_embedding.weight"],
+          "model.ln_final.weight": hf["final_layer_norm.weight"], "model.ln_final.bias": hf["final_layer_norm.bias"]}
+    n_layers = 1 + max(int(k.split(".")[2]) for k in hf if k.startswith("encoder.layers."))
+    for i in range(n_layers):
+        s, d = f"encoder.layers.{i}.", f"model.transformer.resblocks.{i}."
+        for wb in ("weight", "bias"):
+            sd[d + "attn.in_proj_" + wb] = torch.cat([hf[s + f"self_attn.{p}_proj.{wb}"] for p in "qkv"], 0)
+            sd[d + "attn.out_proj." + wb] = hf[s + "self_attn.out_proj." + wb]
+            sd[d + "ln_1." + wb], sd[d + "ln_2." + wb] = hf[s + "layer_norm1." + wb], hf[s + "layer_norm2." + wb]
+            sd[d + "mlp.c_fc." + wb], sd[d + "mlp.c_proj." + wb] = hf[s + "mlp.fc1." + wb], hf[s + "mlp.fc2." + wb]
+    return sd
+
+
+def test_text_tower_golden():
+    """oracle/text.py (the FrozenOpenCLIPEmbedder restatement) == transformers' CLIPTextModel — the class the reference's own
+    FrozenCLIPEmbedder binds and an independent implementation of the same text tower — on the same synthetic weights, for
+    both layer choices (`last`, `penultimate`), the empty prompt and a 40-token prompt"""
+    from oracle import text as otext
+    g = G("g_text_hf")
+    sd = _openclip_names_from_hf(sd_from(g, "names_shapes", "text_hf"))
+    tokens = g["tokens"].long()
+    with torch.no_grad():
+        assert rel_l2(otext.encode_with_transformer(sd, tokens, heads=4, layer_idx=0), g["last"]) < 1e-5
+        assert rel_l2(otext.encode_with_transformer(sd, tokens, heads=4, layer_idx=1), g["penultimate"]) < 1e-5
