@@ -17,6 +17,7 @@ from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL  # noqa: E402
 class Recorder:
     def __init__(self):
         self.calls = []
+        self.tiled = []
 
     def ptrs(self):
         return [(name, tuple(p)) for name, p in self.calls]
@@ -60,6 +61,9 @@ def dry(monkeypatch):
             assert rowvec.shape[0] >= (M + rows_per_frame - 1) // rows_per_frame
         if resid is not None:
             assert resid.shape[0] >= M and resid.shape[1] >= n_out and resid.dtype == torch.float16
+        if tap_inner == 2:   # tiled conv weights: [ceil(N/64)*64 * 9*Cin/32 rows of 32]
+            assert mode == hip.MODE_CONV3X3 and w.shape == ((N + 63) // 64 * 64 * K // 32, 32), (w.shape, N, K)
+            rec.tiled.append((N, K))
         rec.calls.append(("igemm", (a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K)))
         return out
 
@@ -112,6 +116,36 @@ def test_unet_structcond_launch_plan(dry):
     same = sum(1 for a, b in zip(first, second) if a == b)
     assert same >= len(first) - 8, (same, len(first))   # only the host->device input staging tensors may move
     assert sum(1 for c in first if c[0] == "attention") == 2 * 16  # 16 transformer blocks: self + cross
+
+
+def test_unet_launch_plan_with_tiled_conv_weights(dry, monkeypatch):
+    """the engine re-lays the weights of every convolution the library's patch kernel would take (here: a stand-in for the
+    planner with the same geometry rule) and passes them as tap_inner = 2 with explicit N / K; repeated forwards reuse the
+    cached tiles (identical weight pointers)"""
+    eng, rec = dry
+    from mgld_vsr_amd import hip
+    from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
+    monkeypatch.setattr(hip, "conv3p_applies", lambda frames, cin, cout, h, w: w % 16 == 0 and w <= 64 and (h * w) % 128 == 0
+                        and cin % 32 == 0 and cout > 32)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    unet, sc = InflatedUNetModelDualcondV2(**UNET_SMALL), InflatedEncoderUNetModelWT(**STRUCT_SMALL)
+    unet.set_engine(eng)
+    sc.set_engine(eng)
+    x, t = torch.randn(T, 4, 16, 16), torch.tensor([541] * T)
+    scd = sc(x, t)
+    ctx = torch.randn(1, 77, 64)
+    unet(x, t, context=ctx, struct_cond=scd)
+    n_tiled = len(rec.tiled)
+    assert n_tiled > 0                                   # the 16x16-level ResBlock convolutions (64 / 128 channels)
+    n0, t0 = len(rec.calls), len(rec.tiled)
+    unet(x, t, context=ctx, struct_cond=scd)
+    first, tiled_first = rec.ptrs()[n0:], len(rec.tiled) - t0
+    n1, t1 = len(rec.calls), len(rec.tiled)
+    unet(x, t, context=ctx, struct_cond=scd)
+    second, tiled_second = rec.ptrs()[n1:], len(rec.tiled) - t1
+    same = sum(1 for a, b in zip(first, second) if a == b)
+    assert same >= len(first) - 8, (same, len(first))
+    assert tiled_first == tiled_second > 0 and len(eng._c3p_w) > 0
 
 
 def test_vae_launch_plan(dry):
