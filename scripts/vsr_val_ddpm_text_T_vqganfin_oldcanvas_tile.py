@@ -41,33 +41,60 @@ def read_image(path):
     return (t - 0.5) / 0.5
 
 
-def parse():
+# option names and defaults as in the reference script (:134-:262)
+REF_CONFIG = "configs/stable-diffusion/v1-inference.yaml"
+REF_CKPT = "checkpoints/stablevsr_025.ckpt"
+REF_VQGAN_CKPT = "checkpoints/vqgan_cfw_00011.ckpt"
+
+
+def parse(argv=None):
     p = argparse.ArgumentParser()
-    p.add_argument("--seqs-path", type=str, required=True, help="dir with one sub-dir of LR PNG frames per sequence")
-    p.add_argument("--flows-path", type=str, default=None)
-    p.add_argument("--outdir", type=str, default="outputs/user_upload")
-    p.add_argument("--ddpm_steps", type=int, default=50)
+    p.add_argument("--seqs-path", type=str, nargs="?", default="inputs/user_upload",
+                   help="dir with one sub-dir of LR PNG frames per sequence")
+    p.add_argument("--flows-path", type=str, default=None, help="(extension) precomputed flows instead of RAFT_SR")
+    p.add_argument("--outdir", type=str, nargs="?", default="outputs/user_upload")
+    p.add_argument("--device", type=str, default="cuda", help="accepted for compatibility; this path runs on the HIP device only")
+    p.add_argument("--ddpm_steps", type=int, default=1000)
+    p.add_argument("--n_iter", type=int, default=1, help="accepted for compatibility (unused by the reference script as well)")
+    p.add_argument("--C", type=int, default=4, help="latent channels (4)")
+    p.add_argument("--f", type=int, default=8, help="downsampling factor (8)")
     p.add_argument("--n_frames", type=int, default=5)
     p.add_argument("--n_samples", type=int, default=1)
-    p.add_argument("--config", type=str, default=None, help="diffusion YAML (model: section); default = shipped hyper-parameters")
-    p.add_argument("--vqgan_config", type=str, default=None)
-    p.add_argument("--ckpt", type=str, default=None)
-    p.add_argument("--vqgan_ckpt", type=str, default=None)
+    p.add_argument("--config", type=str, default=REF_CONFIG,
+                   help="diffusion YAML (model: section); the shipped hyper-parameters when the default file is absent")
+    p.add_argument("--vqgan_config", type=str, default=None, help="(extension) video-VAE YAML; default = shipped hyper-parameters")
+    p.add_argument("--ckpt", type=str, default=REF_CKPT, help="synthetic weights (with a warning) when the default file is absent")
+    p.add_argument("--vqgan_ckpt", type=str, default=REF_VQGAN_CKPT)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--precision", type=str, default="autocast", choices=["full", "autocast"])
     p.add_argument("--select_idx", type=int, default=0)
     p.add_argument("--n_gpus", type=int, default=1)
-    p.add_argument("--dec_w", type=float, default=1.0)
+    p.add_argument("--dec_w", type=float, default=0.5)
     p.add_argument("--tile_overlap", type=int, default=32)
     p.add_argument("--upscale", type=float, default=4.0)
-    p.add_argument("--colorfix_type", type=str, default="adain", choices=["adain", "wavelet", "nofix"])
+    p.add_argument("--colorfix_type", type=str, default="nofix", choices=["adain", "wavelet", "nofix"])
     p.add_argument("--vqgantile_stride", type=int, default=750)
     p.add_argument("--vqgantile_size", type=int, default=960)
-    p.add_argument("--guidance_scale", type=float, default=-10.0)
+    p.add_argument("--guidance_scale", type=float, default=-10.0, help="(extension) the reference hard-codes -10")
     p.add_argument("--latent-dir", type=str, default=None,
                    help="also dump the sampled latents, one <frame>.npy [4,h,w] per frame (what vsr_val_ddpm_text_T_vqganfin_w_latent.py"
                         ":389-397 writes for the stage-2 VAE-decoder training); frames that fit one patch only")
-    return p.parse_args()
+    opt = p.parse_args(argv)
+    if opt.device != "cuda":
+        p.error("--device: only 'cuda' (the HIP device) is supported; there is no CPU path")
+    if opt.C != 4 or opt.f != 8:
+        p.error("--C / --f: the SD-2.1 latent space of this path is 4 channels at 1/8 resolution")
+    # the reference's default files are not shipped: fall back to the built-in hyper-parameters / synthetic weights when a
+    # DEFAULT path is absent; an explicitly given path must exist
+    for name, ref in (("config", REF_CONFIG), ("ckpt", REF_CKPT), ("vqgan_ckpt", REF_VQGAN_CKPT)):
+        v = getattr(opt, name)
+        if v is not None and not os.path.exists(v):
+            if v == ref:
+                print(f"[mgld] --{name}: default file {ref} not found -> built-in {'hyper-parameters' if name == 'config' else 'synthetic weights'}")
+                setattr(opt, name, None)
+            else:
+                p.error(f"--{name}: {v} does not exist")
+    return opt
 
 
 def main():

@@ -23,8 +23,8 @@ def test_cli_runs_on_png_sequence(tmp_path):
         Image.fromarray((im * 255).astype(np.uint8)).save(seq / f"{i:03d}.png")
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py"), "--seqs-path",
-           str(tmp_path / "seqs"), "--outdir", str(out), "--ddpm_steps", "2", "--n_frames", "2", "--latent-dir",
-           str(tmp_path / "lat")]
+           str(tmp_path / "seqs"), "--outdir", str(out), "--ddpm_steps", "2", "--n_frames", "2", "--dec_w", "1.0", "--colorfix_type",
+           "adain", "--device", "cuda", "--latent-dir", str(tmp_path / "lat")]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]

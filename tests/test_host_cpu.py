@@ -66,6 +66,33 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
             assert int(got[f"{name}.{f}"]) == getattr(cls, f).offset, (name, f)
 
 
+def test_cli_option_surface_matches_the_reference_script(capsys):
+    """every option of scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py (reference :134-:262) is accepted with the
+    reference's default; the defaults that name files the reference ships fall back to built-ins when absent"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cli", os.path.join(ROOT, "scripts", "vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    o = cli.parse([])
+    ref_defaults = dict(seqs_path="inputs/user_upload", outdir="outputs/user_upload", device="cuda", ddpm_steps=1000, n_iter=1, C=4,
+                        f=8, n_frames=5, n_samples=1, seed=42, precision="autocast", select_idx=0, n_gpus=1, dec_w=0.5,
+                        tile_overlap=32, upscale=4.0, colorfix_type="nofix", vqgantile_stride=750, vqgantile_size=960)
+    for k, v in ref_defaults.items():
+        assert getattr(o, k) == v, k
+    assert (cli.REF_CONFIG, cli.REF_CKPT, cli.REF_VQGAN_CKPT) == ("configs/stable-diffusion/v1-inference.yaml",
+                                                                 "checkpoints/stablevsr_025.ckpt", "checkpoints/vqgan_cfw_00011.ckpt")
+    assert o.config is None and o.ckpt is None and o.vqgan_ckpt is None      # default files absent here -> built-ins
+    o = cli.parse(["--seqs-path", "a", "--outdir", "b", "--ddpm_steps", "50", "--n_iter", "1", "--C", "4", "--f", "8", "--n_frames", "5",
+                   "--n_samples", "1", "--seed", "1", "--precision", "full", "--select_idx", "1", "--n_gpus", "2", "--dec_w", "1.0",
+                   "--tile_overlap", "32", "--upscale", "4", "--colorfix_type", "adain", "--vqgantile_stride", "750",
+                   "--vqgantile_size", "960", "--device", "cuda"])
+    assert o.select_idx == 1 and o.n_gpus == 2 and o.colorfix_type == "adain"
+    for bad in (["--device", "cpu"], ["--C", "8"], ["--ckpt", "/nonexistent/x.ckpt"]):
+        with pytest.raises(SystemExit):
+            cli.parse(bad)
+    capsys.readouterr()
+
+
 def test_unet_state_dict_contract():
     from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
     g = G("g_unet")
