@@ -208,6 +208,20 @@ class LatentDiffusionVSRTextWT(nn.Module):
         return (extract_into_tensor(sqrt_alphas_cumprod.to(dev), t.to(dev), x_start.shape) * x_start +
                 extract_into_tensor(sqrt_one_minus_alphas_cumprod.to(dev), t.to(dev), x_start.shape) * noise)
 
+    # ---- schedule helpers inherited from DDPM in the reference (ddpm.py:340-353, 398-401): gathers over the fp32 buffers --
+    def _gather(self, name, t, like):
+        return extract_into_tensor(getattr(self, name).to(like.device), t.to(like.device), like.shape)
+
+    def q_sample(self, x_start, t, noise=None):
+        return self.q_sample_respace(x_start, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, noise)
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return self._gather("sqrt_recip_alphas_cumprod", t, x_t) * x_t - self._gather("sqrt_recipm1_alphas_cumprod", t, x_t) * noise
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = self._gather("posterior_mean_coef1", t, x_t) * x_start + self._gather("posterior_mean_coef2", t, x_t) * x_t
+        return mean, self._gather("posterior_variance", t, x_t), self._gather("posterior_log_variance_clipped", t, x_t)
+
     def compute_flow(self, lrs):
         """ddpm.py:3404-3429: lrs [n,t,3,h,w] in [0,1] -> (flows_forward, flows_backward), each [n,t-1,2,h,w].  Both
         directions go through the flow network (RAFT_SR, mgld_vsr_amd/raft.py) as one batch of frame pairs."""
@@ -535,6 +549,31 @@ class LatentDiffusionVSRTextWT(nn.Module):
             cond = cond[:batch_size]
         return self._sample_loop(cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
                                  return_intermediates, None, noise, None, use_graph)
+
+    @torch.no_grad()
+    def p_sample_loop(self, cond, struct_cond, shape, guidance_scale=-1.0, lr_images=None, flows=None, masks=None,
+                      return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None, quantize_denoised=False,
+                      mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, time_replace=None, adain_fea=None,
+                      interfea_path=None):
+        """ddpm.py:4501-4616, the loop `sample` enters: same arguments; the whole loop runs as the captured step graph, so the
+        per-step hooks (callback / img_callback) and the inpainting / feature-dump options are refused rather than ignored."""
+        self._check_unsupported(lr_images=lr_images, callback=callback, mask=mask, x0=x0, img_callback=img_callback,
+                                start_T=start_T, adain_fea=adain_fea, interfea_path=interfea_path)
+        return self._sample_loop(cond, struct_cond, tuple(shape), guidance_scale, flows, masks, x_T, timesteps, time_replace,
+                                 return_intermediates, log_every_t, None, None, True)
+
+    @torch.no_grad()
+    def p_sample_loop_canvas(self, cond, struct_cond, shape, guidance_scale=-1.0, lr_images=None, flows=None, masks=None,
+                             return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
+                             quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None,
+                             time_replace=None, adain_fea=None, interfea_path=None, tile_size=64, tile_overlap=32, batch_size=4):
+        """ddpm.py:4619-4693, the loop `sample_canvas` enters (`batch_size` = tiles per UNet pass in the reference; here every
+        tile of a step goes through one pass)."""
+        assert tile_size is not None
+        self._check_unsupported(lr_images=lr_images, callback=callback, mask=mask, x0=x0, img_callback=img_callback,
+                                start_T=start_T, adain_fea=adain_fea, interfea_path=interfea_path)
+        return self._sample_loop(cond, struct_cond, tuple(shape), guidance_scale, flows, masks, x_T, timesteps, time_replace,
+                                 return_intermediates, log_every_t, None, (tile_size, tile_overlap), True)
 
     @torch.no_grad()
     def sample_canvas(self, cond, struct_cond, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, batch_size=16,

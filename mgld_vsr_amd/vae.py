@@ -386,11 +386,13 @@ class AutoencoderKL(_AutoencoderBase):
         return super().load_state_dict({k: v for k, v in sd.items() if k in own or not k.startswith("decoder.")}, strict=strict)
 
     @torch.no_grad()
-    def encode(self, x):
+    def encode(self, x, return_encfea=False):
+        """autoencoder.py:347-353: the posterior, plus the moments tensor it was built from when `return_encfea`"""
         eng = self.engine()
         eng.reset()
         m, _ = self._moments(eng, x.to(eng.device, torch.float32))
-        return DiagonalGaussianDistribution(m)
+        posterior = DiagonalGaussianDistribution(m)
+        return (posterior, m) if return_encfea else posterior
 
 
 class VideoAutoencoderKLResi(_AutoencoderBase):

@@ -171,6 +171,35 @@ def test_model_schedule_matches_reference(S):
     assert torch.equal(out, g["qs_out"])
 
 
+def test_ddpm_helper_surface():
+    """the schedule helpers the reference class inherits from DDPM (q_sample, predict_start_from_noise, q_posterior:
+    ddpm.py:340-353, 398-401) and the two loop entry points behind sample / sample_canvas exist with the reference's
+    argument lists; the helpers are buffer gathers and invert each other"""
+    import inspect
+    model = _small_model()
+    model.register_schedule(given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.0120,
+                            cosine_s=8e-3)
+    x0, eps = torch.randn(3, 4, 8, 8), torch.randn(3, 4, 8, 8)
+    t = torch.tensor([10, 500, 999])
+    xt = model.q_sample(x0, t, eps)
+    a = model.sqrt_alphas_cumprod[t].view(3, 1, 1, 1)
+    b = model.sqrt_one_minus_alphas_cumprod[t].view(3, 1, 1, 1)
+    assert torch.equal(xt, a * x0 + b * eps)
+    assert torch.allclose(model.predict_start_from_noise(xt, t, eps), x0, atol=2e-3)   # sqrt(1/ac - 1) reaches ~240 at t = 999
+    mean, var, logvar = model.q_posterior(x0, xt, t)
+    c1, c2 = model.posterior_mean_coef1[t].view(3, 1, 1, 1), model.posterior_mean_coef2[t].view(3, 1, 1, 1)
+    assert torch.equal(mean, c1 * x0 + c2 * xt) and var.shape == (3, 1, 1, 1)
+    assert torch.equal(logvar.flatten(), model.posterior_log_variance_clipped[t])
+    ref_loop = ["cond", "struct_cond", "shape", "guidance_scale", "lr_images", "flows", "masks", "return_intermediates", "x_T",
+                "verbose", "callback", "timesteps", "quantize_denoised", "mask", "x0", "img_callback", "start_T", "log_every_t",
+                "time_replace", "adain_fea", "interfea_path"]
+    sig = lambda f: [k for k in inspect.signature(f).parameters if k != "self"]
+    assert sig(model.p_sample_loop) == ref_loop                                          # ddpm.py:4501-4505
+    assert sig(model.p_sample_loop_canvas) == ref_loop + ["tile_size", "tile_overlap", "batch_size"]   # ddpm.py:4619-4623
+    with pytest.raises(NotImplementedError):
+        model.p_sample_loop(None, None, (3, 4, 8, 8), callback=lambda i: None)
+
+
 def test_tiling_geometry_and_weights():
     g = G("g_sample")
     model = _small_model()
