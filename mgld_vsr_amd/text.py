@@ -66,9 +66,15 @@ class FrozenOpenCLIPEmbedder(nn.Module):
         self._context = None
         self._engine = None
         self.model = _TextTower(vocab_size, max_length, context_dim, layers, self.heads) if build_tower else None
-        if freeze and self.model is not None:
-            for p in self.parameters():
-                p.requires_grad = False
+        if freeze:
+            self.freeze()
+
+    def freeze(self):
+        """modules.py:167-170"""
+        if self.model is not None:
+            self.model = self.model.eval()
+        for p in self.parameters():
+            p.requires_grad = False
 
     def set_context(self, ctx):
         """install a precomputed empty-prompt embedding [1,77,context_dim]"""
