@@ -303,6 +303,40 @@ def gen_text_hf():
     save("g_text_hf", tokens=tokens, last=out.last_hidden_state, penultimate=pen, names_shapes=names_shapes(m))
 
 
+def gen_signatures():
+    """Argument lists of the reference's public entry points on this path (interface data for the drop-in check in
+    tests/test_host_cpu.py::test_drop_in_signatures): read with `ast` from the reference sources, nothing is imported."""
+    import ast
+    want = {
+        "ldm/models/diffusion/ddpm.py": {"LatentDiffusionVSRTextWT": ["sample", "sample_canvas", "p_sample_loop", "p_sample_loop_canvas", "compute_flow",
+                                                                      "compute_temporal_condition_v4", "apply_model", "get_learned_conditioning",
+                                                                      "encode_first_stage", "_gaussian_weights"],
+                                         "DDPM": ["q_sample", "q_sample_respace", "predict_start_from_noise", "q_posterior", "register_schedule"]},
+        "ldm/modules/diffusionmodules/openaimodel.py": {"InflatedUNetModelDualcondV2": ["forward"], "InflatedEncoderUNetModelWT": ["forward"]},
+        "ldm/models/autoencoder.py": {"VideoAutoencoderKLResi": ["encode", "decode", "init_from_ckpt"], "AutoencoderKL": ["encode", "init_from_ckpt"]},
+        "ldm/modules/encoders/modules.py": {"FrozenOpenCLIPEmbedder": ["__init__", "freeze", "forward", "encode", "encode_with_transformer"]},
+        "scripts/util_image.py": {"ImageSpliterTh": ["__init__", "extract_starts", "update", "gather"]},
+        "basicsr/archs/raft_arch.py": {"RAFT_SR": ["__init__", "forward"]},
+        "basicsr/archs/arch_util.py": {None: ["flow_warp", "resize_flow"]},
+        "scripts/util_flow.py": {None: ["forward_backward_consistency_check"]},
+        "scripts/wavelet_color_fix.py": {None: ["adaptive_instance_normalization", "wavelet_reconstruction"]},   # what the scripts import
+    }
+    out = {}
+    for rel, classes in want.items():
+        tree = ast.parse(open(os.path.join(ref_import.REF, rel)).read())
+        for cname, fns in classes.items():
+            body = tree.body if cname is None else next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cname).body
+            for f in body:
+                if isinstance(f, ast.FunctionDef) and f.name in fns:
+                    args = [a.arg for a in f.args.args if a.arg != "self"]
+                    out[f"{rel}:{cname or ''}:{f.name}"] = args
+    missing = [f"{rel}:{c or ''}:{f}" for rel, cl in want.items() for c, fs in cl.items() for f in fs if f"{rel}:{c or ''}:{f}" not in out]
+    assert not missing, missing
+    with open(os.path.join(HERE, "g_signatures.json"), "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print("wrote g_signatures.json", len(out))
+
+
 def gen_spliter():
     ui = ref_import.ref("scripts.util_image")
     out = {}

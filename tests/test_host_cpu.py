@@ -200,6 +200,39 @@ def test_ddpm_helper_surface():
         model.p_sample_loop(None, None, (3, 4, 8, 8), callback=lambda i: None)
 
 
+def test_drop_in_signatures():
+    """every public entry point of the reference on this path exists here under the same dotted name and takes the
+    reference's arguments in the reference's order (tests/golden/g_signatures.json, read from the reference sources with
+    `ast` by make_golden.py); this side may only append optional extras (noise=, use_graph=, **kw)"""
+    import importlib
+    import inspect
+    import json
+    with open(os.path.join(HERE, "golden", "g_signatures.json")) as fh:
+        ref = json.load(fh)
+    problems = []
+    for key, want in ref.items():
+        rel, cname, fname = key.split(":")
+        mod = importlib.import_module(rel[:-3].replace("/", "."))
+        owner = getattr(mod, cname) if cname and cname != "DDPM" else (
+            importlib.import_module("ldm.models.diffusion.ddpm").LatentDiffusionVSRTextWT if cname == "DDPM" else mod)
+        fn = getattr(owner, fname, None)
+        if fn is None:
+            problems.append(f"missing {key}")
+            continue
+        sig = inspect.signature(fn)
+        have = [k for k, p in sig.parameters.items() if k != "self" and p.kind not in (p.VAR_POSITIONAL, p.VAR_KEYWORD)]
+        renamed_ok = {("encode_with_transformer", "text"): "tokens"}      # the reference passes token ids under the name `text`
+        have_cmp = have[:len(want)]
+        want_cmp = [renamed_ok.get((fname, w), w) for w in want]
+        if have_cmp != want_cmp:
+            problems.append(f"{key}: reference {want} / here {have}")
+            continue
+        for extra in have[len(want):]:
+            if sig.parameters[extra].default is inspect.Parameter.empty:
+                problems.append(f"{key}: extra required argument {extra}")
+    assert not problems, "\n".join(problems)
+
+
 def test_tiling_geometry_and_weights():
     g = G("g_sample")
     model = _small_model()
