@@ -27,13 +27,16 @@ torch.set_grad_enabled(False)
 torch.set_num_threads(8)
 
 
+OUT = os.environ.get("MGLD_GOLDEN_OUT", HERE)     # the regenerate-and-compare test writes into a temp dir
+
+
 def save(name, **arrs):
     out = {}
     for k, v in arrs.items():
         if isinstance(v, torch.Tensor):
             v = v.detach().cpu().numpy()
         out[k] = v
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
@@ -332,18 +335,32 @@ def gen_signatures():
                     out[f"{rel}:{cname or ''}:{f.name}"] = args
     missing = [f"{rel}:{c or ''}:{f}" for rel, cl in want.items() for c, fs in cl.items() for f in fs if f"{rel}:{c or ''}:{f}" not in out]
     assert not missing, missing
-    with open(os.path.join(HERE, "g_signatures.json"), "w") as fh:
+    with open(os.path.join(OUT, "g_signatures.json"), "w") as fh:
         json.dump(out, fh, indent=0, sort_keys=True)
     print("wrote g_signatures.json", len(out))
 
 
 def gen_spliter():
+    """ImageSpliterTh of the reference (scripts/util_image.py:686-769): start lists for the script's default patch settings
+    and ragged sizes, and — on a small 2-frame image — the iteration order (patches + index tuples), update() accumulation
+    and the uniform-count gather(), with sf = 1 and sf = 2."""
     ui = ref_import.ref("scripts.util_image")
     out = {}
-    for L, size, stride in [(1024, 960, 750), (512, 960, 750), (2000, 960, 750), (100, 64, 32)]:
+    for L, size, stride in [(1024, 960, 750), (512, 960, 750), (2000, 960, 750), (100, 64, 32), (960, 960, 750), (961, 960, 750)]:
         sp = ui.ImageSpliterTh(torch.zeros(1, 1, L, L + 8), size, stride, sf=1)
         out[f"h_{L}_{size}_{stride}"] = np.array(sp.height_starts_list)
         out[f"w_{L}_{size}_{stride}"] = np.array(sp.width_starts_list)
+    for sf in (1, 2):
+        im = synth.synth_tensor(f"spliter/im{sf}", (2, 3, 40, 52))
+        sp = ui.ImageSpliterTh(im, 24, 16, sf=sf)
+        idx, k = [], 0
+        for pch, index_infos in sp:
+            # stand-in for the per-patch model: a smooth function of the patch, upsampled by sf
+            res = torch.nn.functional.interpolate(pch * (1.0 + 0.1 * k) + 0.01 * k, scale_factor=sf, mode="nearest")
+            sp.update(res, index_infos)
+            idx.append(list(index_infos))
+            k += 1
+        out[f"it_im_sf{sf}"], out[f"it_index_sf{sf}"], out[f"it_gather_sf{sf}"] = im, np.array(idx), sp.gather()
     save("g_spliter", **out)
 
 
@@ -355,10 +372,7 @@ if __name__ == "__main__":
     gen_raft()
     gen_flow()
     gen_guidance()
-    try:
-        gen_spliter()
-    except Exception as e:  # util_image imports optional deps
-        print("spliter fixture skipped:", repr(e))
+    gen_spliter()
     gen_vae()
     model, ddpm = build_ref_model()
     gen_schedule(model)

@@ -60,6 +60,7 @@ def install():
     tv.models = _mod("torchvision.models")
 
     _mod("cv2")
+    _mod("skimage", img_as_ubyte=None, img_as_float32=None)
     _mod("taming")
     _mod("taming.modules")
     _mod("taming.modules.vqvae")
@@ -93,6 +94,16 @@ def install():
         sys.modules[name] = m
         return m
 
+    # `ldm` and `scripts` are namespace packages in the reference (no __init__.py) while the repo root holds regular packages
+    # of the same names (the product's drop-in surface).  Pin both names to the reference tree explicitly, so that whatever
+    # sys.path order the caller has, `ldm.*` / `scripts.*` imported through this shim are the reference's files.
+    for top in ("ldm", "scripts"):
+        stale = [k for k in sys.modules if k == top or k.startswith(top + ".")]
+        for k in stale:
+            f = getattr(sys.modules[k], "__file__", None) or ""
+            if not f.startswith(REF):
+                del sys.modules[k]
+        pkg(top, os.path.join(REF, top))
     b = pkg("basicsr", os.path.join(REF, "basicsr"))
     b.archs = pkg("basicsr.archs", os.path.join(REF, "basicsr", "archs"))
     b.ops = pkg("basicsr.ops", os.path.join(REF, "basicsr", "ops"))
@@ -118,5 +129,10 @@ def install():
 
 
 def ref(modname):
+    """import a module of the reference tree; refuses anything that does not resolve to a file under REF"""
     install()
-    return importlib.import_module(modname)
+    m = importlib.import_module(modname)
+    f = os.path.realpath(getattr(m, "__file__", None) or "")
+    if not f.startswith(os.path.realpath(REF) + os.sep):
+        raise RuntimeError(f"ref_import.ref('{modname}') resolved to {f or '<no file>'}, not to the reference tree {REF}")
+    return m

@@ -312,12 +312,36 @@ def test_conv3p_planner_routes_the_unet_convolutions():
     assert not hip.conv3p_applies(8, 1280, 1280, 8, 8)
 
 
-def test_spliter_starts():
+def _spliter_case(ImageSpliterTh, g, sf, to_dev=lambda t: t):
+    """replay the generator's per-patch stand-in model (tests/golden/make_golden.py::gen_spliter) through a spliter class"""
+    import torch.nn.functional as F
+    im = torch.from_numpy(g[f"it_im_sf{sf}"])
+    sp = ImageSpliterTh(to_dev(im), 24, 16, sf=sf)
+    idx, k = [], 0
+    for pch, index_infos in sp:
+        res = F.interpolate(pch.cpu() * (1.0 + 0.1 * k) + 0.01 * k, scale_factor=sf, mode="nearest")
+        sp.update(to_dev(res), index_infos)
+        idx.append(list(index_infos))
+        k += 1
+    return np.array(idx), sp.gather().cpu()
+
+
+def test_spliter_vs_reference_fixture():
+    """H3: ImageSpliterTh start lists, iteration order, update() and gather() against outputs of the reference class
+    (scripts/util_image.py:686-769) captured in tests/golden/g_spliter.npz"""
     from scripts.util_image import ImageSpliterTh
-    sp = ImageSpliterTh(torch.zeros(1, 1, 1024, 1032), 960, 750, sf=1)
-    assert sp.height_starts_list == [0, 64] and sp.width_starts_list == [0, 72]
-    sp = ImageSpliterTh(torch.zeros(1, 1, 512, 512), 960, 750)
-    assert sp.height_starts_list == [0] and len(sp) == 1
+    g = np.load(os.path.join(HERE, "golden", "g_spliter.npz"))
+    for key in g.files:
+        if key.startswith("h_"):
+            L, size, stride = (int(v) for v in key.split("_")[1:])
+            sp = ImageSpliterTh(torch.zeros(1, 1, L, L + 8), size, stride, sf=1)
+            assert sp.height_starts_list == g[key].tolist(), key
+            assert sp.width_starts_list == g["w" + key[1:]].tolist(), key
+            assert len(sp) == len(g[key]) * len(g["w" + key[1:]])
+    for sf in (1, 2):
+        idx, out = _spliter_case(ImageSpliterTh, g, sf)
+        assert (idx == g[f"it_index_sf{sf}"]).all()
+        assert torch.equal(out, torch.from_numpy(g[f"it_gather_sf{sf}"]))       # same fp32 arithmetic: bit-equal
 
 
 def test_product_path_never_imports_oracle():

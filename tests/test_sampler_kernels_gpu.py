@@ -1,9 +1,16 @@
 """GPU parity: DDPM step, flow warp, motion guidance (closed-form adjoint vs autograd oracle), fb-consistency,
 flow resize, AdaIN / wavelet colour fix, aggregation-sampling tile ops — libmgld_hip (C ABI) vs oracle/ (torch CPU)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
 
 from oracle import colorfix as ocf
 from oracle import flow as oflow
@@ -187,20 +194,23 @@ def test_preproc_png_payload(hip):
     assert (got == ref).all()                                   # integer payload: bit-exact
 
 
-def test_image_spliter_device_matches_host(hip):
-    """scripts.util_image.ImageSpliterTh on device tensors (crop / accumulate / normalise kernels) == the reference's host
-    tensor arithmetic, for the large-frame branch of the script (960-pixel patches, stride 750)."""
+def test_image_spliter_device_vs_reference_fixture(hip):
+    """scripts.util_image.ImageSpliterTh on device tensors (crop / accumulate / normalise kernels) against outputs of the
+    REFERENCE class captured in tests/golden/g_spliter.npz (iteration order, index tuples, uniform-count gather; sf 1 and 2),
+    and — at the script's patch settings (960 / 750) — patch contents against plain slicing of the input."""
+    import numpy as np
     from scripts.util_image import ImageSpliterTh
-    g = torch.Generator().manual_seed(11)
-    im = torch.randn(2, 3, 1024, 1100, generator=g)
-    host, dev = ImageSpliterTh(im, 960, 750, sf=1), ImageSpliterTh(im.cuda(), 960, 750, sf=1)
-    assert len(host) == len(dev) == 4
-    for (ph, ih), (pd, idd) in zip(host, dev):
-        assert ih == idd and torch.equal(pd.cpu(), ph)
-        res = ph * 0.5 + 0.25
-        host.update(res, ih)
-        dev.update(res.cuda(), idd)
-    assert torch.allclose(dev.gather().cpu(), host.gather(), atol=1e-6)
+    from test_host_cpu import _spliter_case
+    g = np.load(os.path.join(HERE, "golden", "g_spliter.npz"))
+    for sf in (1, 2):
+        idx, out = _spliter_case(ImageSpliterTh, g, sf, to_dev=lambda t: t.cuda())
+        assert (idx == g[f"it_index_sf{sf}"]).all()
+        assert torch.allclose(out, torch.from_numpy(g[f"it_gather_sf{sf}"]), atol=1e-6, rtol=0)
+    im = torch.randn(2, 3, 1024, 1100, generator=torch.Generator().manual_seed(11))
+    dev = ImageSpliterTh(im.cuda(), 960, 750, sf=1)
+    assert dev.height_starts_list == g["h_1024_960_750"].tolist() and len(dev) == 4
+    for pd, (h0, h1, w0, w1) in dev:
+        assert torch.equal(pd.cpu(), im[:, :, h0:h1, w0:w1])
 
 
 # ------------------------------------------------------------------------------------------------------------------
