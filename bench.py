@@ -48,14 +48,37 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--spawn-selftest", action="store_true",
+                    help="launcher check without a GPU: start the N ranks, rendezvous, barrier + max-reduce, print the JSON "
+                         "skeleton with the world size the ranks saw (tests/test_parallel_cpu.py)")
+    ap.add_argument("--dump-shapes", default=None, help="write the per-problem table of the roofline pass to this JSON file")
     return ap.parse_args()
 
 
-def dist_setup(n):
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU, the
+    reference's own scheme: N processes, `--n_gpus N --select_idx r`, oldcanvas_tile.py:337-339) by re-executing this file
+    under torch.distributed.run, rendezvous on 127.0.0.1, and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dist_setup(n, backend="nccl"):
     if n <= 1:
         return 0, 1, 0
     from mgld_vsr_amd import parallel
-    return parallel.init(backend="nccl")   # RCCL over xGMI; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun
+    rank, world, local = parallel.init(backend=backend)   # nccl = RCCL over xGMI; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun
+    if world != n:
+        raise SystemExit(f"bench.py --gpus {n}: the process group has {world} ranks")
+    return rank, world, local
 
 
 def build_pipeline(args):
@@ -104,72 +127,96 @@ def igemm_algo_bytes(p):
     return b * (2.0 * a_elems + 2.0 * p.N * p.K + out_b * p.M * n_out + (2.0 * p.M * n_out if p.R else 0.0))
 
 
+HBM_PEAK_GBPS = 8000.0      # HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable with a float4 copy)
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.sh).  PMC counters cannot be read from inside this process;
+    the file is only used when it was taken for THIS kernel name on THIS kernel source (sha256 of csrc/igemm.hip), else null."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            pm = json.load(fh)
+        with open(os.path.join(ROOT, "mgld_vsr_amd", "csrc", "igemm.hip"), "rb") as fh:
+            sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+        ent = pm.get("kernels", {}).get(kernel)
+        if ent and pm.get("igemm_hip_sha16") == sha:
+            return round(ent["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def roofline(pipe, args, frames, noise, flows, masks):
-    """Dominant kernel = the 128x128-tile MFMA implicit GEMM.  Collect every igemm problem of one full pass, then time
-    each distinct problem of that tile config in isolation with hipEvents (10 back-to-back launches on the launch
-    stream) and weight by its launch count:  achieved = sum(flops) / sum(count * avg_duration)."""
+    """One more pass of the same segment with EVERY launch of the GEMM family (implicit-GEMM / patch-conv kernels incl. their
+    split-K reduce), the flash attention and the HBM-bound norm kernels bracketed by hipEvents on the launch stream, IN SEQUENCE
+    (eager launches, the same launch list the hipGraph replays): each kernel is timed where it sits in the pipeline, with its
+    operands in the cache state its producers left them.  Launches are grouped by the kernel instantiation the launcher picked
+    (mgld_igemm_kernel_name: the name rocprofv3 prints), so `roofline` and profiles/r02_kernel_stats.txt describe the same kernels.
+    `roofline` = the kernel with the largest total time."""
     from mgld_vsr_amd import hip
-    hip.IGEMM_LOG = []
+    hip.TIMED = []
     pipe.run_segment(frames, flows=flows, masks=masks, noise=noise, use_graph=False, tile=TILE)
     torch.cuda.synchronize()
-    log, hip.IGEMM_LOG = hip.IGEMM_LOG, None
-    groups = {}
-    for p in log:
-        cfg = hip.igemm_config(p)
-        key = (cfg, p.mode, p.M, p.N, p.K, p.Cin, p.Hin, p.Win, p.stride, p.up2, p.act, max(1, p.batch), p.lda, p.ldc)
-        g = groups.setdefault(key, {"p": p, "count": 0, "flops": hip.igemm_flops(p), "cfg": cfg, "bytes": igemm_algo_bytes(p)})
-        g["count"] += 1
-    tot = {}
-    e0, e1 = hip.Event(), hip.Event()
-    for key, g in groups.items():
-        for _ in range(2):
-            hip.igemm_relaunch(g["p"])
-        e0.record()
-        for _ in range(10):
-            hip.igemm_relaunch(g["p"])
-        e1.record()
-        e1.sync()
-        g["ms"] = e0.elapsed_ms(e1) / 10.0
-        t = tot.setdefault(g["cfg"], {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
-        t["bytes"] += g["bytes"] * g["count"]
-        t["flops"] += g["flops"] * g["count"]
-        t["ms"] += g["ms"] * g["count"]
-        t["launches"] += g["count"]
-    dump = os.path.join(ROOT, "gpurun_out")
-    if os.path.isdir(dump):   # per-problem table for kernel tuning (scratch output, not part of the JSON line)
-        rows = [{"cfg": g["cfg"], "mode": k[1], "M": k[2], "N": k[3], "K": k[4], "Cin": k[5], "H": k[6], "stride": k[8], "up2": k[9],
-                 "act": k[10], "batch": k[11], "count": g["count"], "us": round(1e3 * g["ms"], 2),
-                 "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 1), "total_ms": round(g["ms"] * g["count"], 2)}
-                for k, g in groups.items()]
-        rows.sort(key=lambda r: -r["total_ms"])
-        with open(os.path.join(dump, "igemm_shapes.json"), "w") as fh:
+    recs, hip.TIMED = hip.TIMED, None
+    kern, shapes, hbm = {}, {}, {}
+    for kind, info, e0, e1 in recs:
+        ms = e0.elapsed_ms(e1)
+        if kind == "igemm":
+            p = info
+            name, splits = hip.igemm_kernel_name(p)
+            k = kern.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "splitk_launches": 0})
+            k["flops"] += hip.igemm_flops(p)
+            k["bytes"] += igemm_algo_bytes(p)
+            k["ms"] += ms
+            k["launches"] += 1
+            k["splitk_launches"] += 1 if splits > 1 else 0
+            key = (name, splits, p.mode, p.M, p.N, p.K, p.Cin, p.Hin, p.Win, p.stride, p.up2, p.act, max(1, p.batch))
+            g = shapes.setdefault(key, {"count": 0, "ms": 0.0, "flops": hip.igemm_flops(p)})
+            g["count"] += 1
+            g["ms"] += ms
+        elif kind == "attention":
+            name = f"flash_attn_kernel<{info['d']}>"
+            k = kern.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "splitk_launches": 0})
+            k["flops"] += info["flops"]
+            k["bytes"] += info["bytes"]
+            k["ms"] += ms
+            k["launches"] += 1
+        else:
+            h = hbm.setdefault(kind, {"bytes": 0.0, "ms": 0.0, "launches": 0})
+            h["bytes"] += info["bytes"]
+            h["ms"] += ms
+            h["launches"] += 1
+    rows = [{"kernel": k[0], "splits": k[1], "mode": k[2], "M": k[3], "N": k[4], "K": k[5], "Cin": k[6], "H": k[7], "W": k[8], "stride": k[9],
+             "up2": k[10], "act": k[11], "batch": k[12], "count": g["count"], "us": round(1e3 * g["ms"] / g["count"], 2),
+             "tflops": round(g["flops"] * g["count"] / (g["ms"] * 1e-3) / 1e12, 1), "total_ms": round(g["ms"], 2)} for k, g in shapes.items()]
+    rows.sort(key=lambda r: -r["total_ms"])
+    dump = args.dump_shapes or (os.path.join(ROOT, "gpurun_out", "igemm_shapes.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+    if dump:   # per-problem table (kernel tuning; a copy of the full-width run is committed under profiles/)
+        with open(dump, "w") as fh:
             json.dump(rows, fh, indent=0)
-    dom_cfg = max(tot, key=lambda c: tot[c]["ms"])
-    dom_tile = dom_cfg % 1000000
-    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; they come
-    # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/, see its note)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pm = json.load(fh)
-        if dom_tile < 300000 and f"<{dom_tile // 1000},{dom_tile % 1000}>" in pm.get("kernel", ""):
-            traffic = round(pm["hbm_bytes_per_launch"])
-    except Exception:
-        traffic = None
-    d = tot[dom_cfg]
-    # launcher config codes (mgld_igemm_config): 300000 + BN = the patch-staged 3x3 conv (128 pixels x BN channels per block)
-    kname = f"conv3p_kernel<128,{dom_tile - 300000}>" if dom_tile >= 300000 else f"igemm_kernel<{dom_tile // 1000},{dom_tile % 1000}>"
+    dom = max(kern, key=lambda n: kern[n]["ms"])
+    d = kern[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    all_flops = sum(t["flops"] for t in tot.values())
-    all_ms = sum(t["ms"] for t in tot.values())
+    gemm = [v for n, v in kern.items() if not n.startswith("flash_attn")]
+    all_flops, all_ms = sum(v["flops"] for v in gemm), sum(v["ms"] for v in gemm)
+    by_kernel = [{"kernel": n, "ms_per_segment": round(v["ms"], 2), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                  "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4)}
+                 for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]]
+    hbm_out = {n: {"achieved_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "frac_of_peak": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                   "ms_per_segment": round(v["ms"], 2), "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2)}
+               for n, v in hbm.items()}
     return {
-        "bound": "mfma", "kernel": kname + (f" splitK x{dom_cfg // 1000000}" if dom_cfg >= 1000000 else ""), "achieved": round(achieved, 2),
-        "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
+        "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": _pmc_traffic(dom),
         "algorithmic_bytes": round(d["bytes"] / d["launches"]),   # per launch: every operand element moved once
-        "launches_per_segment": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-        "kernel_ms_per_segment": round(d["ms"], 2),
-        "all_igemm": {"tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "ms_per_segment": round(all_ms, 2),
-                      "gflop_per_segment": round(all_flops / 1e9, 1)},
+        "launches_per_segment": d["launches"], "splitk_launches": d["splitk_launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+        "kernel_ms_per_segment": round(d["ms"], 2), "timing": "hipEvents around every launch, in sequence (eager pass of the same launch list)",
+        "all_gemm": {"tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4),
+                     "ms_per_segment": round(all_ms, 2), "gflop_per_segment": round(all_flops / 1e9, 1)},
+        "by_kernel": by_kernel,
+        "hbm": {"peak_gbps": HBM_PEAK_GBPS, "kernels": hbm_out},   # the HBM-bound list of SURVEY 8(d): achieved = algorithmic bytes / time
     }
 
 
@@ -222,9 +269,23 @@ GRAPH = True
 def main():
     global TILE, GRAPH
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))      # plain `python bench.py --gpus N`: launch the N ranks, rank 0 prints the line
     TILE = (64, 32) if args.tile else None
     GRAPH = not args.no_graph
-    rank, world, local = dist_setup(args.gpus)
+    if args.spawn_selftest:
+        from mgld_vsr_amd import parallel
+        rank, world, local = dist_setup(args.gpus, "gloo")
+        parallel.barrier(sync_device=False)
+        dt = parallel.max_over_ranks(1e-3 * (rank + 1))
+        if rank == 0:
+            print(json.dumps({"metric": "HR frames/sec at 512^2, 50 DDPM steps", "value": None, "n_gpus": world, "selftest": True,
+                              "max_over_ranks_ok": abs(dt - 1e-3 * world) < 1e-9}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+    rank, world, local = dist_setup(args.gpus, args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local)

@@ -94,9 +94,9 @@ typedef struct MgldIGemm {
   int32_t tap_inner;      /* CONV3X3/TCONV3 with Cin % 64 == 0 and no upsample fold: 1 = the K axis of W is ordered
                              (64-channel block, tap, channel) instead of (tap, Cin): all taps of one channel block are
                              consumed back to back, so the shifted re-reads of the input hit L1/L2.
-                             2 = CONV3X3 problems the patch-staged kernel takes (3x3, stride 1, pad 1, same size,
-                             Win % 16 == 0, Win <= 64, Hin*Win % 128 == 0, Cin % 32 == 0, N > 32, no batch; query with
-                             mgld_igemm_config: code % 1000000 >= 300000): W is tiled [ceil(N/64)][Cin/32][3 kernel rows]
+                             2 = CONV3X3 problems a patch-staged kernel takes (3x3, stride 1, pad 1, output = input size or
+                             twice it with up2, Wout >= 16, Hout >= 8, Cin % 32 == 0, N > 32, no batch; query with
+                             mgld_igemm_config on a struct with tap_inner = 2: code % 1000000 >= 300000): W is tiled [ceil(N/64)][Cin/32][3 kernel rows]
                              [4 groups of 16 rows][3 kernel columns][16 rows][32 channels] (rows past N zero; within a
                              16x32 tile the 16-byte slot c of row r holds channels 8*(c ^ ((r>>2)&3)) .. +8, the LDS
                              image), so each 1-KiB DMA piece is one linear read; ldw unused */
@@ -107,13 +107,18 @@ typedef struct MgldIGemm {
   int32_t kh, kw;         /* CONV3X3 mode with a general kernel: kh x kw taps (1..15 each), K = kh*kw*Cin, W laid out
                              [Cout][ky][kx][Cin]; 0,0 (or 3,3) = the 3x3 kernel.  Other sizes use the per-lane gather path
                              (RAFT's 7x7, 1x5, 5x1 and strided 1x1 convolutions, raft_arch.py:216,383-389,430).         */
-  int32_t reserved1;
+  int32_t tune;           /* 0 = the launcher picks the kernel variant.  > 0 (tuning runs / variant tests): force variant
+                             tune - 1 of the 2-D-tile patch conv where it applies (ids: csrc/igemm.hip "conv3q launch plan"). */
 } MgldIGemm;
 
 int mgld_igemm(const MgldIGemm* p, void* stream);
 /* block tile the launcher selects for this problem, encoded BM*1000+BN, plus splits*1000000 when the problem is
  * split along K (profiling / roofline bookkeeping) */
 int mgld_igemm_config(const MgldIGemm* p);
+/* name of the kernel instantiation the launcher runs for this problem, spelled as rocprofv3 --kernel-trace prints it (e.g.
+ * "conv3q_kernel<16, 16, 64, 64, 32, false>"); returns the number of K splits (>= 1) or a negative error.  bench.py groups
+ * its in-sequence hipEvent timings by this name so that `roofline` and profiles/ speak about the same kernel. */
+int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen);
 /* fp32 scratch for split-K partial sums (few output tiles, deep K: the 16x16 / 8x8 UNet levels).  Caller-owned device
  * memory, must stay valid while launches that may use it are in flight / captured; single-stream use.  Without it the
  * launcher falls back to smaller tiles. */

@@ -22,6 +22,7 @@
 //   * problems with too few output tiles for 256 CUs but a deep K (the 16x16 / 8x8 UNet levels: M <= 2048, K up to
 //     23040) are split along K over grid.z into fp32 partials and finished by a small reduce+epilogue kernel.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -64,10 +65,24 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   return x;
 }
 
-// ---- shared tile epilogue (used by igemm_kernel and conv3p_kernel) ---------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// tile-local output row -> global output row m (or -1: the row does not exist)
+struct RowMapLinear {   // BM consecutive rows starting at bm0
+  int bm0, M;
+  __device__ __forceinline__ int operator()(int r) const { const int m = bm0 + r; return m < M ? m : -1; }
+};
+template <int TX>
+struct RowMap2D {       // a TY x TX pixel tile of one frame, raster order inside the tile
+  int fbase, y0, x0, H, W;
+  __device__ __forceinline__ int operator()(int r) const {
+    const int y = y0 + r / TX, x = x0 + (r & (TX - 1));
+    return (y < H && x < W) ? fbase + y * W + x : -1;
+  }
+};
+
+// ---- shared tile epilogue (used by igemm_kernel, conv3p_kernel and conv3q_kernel) ---------------------------------
+template <int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restrict__ ws, const bool splitk, const int kz, const int bz,
-                                              const int bm0, const int bn0, const int wm, const int wn, const int wave,
+                                              const RowMap rmap, const int bn0, const int wm, const int wn, const int wave,
                                               const int lane, f32x16 (&acc)[WN / 32][WM / 32], char* smem) {
   constexpr int MI = WM / 32, NI = WN / 32;
   const int M = p.M, N = p.N;
@@ -121,8 +136,8 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
     // ---- phase 2: patch rows -> epilogue math -> global, 8 columns (16 B of fp16 / 32 B of fp32) per lane ----
     for (int r0 = 0; r0 < 32; r0 += rpi) {
       const int row = r0 + prow;
-      const int m = bm0 + wm * WM + mi * 32 + row;
-      if (row < 32 && m < M && n < Nout) {
+      const int m = row < 32 ? rmap(wm * WM + mi * 32 + row) : -1;
+      if (m >= 0 && n < Nout) {
         const f32x4 a0 = *(const f32x4*)(patch + row * LDW + pcv);
         const f32x4 a1 = *(const f32x4*)(patch + row * LDW + pcv + 4);
         float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -185,7 +200,7 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
 }
 
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const MgldIGemm p, float* __restrict__ ws, int kchunk, int order) {
   constexpr int WAVES_N = BN / WN;
   constexpr int NW = (BM / WM) * (BN / WN);       // waves per block: 4 (256 threads) or 8 (512 threads)
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -200,7 +215,22 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  // Workgroups are dealt round-robin to the 8 XCDs (private L2s) in linear-id order.  order 1: the N/BN blocks that share an A
+  // tile run back to back on ONE XCD (XCD k owns the row tiles k, k+8, ...): A leaves HBM once instead of once per column tile
+  // (big-M / small-N problems: the 64x64-level projections).  order 2: the M/BM blocks that share a W tile run on one XCD (XCD k
+  // owns the column tiles k, k+8, ...): each XCD streams an eighth of the weights (small-M / deep-K problems).  Speed only.
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (order == 1) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    tile_m = xcd + 8 * (j / (int)gridDim.y);
+    tile_n = j % (int)gridDim.y;
+  } else if (order == 2) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    tile_n = xcd + 8 * (j / (int)gridDim.x);
+    tile_m = j % (int)gridDim.x;
+  }
   const int bm0 = tile_m * BM;
   const int bn0 = tile_n * BN;
   const bool splitk = (ws != nullptr);
@@ -499,7 +529,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     }
   }
 
-  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, bm0, bn0, wm, wn, wave, lane, acc, smem);
+  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, RowMapLinear{bm0, M}, bn0, wm, wn, wave, lane, acc, smem);
 }
 
 // ---- conv3p: 3x3 / stride 1 / pad 1 conv with the activation PATCH staged once per 32 input channels -----------------
@@ -703,7 +733,189 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
     }
   }
 #undef MGLD_ISSUE_A
-  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, 0, bm0, bn0, wm, wn, wave, lane, acc, smem);
+  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, 0, RowMapLinear{bm0, p.M}, bn0, wm, wn, wave, lane, acc, smem);
+}
+
+// ---- conv3q: the patch-staged 3x3 / stride 1 / pad 1 conv on 2-D PIXEL TILES -------------------------------------------
+// conv3p above tiles the raster (BM consecutive pixels of one frame): its patch grows with the image width (BM + 2W + 2 rows), so it
+// stops at W = 64, and the wrap of the dx = +-1 taps needs per-lane redirects.  Here a block owns a TY x TX pixel tile and stages the
+// (TY+2) x (TX+2) input patch (with its own halo columns; out-of-image rows zero-filled by the DMA) once per 32-channel slice: any image
+// size (the VAE's 128^2 .. 512^2 levels, non-square frames, ragged edges), and tap (dy, dx) of a lane's pixel is its patch row plus the
+// constant dy*PW + dx — nine per-lane byte offsets computed once.  UP2 folds the nearest-2x upsample of the reference's Upsample blocks
+// (openaimodel.py:185, model.py:96) into those offsets: the block stages the LOW-resolution (TY/2+2) x (TX/2+2) patch (4x fewer bytes)
+// and tap (dy, dx) of output pixel (y, x) reads low-res pixel ((y+dy-1)>>1, (x+dx-1)>>1); zero padding of the upsampled image falls on
+// out-of-image low-res pixels.  256-pixel tiles (16x16, 8x32) run eight waves of 64 pixels x 32 channels: 3 fragment reads per 2 MFMAs
+// instead of 2 per 1 and half the weight bytes per FLOP of the 128-pixel tiles.  Weights: the tiled layout of tap_inner = 2 only.
+template <int TY, int TX, int BN, int WM, int WN, bool UP2>
+__global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kernel(const MgldIGemm p, float* __restrict__ ws, int hchunk,
+                                                                                  int tiles_x, int tiles_y) {
+  constexpr int BM = TY * TX;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int NW = (BM / WM) * WAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int PW = UP2 ? TX / 2 + 2 : TX + 2, PH = UP2 ? TY / 2 + 2 : TY + 2;
+  constexpr int PR = PW * PH;                   // patch rows (one 64-B LDS row per input pixel and slice)
+  constexpr int NPA = (PR + 15) / 16;           // 1-KiB DMA pieces per patch
+  constexpr int ASLOTS = (NPA + NW - 1) / NW;   // pieces per wave; slot s is issued during stage s of the previous slice
+  constexpr int A_BYTES = NPA * 1024;
+  constexpr int BSUB = BN * PB, B_BYTES = 3 * BSUB, NPB = 3 * BN / 16, BSLOTS = (NPB + NW - 1) / NW;
+  constexpr int B_BASE = 2 * A_BYTES;
+  static_assert(NW == 4 || NW == 8, "four or eight waves per block");
+  static_assert(ASLOTS <= 3, "the patch must arrive within the three stages of a slice");
+  static_assert((TX & (TX - 1)) == 0 && TX >= 8 && (TY % 2) == 0 && BM % WM == 0 && BN % 64 == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if ((gridDim.x & 7) == 0) {   // the N/BN blocks sharing a patch run back to back on one XCD (see conv3p)
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    tile_m = xcd + 8 * (j / (int)gridDim.y);
+    tile_n = j % (int)gridDim.y;
+  }
+  const int tpf = tiles_x * tiles_y;
+  const int frame = tile_m / tpf;
+  const int trem = tile_m - frame * tpf;
+  const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+  const int y0 = tyi * TY, x0 = txi * TX;       // output coordinates of the tile's first pixel
+  const int bn0 = tile_n * BN;
+  const bool splitk = (ws != nullptr);
+  const int kz = splitk ? blockIdx.z : 0;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const f16* __restrict__ A = (const f16*)p.A;
+  const f16* __restrict__ W = (const f16*)p.W;
+  const int N = p.N, Cin = p.Cin, Hin = p.Hin, Win = p.Win;
+  const int nh = Cin >> 5;
+  const int h0 = splitk ? kz * hchunk : 0;
+  const int h1 = splitk ? min(nh, h0 + hchunk) : nh;
+  const char* zero = (const char*)g_zero_page;
+
+  // ---- DMA assignment: activation piece q = s*NW + wave = patch rows [16q, 16q+16) ----
+  const char* fa_ptr[ASLOTS];
+  unsigned fa_step[ASLOTS];
+  {
+    const int yb = (UP2 ? (y0 >> 1) : y0) - 1, xb = (UP2 ? (x0 >> 1) : x0) - 1;
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s) {
+      const int j = (s * NW + wave) * 16 + (lane >> 2);
+      const int pr = j / PW, pc = j - pr * PW;
+      const int y = yb + pr, x = xb + pc;
+      const bool ok = (j < PR) && ((unsigned)y < (unsigned)Hin) && ((unsigned)x < (unsigned)Win);
+      const int cl = (lane & 3) ^ ((j >> 2) & 3);
+      fa_ptr[s] = ok ? (const char*)(A + (((int64_t)frame * Hin + y) * Win + x) * p.lda + h0 * 32 + cl * 8) : zero;
+      fa_step[s] = ok ? 64u : 0u;
+    }
+  }
+  // weight piece b = k*NW + wave: tap column dxi = b / (BN/16), rows (b % (BN/16))*16 .. +16 of the tiled layout
+  const char* fw_ptr[BSLOTS];
+  bool fw_ok[BSLOTS];
+#pragma unroll
+  for (int k = 0; k < BSLOTS; ++k) {
+    const int b = k * NW + wave;
+    const int dxi = b / (BN / 16), rb = b - dxi * (BN / 16);
+    const int g64 = (bn0 >> 6) + (rb >> 2);
+    fw_ok[k] = (g64 * 64 < ((N + 63) & ~63)) && (b < NPB);
+    fw_ptr[k] = (const char*)(W + (((int64_t)g64 * nh * 3 * 4 + (rb & 3)) * 3 + dxi) * 512 + lane * 8);
+  }
+  auto issue_b = [&](const int buf, const int h, const int dyi) {
+    const int64_t soff = (int64_t)(h * 3 + dyi) * (12 * 512);
+#pragma unroll
+    for (int k = 0; k < BSLOTS; ++k) {
+      const int b = k * NW + wave;
+      if (b < NPB) {
+        const char* src = fw_ok[k] ? fw_ptr[k] + soff * 2 : zero;
+        glds16(src, smem + B_BASE + buf * B_BYTES + b * 1024);
+      }
+    }
+  };
+#define MGLD_Q_ISSUE_A(S, PAR)                                                    \
+  if constexpr ((S) < ASLOTS) {                                                   \
+    if ((S) * NW + wave < NPA) {                                                  \
+      glds16(fa_ptr[S], smem + (PAR) * A_BYTES + ((S) * NW + wave) * 1024);       \
+      fa_ptr[S] += fa_step[S];                                                    \
+    }                                                                             \
+  }
+
+  // ---- fragment addresses: byte offset of this lane's patch row for each of the nine taps (first 16-channel step) ----
+  int a_off[MI][9];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int r = wm * WM + mi * 32 + l31;
+    const int ty = r / TX, tx = r & (TX - 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dyi = t / 3, dxi = t - dyi * 3;
+      const int j = UP2 ? (((ty + dyi - 1) >> 1) + 1) * PW + ((tx + dxi - 1) >> 1) + 1 : (ty + dyi) * PW + tx + dxi;
+      a_off[mi][t] = j * PB + ((lhi ^ ((j >> 2) & 3)) << 4);
+    }
+  }
+  int w_off[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int r = wn * WN + ni * 32 + l31;
+    w_off[ni] = r * PB + ((lhi ^ ((r >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  if (h0 < h1) {
+    MGLD_Q_ISSUE_A(0, 0)
+    MGLD_Q_ISSUE_A(1, 0)
+    MGLD_Q_ISSUE_A(2, 0)
+    issue_b(0, h0, 0);
+  }
+  int cur = 0;
+  for (int h = h0; h < h1; ++h) {
+    const int pa = (h - h0) & 1;
+    const bool more = (h + 1 < h1);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (more) {
+        if (s == 0) { MGLD_Q_ISSUE_A(0, pa ^ 1) }
+        if (s == 1) { MGLD_Q_ISSUE_A(1, pa ^ 1) }
+        if (s == 2) { MGLD_Q_ISSUE_A(2, pa ^ 1) }
+      }
+      if (s < 2) issue_b(cur ^ 1, h, s + 1);
+      else if (more) issue_b(cur ^ 1, h + 1, 0);
+      const int abase = pa * A_BYTES;
+      const int bb = B_BASE + cur * B_BYTES;
+      f16x8 fa[2][MI], fw[2][NI];
+      auto load = [&](const int u, const int set) {
+        const int dxi = u >> 1, kx = (u & 1) << 5;           // second 16-channel step: logical chunk ^ 2 = byte offset ^ 32
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[set][mi] = *(const f16x8*)(smem + abase + (a_off[mi][s * 3 + dxi] ^ kx));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fw[set][ni] = *(const f16x8*)(smem + bb + dxi * BSUB + (w_off[ni] ^ kx));
+      };
+      load(0, 0);
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        if (u + 1 < 6) load(u + 1, (u + 1) & 1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u & 1][ni], fa[u & 1][mi], acc[ni][mi], 0, 0, 0);
+      }
+      cur ^= 1;
+    }
+  }
+#undef MGLD_Q_ISSUE_A
+  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, 0, RowMap2D<TX>{frame * p.Hout * p.Wout, y0, x0, p.Hout, p.Wout}, bn0, wm, wn, wave,
+                                lane, acc, smem);
 }
 
 // split-K finish: out = alpha*act(sum_z ws[z] + bias + bias_m + rowvec) + beta*R.  One thread per 4 columns.
@@ -758,6 +970,22 @@ int num_cus() {
 float* g_ws = nullptr;     // split-K workspace (set by mgld_set_workspace; single-stream use)
 size_t g_ws_bytes = 0;
 
+// XCD-aware tile order of igemm_kernel (see the kernel): 0 = dispatch order, 1 = A-sharing blocks on one XCD, 2 = W-sharing blocks
+// on one XCD.  env MGLD_IGEMM_ORDER = 0 / 1 / 2 forces (A/B runs); default: by which operand is re-fetched more.
+inline int tile_order(const MgldIGemm* p, int gx, int gy) {
+  static int force = -2;
+  if (force < -1) { const char* e = getenv("MGLD_IGEMM_ORDER"); force = e ? atoi(e) : -1; }
+  int o = force;
+  if (o < 0) {
+    // bytes each order re-reads beyond one XCD's L2: order 1 streams W into every XCD, order 2 streams A into every XCD
+    const double a_bytes = 2.0 * p->M * (p->mode == MGLD_MODE_LINEAR ? p->K : p->Cin), w_bytes = 2.0 * p->N * p->K;
+    o = (gy > 1 && a_bytes >= w_bytes) ? 1 : (gx > 1 && gy >= 8 ? 2 : 0);
+  }
+  if (o == 1 && ((gx & 7) || gy < 2)) o = 0;
+  if (o == 2 && ((gy & 7) || gx < 2)) o = 0;
+  return o;
+}
+
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
 void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   constexpr int LDS = NST * (BM + BN) * ROWB;
@@ -771,7 +999,7 @@ void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   const int gz = splits > 1 ? splits : (p->batch > 0 ? p->batch : 1);
   dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), gz);
   hipLaunchKernelGGL((igemm_kernel<MODE, FAST, BM, BN, WM, WN, NST>), grid, dim3(THREADS), LDS, s, *p,
-                     splits > 1 ? g_ws : nullptr, kchunk);
+                     splits > 1 ? g_ws : nullptr, kchunk, tile_order(p, (int)grid.x, (int)grid.y));
 }
 
 // FAST: every 64-deep stage lies inside one tap and inside K (see the kernel)
@@ -904,6 +1132,98 @@ int launch_conv3p(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
   return mgld_check_launch("igemm(conv3p)");
 }
 
+
+// ---- conv3q launch plan -------------------------------------------------------------------------------------------
+// variants (id): tile TY x TX pixels, BN weight rows, wave tile WM pixels x WN channels
+//   0: 8x16 x 64, 32x32 (8 waves)      1: 16x16 x 64, 64x32 (8 waves)     2: 8x16 x 128, 64x32 (8 waves)
+//   3: 16x16 x 128, 64x64 (8 waves)    4: 8x32 x 64, 64x32 (8 waves)      5: 8x16 x 64, 64x32 (4 waves)
+constexpr int Q3_NVAR = 6;
+template <int TY, int TX, int BN, int WM, int WN, bool UP2>
+constexpr int conv3q_lds() {
+  constexpr int PW = UP2 ? TX / 2 + 2 : TX + 2, PH = UP2 ? TY / 2 + 2 : TY + 2;
+  constexpr int NPA = (PW * PH + 15) / 16, NW = (TY * TX / WM) * (BN / WN);
+  constexpr int stages = 2 * NPA * 1024 + 2 * 3 * BN * PB, epi = NW * 32 * (WN + 4) * 4;
+  return stages > epi ? stages : epi;
+}
+inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
+  switch (id) {
+    case 1: *ty = 16; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<16, 16, 64, 64, 32, true>() : conv3q_lds<16, 16, 64, 64, 32, false>(); break;
+    case 2: *ty = 8; *tx = 16; *bn = 128; *lds = conv3q_lds<8, 16, 128, 64, 32, false>(); break;
+    case 3: *ty = 16; *tx = 16; *bn = 128; *lds = conv3q_lds<16, 16, 128, 64, 64, false>(); break;
+    case 4: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 32, false>(); break;
+    case 5: *ty = 8; *tx = 16; *bn = 64; *lds = conv3q_lds<8, 16, 64, 64, 32, false>(); break;
+    default: *ty = 8; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<8, 16, 64, 32, 32, true>() : conv3q_lds<8, 16, 64, 32, 32, false>(); break;
+  }
+}
+
+// true when the problem takes the 2-D-tile patch kernel (tiled weights, tap_inner = 2); *id = variant, *splits / *hchunk = K split
+bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
+  static int knob = -1, force = -2, fsplit = -1;   // env MGLD_CONV3Q=0: off; MGLD_CONV3Q_FORCE=<id>; MGLD_CONV3P_SPLITS (tuning)
+  if (knob < 0) { const char* e = getenv("MGLD_CONV3Q"); knob = e ? atoi(e) : 1; }
+  if (force < -1) { const char* e = getenv("MGLD_CONV3Q_FORCE"); force = e ? atoi(e) : -1; }
+  if (fsplit < 0) { const char* e = getenv("MGLD_CONV3P_SPLITS"); fsplit = e ? atoi(e) : 0; }
+  if (!knob || p->mode != MGLD_MODE_CONV3X3 || p->tap_inner != 2) return false;
+  if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
+  if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->N <= 32 || p->act == MGLD_ACT_GEGLU || (p->Cin & 31)) return false;
+  const int sc = p->up2 ? 2 : 1;
+  if (p->Hout != sc * p->Hin || p->Wout != sc * p->Win || p->Wout < 16 || p->Hout < 8 || (p->M % (p->Hout * p->Wout))) return false;
+  const int frames = p->M / (p->Hout * p->Wout), N = p->N, nh = p->Cin >> 5;
+  const int64_t t256 = (int64_t)frames * cdiv(p->Hout, 16) * cdiv(p->Wout, 16) * cdiv(N, 64);
+  int v;
+  if (p->up2) v = (t256 >= 448) ? 1 : 0;
+  else if (p->Wout == 16 && (N & 127) == 0) v = 2;        // 16x16 level: 128 weight rows (as the raster kernel)
+  else v = (t256 >= 448 && p->Hout >= 16) ? 1 : 0;
+  if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1)) v = force;
+  if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2)) v = p->tune - 1;
+  int ty, tx, bn, lds;
+  q3_geom(v, &ty, &tx, &bn, &lds, p->up2 != 0);
+  const int64_t tiles = (int64_t)frames * cdiv(p->Hout, ty) * cdiv(p->Wout, tx) * cdiv(N, bn);
+  const int slots = num_cus() * ((160 * 1024) / lds);
+  int s = fsplit > 0 ? fsplit : (int)(slots / tiles);
+  if (s > nh / 4) s = nh / 4;
+  if (s > 16) s = 16;
+  if (s < 2 || g_ws == nullptr || (size_t)s * p->M * N * sizeof(float) > g_ws_bytes) s = 1;
+  int hc = (nh + s - 1) / s;
+  s = (nh + hc - 1) / hc;
+  *id = v; *splits = s; *hchunk = hc;
+  return true;
+}
+
+template <int TY, int TX, int BN, int WM, int WN, bool UP2>
+int launch_conv3q(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
+  constexpr int lds = conv3q_lds<TY, TX, BN, WM, WN, UP2>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv3q_kernel<TY, TX, BN, WM, WN, UP2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  const int frames = p->M / (p->Hout * p->Wout);
+  const int tiles_x = cdiv(p->Wout, TX), tiles_y = cdiv(p->Hout, TY);
+  dim3 grid(frames * tiles_x * tiles_y, cdiv(p->N, BN), splits > 1 ? splits : 1);
+  constexpr int THREADS = 64 * (TY * TX / WM) * (BN / WN);
+  hipLaunchKernelGGL((conv3q_kernel<TY, TX, BN, WM, WN, UP2>), grid, dim3(THREADS), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk,
+                     tiles_x, tiles_y);
+  if (splits > 1) {
+    const int64_t total = (int64_t)p->M * ((p->N + 3) >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, *p, g_ws, splits);
+  }
+  return mgld_check_launch("igemm(conv3q)");
+}
+
+int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int hchunk) {
+  if (p->up2) return id == 1 ? launch_conv3q<16, 16, 64, 64, 32, true>(p, s, splits, hchunk) : launch_conv3q<8, 16, 64, 32, 32, true>(p, s, splits, hchunk);
+  switch (id) {
+    case 1: return launch_conv3q<16, 16, 64, 64, 32, false>(p, s, splits, hchunk);
+    case 2: return launch_conv3q<8, 16, 128, 64, 32, false>(p, s, splits, hchunk);
+    case 3: return launch_conv3q<16, 16, 128, 64, 64, false>(p, s, splits, hchunk);
+    case 4: return launch_conv3q<8, 32, 64, 64, 32, false>(p, s, splits, hchunk);
+    case 5: return launch_conv3q<8, 16, 64, 64, 32, false>(p, s, splits, hchunk);
+    default: return launch_conv3q<8, 16, 64, 32, 32, false>(p, s, splits, hchunk);
+  }
+}
+
 }  // namespace
 
 extern "C" int mgld_set_workspace(void* ptr, int64_t bytes) {
@@ -916,9 +1236,36 @@ extern "C" int mgld_set_workspace(void* ptr, int64_t bytes) {
 extern "C" int mgld_igemm_config(const MgldIGemm* p) {
   if (!p) return 0;
   int cfg, splits, kchunk;
-  if (conv3p_plan(p, &cfg, &splits, &kchunk)) return 300000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // patch conv
+  if (conv3q_plan(p, &cfg, &splits, &kchunk)) return 400000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // 2-D-tile patch conv
+  if (conv3p_plan(p, &cfg, &splits, &kchunk)) return 300000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // raster patch conv
   choose(p, &cfg, &splits, &kchunk);
   return cfg + (splits > 1 ? splits * 1000000 : 0);
+}
+
+// name of the kernel template instantiation the launcher runs for this problem, spelled as rocprofv3 prints it
+extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen) {
+  MGLD_REQUIRE(p && buf && buflen > 0, "igemm_kernel_name: null");
+  int cfg, splits, kchunk;
+  if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
+    static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}};
+    snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false");
+    return splits;
+  }
+  if (conv3p_plan(p, &cfg, &splits, &kchunk)) {
+    snprintf(buf, buflen, cfg == 64 ? "conv3p_kernel<128, 64, 32, 32>" : "conv3p_kernel<128, 128, 64, 32>");
+    return splits;
+  }
+  choose(p, &cfg, &splits, &kchunk);
+  int bm = cfg / 1000, bn = cfg % 1000, wm, wn;
+  switch (cfg) {
+    case 128128: wm = 64; wn = (p->act == MGLD_ACT_GEGLU) ? 64 : 32; break;
+    case 64128: wm = 32; wn = 64; break;
+    case 128032: wm = 32; wn = 32; break;
+    case 128064: wm = 64; wn = 32; break;
+    default: bm = 64; bn = 64; wm = 32; wn = 32; break;
+  }
+  snprintf(buf, buflen, "igemm_kernel<%d, %s, %d, %d, %d, %d, 2>", p->mode, fast_ok(p) ? "true" : "false", bm, bn, wm, wn);
+  return cfg == 128128 ? splits : 1;
 }
 
 extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
@@ -945,7 +1292,8 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   }
   if (p->tap_inner == 2) {
     int c_, s_, h_;
-    MGLD_REQUIRE(conv3p_plan(p, &c_, &s_, &h_), "igemm: tiled conv weights (tap_inner = 2) need a problem the patch conv takes");
+    MGLD_REQUIRE(conv3q_plan(p, &c_, &s_, &h_) || conv3p_plan(p, &c_, &s_, &h_),
+                 "igemm: tiled conv weights (tap_inner = 2) need a problem a patch conv takes");
   } else if (p->tap_inner)
     MGLD_REQUIRE(p->mode != MGLD_MODE_LINEAR && (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2) &&
                      !(p->mode == MGLD_MODE_CONV3X3 && p->kh > 0 && !(p->kh == 3 && p->kw == 3)),
@@ -954,6 +1302,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;
+  if (conv3q_plan(p, &cfg, &splits, &kchunk)) return dispatch_conv3q(p, s, cfg, splits, kchunk);
   if (conv3p_plan(p, &cfg, &splits, &kchunk))
     return cfg == 64 ? launch_conv3p<64, 32, 32>(p, s, splits, kchunk) : launch_conv3p<128, 64, 32>(p, s, splits, kchunk);
   choose(p, &cfg, &splits, &kchunk);

@@ -233,8 +233,8 @@ class Engine:
         assert wp.shape[1] == 9 * cin, (wp.shape, cin)
         tap_inner = 1 if conv_tap_inner(cin, up2) else 0          # must match pack_conv3x3(..., tap_inner) of wp
         kw = {}
-        if stride == 1 and not up2 and tuple(pad) == (1, 1) and (ho, wo) == (hin, win):
-            wt = self._conv3p_tiled(wp, x.n, cin, cout, hin, win, tap_inner)
+        if stride == 1 and tuple(pad) == (1, 1) and (ho, wo) == ((2 * hin, 2 * win) if up2 else (hin, win)):
+            wt = self._conv3p_tiled(wp, x.n, cin, cout, hin, win, tap_inner, up2)
             if wt is not None:
                 wp, tap_inner, kw = wt, 2, dict(N=cout, K=9 * cin)
         hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec,
@@ -243,14 +243,14 @@ class Engine:
         self.launches += 1
         return out
 
-    def _conv3p_tiled(self, wp, frames, cin, cout, h, w, tap_inner):
+    def _conv3p_tiled(self, wp, frames, cin, cout, h, w, tap_inner, up2=False):
         """weights of a convolution the library's patch kernel takes, re-laid as [N/16][Cin/32][9][16][32] so that every
         1-KiB DMA piece of a weight stage is contiguous (include/mgld_hip.h, tap_inner = 2).  Built once per weight tensor on
         first use (eager pass); None = keep the [N, K] layout."""
-        geo = (cin, cout, h, w)
+        geo = (cin, cout, h, w, bool(up2))
         ok = self._c3p_geo.get(geo)
         if ok is None:
-            ok = self._c3p_geo[geo] = bool(hip.conv3p_applies(frames, cin, cout, h, w))
+            ok = self._c3p_geo[geo] = bool(hip.conv3p_applies(frames, cin, cout, h, w, up2))
         if not ok:
             return None
         key = (wp.data_ptr(), tap_inner)

@@ -109,25 +109,26 @@ class _StubFlow(torch.nn.Module):
         super().__init__()
 
 
-def build_ref_model():
+def build_ref_model(unet_cfg=None, struct_cfg=None, vae_dd=None, num_frames=T, flownet_config=None):
+    unet_cfg, struct_cfg = dict(unet_cfg or UNET_SMALL), dict(struct_cfg or STRUCT_SMALL)
     stubs = types.ModuleType("golden_stubs")
     stubs.StubCond, stubs.StubFlow = _StubCond, _StubFlow
     sys.modules["golden_stubs"] = stubs
     ddpm = ref_import.ref("ldm.models.diffusion.ddpm")
-    fs_dd = dict(VAE_DD_SMALL)
+    fs_dd = dict(vae_dd or VAE_DD_SMALL)
     fs_dd.pop("num_frames")
     model = ddpm.LatentDiffusionVSRTextWT(
         first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
                             "params": {"embed_dim": 4, "ddconfig": fs_dd, "lossconfig": {"target": "torch.nn.Identity"}}},
-        cond_stage_config={"target": "golden_stubs.StubCond", "params": {"ctx_dim": UNET_SMALL["context_dim"]}},
+        cond_stage_config={"target": "golden_stubs.StubCond", "params": {"ctx_dim": unet_cfg["context_dim"]}},
         structcond_stage_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedEncoderUNetModelWT",
-                                 "params": dict(STRUCT_SMALL)},
-        flownet_config={"target": "golden_stubs.StubFlow", "params": {}},
-        num_frames=T, linear_start=0.00085, linear_end=0.0120, num_timesteps_cond=1, log_every_t=200, timesteps=1000,
+                                 "params": struct_cfg},
+        flownet_config=flownet_config or {"target": "golden_stubs.StubFlow", "params": {}},
+        num_frames=num_frames, linear_start=0.00085, linear_end=0.0120, num_timesteps_cond=1, log_every_t=200, timesteps=1000,
         first_stage_key="image", cond_stage_key="caption", image_size=128, channels=4, cond_stage_trainable=False,
         conditioning_key="crossattn", scale_factor=0.18215, use_ema=False, time_replace=1000, use_usm=True,
         unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedUNetModelDualcondV2",
-                     "params": dict(UNET_SMALL)})
+                     "params": unet_cfg})
     model.eval()
     synth.fill_module_(model.model.diffusion_model, "unet")
     synth.fill_module_(model.structcond_stage_model, "structcond")
@@ -263,6 +264,53 @@ def gen_sample(model, ddpm):
     out["gauss16"] = model._gaussian_weights(16, 16, 1)[0, 0]
     out["gauss64"] = model._gaussian_weights(64, 64, 1)[0, 0]
     save("g_sample", **out)
+
+
+def gen_fullwidth():
+    """G10: BASELINE configs[0] at FULL width through the reference's own classes — one 512x512 frame (T = 1,
+    latent 64x64), 4 DDPM steps, no flows: first-stage encode -> q_sample_respace -> model.sample -> video-VAE encode /
+    decode -> AdaIN -> clamp, the call sequence of the script's per-segment body (oldcanvas_tile.py:429-471 without the tile
+    arguments).  Latents are stored in full (64 KiB each), the 3 MB pixel tensors as stride-4 slices + norms; inputs and
+    weights are regenerated on the test side from the same synth recipes.  ~2 min on 8 CPU threads: not part of the default
+    `make_golden.py` run (`make_golden.py fullwidth`)."""
+    from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
+    ae = ref_import.ref("ldm.models.autoencoder")
+    cf = ref_import.ref("scripts.wavelet_color_fix")
+    Tn, S, H, h = 1, 4, 512, 64
+    ucfg, scfg, dd = dict(UNET_FULL, num_frames=Tn), dict(STRUCT_FULL, num_frames=Tn), dict(VAE_DD_FULL, num_frames=Tn)
+    model, ddpm = build_ref_model(ucfg, scfg, dd, Tn)
+    vq = ae.VideoAutoencoderKLResi(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4, fusion_w=1.0,
+                                   freeze_dec=True, version=1).eval()
+    synth.fill_module_(vq, "vae")
+    x = synth.synth_tensor("one/x", (Tn, 3, H, H), 0.5).clamp(-1, 1)
+    n_post, n0 = synth.synth_tensor("one/np", (Tn, 4, h, h)), synth.synth_tensor("one/n0", (Tn, 4, h, h))
+    steps = [synth.synth_tensor(f"one/n{i}", (Tn, 4, h, h)) for i in range(S)]          # indexed by schedule index i
+    sac, somac = respace(model, S)
+    post = model.first_stage_model.encode(x)
+    init = model.scale_factor * (post.mean + post.std * n_post)                          # get_first_stage_encoding with injected noise
+    ctx = model.cond_stage_model([""])
+    xT = model.q_sample_respace(x_start=init, t=torch.full((Tn,), 999).long(), sqrt_alphas_cumprod=sac,
+                                sqrt_one_minus_alphas_cumprod=somac, noise=n0)
+    # one network evaluation at the first step's timestep (per-network full-width parity against the reference itself)
+    t0 = torch.tensor([model.ori_timesteps[S - 1]] * Tn).long()
+    scd = model.structcond_stage_model(init, t0)
+    eps0 = model.model.diffusion_model(xT, t0, context=ctx, struct_cond=scd)
+    queue = [steps[i] for i in reversed(range(S))]                                       # loop order i = S-1 .. 0
+    orig = ddpm.noise_like
+    ddpm.noise_like = lambda shape, device, repeat=False: queue.pop(0)
+    try:
+        x0, _ = model.sample(cond=ctx, struct_cond=init, guidance_scale=-10.0, lr_images=None, flows=None, masks=None,
+                             batch_size=1, timesteps=S, time_replace=S, x_T=xT, return_intermediates=True, verbose=False)
+    finally:
+        ddpm.noise_like = orig
+    _, fea = vq.encode(x)
+    dec = vq.decode(x0 * 1. / model.scale_factor, fea)
+    out = torch.clamp((cf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, min=0.0, max=1.0)
+    nrm = lambda t: np.array([float(t.double().norm()), float(t.double().mean())])
+    save("g_full_c1", init=init, xT=xT, eps0=eps0, x0=x0, dec_s4=dec[:, :, ::4, ::4], dec_norm=nrm(dec), out_s4=out[:, :, ::4, ::4],
+         out_norm=nrm(out), fea0_s8=fea[0][:, ::8, ::8, ::8], fea0_norm=nrm(fea[0]), fea1_s4=fea[1][:, ::8, ::4, ::4],
+         fea1_norm=nrm(fea[1]), post_mean=post.mean, post_logvar=post.logvar,
+         **{f"sc_{k}_norm": nrm(v) for k, v in scd.items()}, sc_8=scd["8"])
 
 
 def gen_raft():

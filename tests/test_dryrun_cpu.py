@@ -125,8 +125,8 @@ def test_unet_launch_plan_with_tiled_conv_weights(dry, monkeypatch):
     eng, rec = dry
     from mgld_vsr_amd import hip
     from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
-    monkeypatch.setattr(hip, "conv3p_applies", lambda frames, cin, cout, h, w: w % 16 == 0 and w <= 64 and (h * w) % 128 == 0
-                        and cin % 32 == 0 and cout > 32)
+    monkeypatch.setattr(hip, "conv3p_applies", lambda frames, cin, cout, h, w, up2=False: w >= 16 and h >= 8 and cin % 32 == 0
+                        and cout > 32)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
     unet, sc = InflatedUNetModelDualcondV2(**UNET_SMALL), InflatedEncoderUNetModelWT(**STRUCT_SMALL)
     unet.set_engine(eng)

@@ -311,6 +311,24 @@ def test_conv3p_planner_routes_the_unet_convolutions():
         assert code(*args, **kw) < 300000, (args, kw)
     assert not hip.conv3p_applies(8, 1280, 1280, 8, 8)
 
+    # tiled weights (tap_inner = 2, what the engine feeds): the 2-D-tile patch kernel, code 400000 + variant id
+    def qcode(frames, cin, cout, h, w, up2=0, tune=0):
+        p = hip.MgldIGemm()
+        sc = 2 if up2 else 1
+        p.mode, p.M, p.N, p.K, p.batch, p.tap_inner, p.tune = hip.MODE_CONV3X3, frames * h * w * sc * sc, cout, 9 * cin, 1, 2, tune
+        p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, sc * h, sc * w, 1, 1, 1, up2
+        return hip.igemm_config(p) % 1000000
+
+    assert qcode(8, 320, 320, 64, 64) == 400001         # 16x16-pixel tiles (640 blocks): 64-pixel x 32-channel wave tiles
+    assert qcode(8, 640, 640, 32, 32) == 400000         # too few 256-pixel tiles for 256 CUs: 8x16 tiles
+    assert qcode(8, 1280, 1280, 16, 16) == 400002       # 16x16 level: 128 weight rows
+    assert qcode(8, 128, 128, 512, 512) == 400001       # the VAE's large levels (W > 64) stay on the patch path
+    assert qcode(8, 512, 512, 64, 64, up2=1) == 400001  # nearest-2x upsample folded into the tap offsets
+    assert qcode(1, 64, 64, 8, 8, up2=1) == 400000
+    assert qcode(8, 320, 320, 64, 64, tune=5) == 400004
+    assert hip.conv3p_applies(8, 256, 256, 128, 128) and hip.conv3p_applies(5, 512, 512, 90, 120) and hip.conv3p_applies(8, 512, 512, 64, 64, True)
+    assert qcode(8, 1280, 1280, 8, 8) < 300000 and qcode(8, 320, 4, 64, 64) < 300000
+
 
 def _spliter_case(ImageSpliterTh, g, sf, to_dev=lambda t: t):
     """replay the generator's per-patch stand-in model (tests/golden/make_golden.py::gen_spliter) through a spliter class"""

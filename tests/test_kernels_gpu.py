@@ -257,7 +257,65 @@ def test_igemm_conv3x3_patch(hip, n, cin, cout, h, w, ti, epi):
               K=9 * cin, **kw)
     torch.cuda.synchronize()
     assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
-    assert torch.equal(out, out2)
+    # the tiled launch runs the 2-D-tile kernel: same products, same per-output summation order unless the K split differs
+    assert rel_l2(_from_tok(out2.cpu().float(), n, h, w), ref) < 1e-3 and rel_l2(out2.float(), out.float()) < 3e-4
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("n,cin,cout,h,w,epi", [
+    (2, 64, 96, 24, 40, 0),        # ragged in both directions for every tile shape, ragged N
+    (1, 128, 128, 136, 144, 1),    # W > 64 (the VAE's large levels), residual + SiLU epilogue
+    (3, 320, 320, 64, 64, 2),      # the UNet's dominant shape, per-frame row vector, strided (concat-slice) input
+    (1, 32, 64, 16, 16, 0)])       # single slice, one tile
+def test_igemm_conv3x3_tile2d(hip, variant, n, cin, cout, h, w, epi):
+    """conv3q: the patch-staged 3x3 conv on 2-D pixel tiles, every kernel variant (tune = id + 1) on square, ragged and
+    W > 64 frames vs torch's conv2d on the same fp16 operands"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    x = h16(rnd(n, cin, h, w, seed=170))
+    wt = h16(rnd(cout, cin, 3, 3, seed=171, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=172)
+    ref = F.conv2d(x.float(), wt.float(), b, padding=1)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    xt = _to_tok(x).to(DEV)
+    kw = {}
+    if epi == 1:
+        r = h16(rnd(n * h * w, cout, seed=173))
+        kw = dict(resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+        ref = 0.5 * F.silu(ref) + 2.0 * _from_tok(r.float(), n, h, w)
+    elif epi == 2:
+        emb = rnd(n, cout, seed=174)
+        kw = dict(rowvec=emb.to(DEV), rows_per_frame=h * w)
+        ref = ref + emb[:, :, None, None]
+        big = torch.zeros(n * h * w, cin + 64, dtype=torch.half, device=DEV)
+        big[:, 32:32 + cin] = xt
+        xt = big[:, 32:32 + cin]
+    assert hip.conv3p_applies(n, cin, cout, h, w)
+    out = torch.full((n * h * w, cout), float("nan"), dtype=torch.half, device=DEV)
+    hip.igemm(xt, tile_conv3p(wk, cin, False), out, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=(cin, h, w, h, w, 1, 1, 1, 0),
+              tap_inner=2, N=cout, K=9 * cin, tune=variant + 1, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 96, 12, 20), (1, 256, 256, 64, 64), (2, 1280, 1280, 8, 8)])
+def test_igemm_conv3x3_tile2d_upsample(hip, variant, n, cin, cout, h, w):
+    """conv3q with the nearest-2x upsample folded into the tap offsets (Upsample blocks: openaimodel.py:185, model.py:96) vs
+    conv2d(interpolate(x, 2, nearest)); (h, w) = the low-resolution input"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    x = h16(rnd(n, cin, h, w, seed=180))
+    wt = h16(rnd(cout, cin, 3, 3, seed=181, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=182)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), wt.float(), b, padding=1)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    assert hip.conv3p_applies(n, cin, cout, h, w, True)
+    out = torch.full((n * 4 * h * w, cout), float("nan"), dtype=torch.half, device=DEV)
+    hip.igemm(_to_tok(x).to(DEV), tile_conv3p(wk, cin, False), out, mode=hip.MODE_CONV3X3, bias=b.to(DEV),
+              conv=(cin, h, w, 2 * h, 2 * w, 1, 1, 1, 1), tap_inner=2, N=cout, K=9 * cin, tune=variant + 1)
+    torch.cuda.synchronize()
+    assert rel_l2(_from_tok(out.cpu().float(), n, 2 * h, 2 * w), ref) < 1e-3
 
 
 def test_igemm_tiled_weights_rejected_off_the_patch_path(hip):

@@ -91,9 +91,11 @@ def test_vae_small_vs_golden(hip):
     assert record("vae_small_fea0", rel_l2(f0, g["fea0"])) < 5e-3 and record("vae_small_fea1", rel_l2(f1, g["fea1"])) < 5e-3
     dec = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])
     assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 5e-3
-    vq.decoder.fusion_w = 0.5
-    dec05 = vq.decode(g["z"].cuda(), fea)
+    vq.decoder.fusion_w = 0.5                                   # the reference script's default --dec_w
+    dec05 = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])     # decoder alone: the reference's own features
     assert record("vae_small_dec_w05", rel_l2(dec05, g["dec_w05"])) < 5e-3
+    dec05p = vq.decode(g["z"].cuda(), fea)                                     # chained with the product's encoder features
+    assert record("vae_small_dec_w05_chained", rel_l2(dec05p, g["dec_w05"])) < 5e-3
     from scripts.wavelet_color_fix import adaptive_instance_normalization, wavelet_reconstruction
     assert rel_l2(adaptive_instance_normalization(g["dec"], g["style"]), g["adain"]) < 1e-5
     assert rel_l2(wavelet_reconstruction(g["dec"], g["style"]), g["wavelet"]) < 1e-5
@@ -252,6 +254,37 @@ def test_pipeline_single_frame_vs_oracle(hip):
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
     assert record("e2e_single_frame_latent", rel_l2(lat, x0)) < 3e-3
     assert record("e2e_single_frame_frames", rel_l2(out, ref)) < 2e-3
+
+
+def test_pipeline_config0_fullwidth_vs_reference(hip):
+    """BASELINE configs[0] in its stated form — ONE 128x128 LR frame pre-upsampled to 512x512 (T = 1, latent 64x64), 4 DDPM
+    steps, FULL-width SD-2.1 UNet + struct-cond encoder + KL-VAE / video decoder, AdaIN — against outputs of the REFERENCE's
+    own classes captured in tests/golden/g_full_c1.npz (no oracle on this path at test time).  north_star
+    tolerance on the outputs: 1e-3 relative L2 (latent in full, HR frame on the stored stride-4 slice)."""
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    from test_oracle_golden import fullwidth_c1_inputs
+    g = G("g_full_c1")
+    Tn, S, H, h, x, noise = fullwidth_c1_inputs()
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=model_configs(Tn))
+    out, lat = pipe.run_segment(x, noise=noise, return_latents=True)
+    assert out.shape == (Tn, 3, H, H)
+    m, vq = pipe.model, pipe.vq_model
+    # per-network figures against the reference (recorded; bounds at 2e-3: single evaluations sit at the fp16 storage floor)
+    ctx = synth.synth_tensor("ctx", (1, 77, 1024))
+    t0 = torch.tensor([m.ori_timesteps[S - 1]] * Tn)
+    sc = m.structcond_stage_model(g["init"].cuda(), t0.cuda())
+    assert record("c1_full_structcond_8", rel_l2(sc["8"], g["sc_8"])) < 2e-3
+    eps0 = m.model.diffusion_model(g["xT"].cuda(), t0.cuda(), context=ctx.cuda(), struct_cond=sc)
+    assert record("c1_full_unet_eps", rel_l2(eps0, g["eps0"])) < 2e-3
+    post, fea = vq.encode(x.cuda())
+    f0 = vq.engine().to_nchw(fea[0])
+    assert record("c1_full_vae_fea0", rel_l2(f0[:, ::8, ::8, ::8], g["fea0_s8"])) < 2e-3
+    dec = vq.decode(g["x0"].cuda() / 0.18215, fea)
+    assert record("c1_full_decoder", rel_l2(dec[:, :, ::4, ::4], g["dec_s4"])) < 2e-3
+    # the outputs
+    assert record("c1_full_latent", rel_l2(lat, g["x0"])) < 1e-3
+    assert record("c1_full_frames", rel_l2(out[:, :, ::4, ::4], g["out_s4"])) < 1e-3
+    assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
 
 
 def test_pipeline_frame_sharded_matches_unsharded(hip):

@@ -183,6 +183,63 @@ def test_text_tower_golden():
         assert rel_l2(otext.encode_with_transformer(sd, tokens, heads=4, layer_idx=1), g["penultimate"]) < 1e-5
 
 
+
+def fullwidth_c1_inputs():
+    """inputs of the config-1 full-width case (tests/golden/make_golden.py::gen_fullwidth), regenerated from the synth recipes"""
+    Tn, S, H, h = 1, 4, 512, 64
+    x = synth.synth_tensor("one/x", (Tn, 3, H, H), 0.5).clamp(-1, 1)
+    noise = {"posterior": synth.synth_tensor("one/np", (Tn, 4, h, h)), "x_T": synth.synth_tensor("one/n0", (Tn, 4, h, h)),
+             "steps": torch.stack([synth.synth_tensor(f"one/n{i}", (Tn, 4, h, h)) for i in range(S)])}
+    return Tn, S, H, h, x, noise
+
+
+def test_oracle_fullwidth_config1_golden():
+    """G10: the oracle chain at FULL width on BASELINE configs[0] (one 512x512 frame, latent 64x64, 4 steps, no flows) against
+    outputs of the reference's own classes (g_full_c1.npz): init latent, x_T, one UNet evaluation, sampled latent, decoded
+    and colour-fixed frame (stride-4 slices + norms)."""
+    from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
+    from ldm.models.autoencoder import AutoencoderKL, VideoAutoencoderKLResi
+    from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
+    g = G("g_full_c1")
+    Tn, S, H, h, x, noise = fullwidth_c1_inputs()
+    ucfg, scfg, dd = dict(UNET_FULL, num_frames=Tn), dict(STRUCT_FULL, num_frames=Tn), dict(VAE_DD_FULL, num_frames=Tn)
+
+    def names(m):
+        return [(k, tuple(v.shape)) for k, v in m.state_dict().items() if v.is_floating_point()]
+    fdd = dict(dd)
+    fdd.pop("num_frames")
+    usd = synth.synth_state_dict(names(InflatedUNetModelDualcondV2(**ucfg)), "unet")
+    ssd = synth.synth_state_dict(names(InflatedEncoderUNetModelWT(**scfg)), "structcond")
+    fsd = synth.synth_state_dict(names(AutoencoderKL(ddconfig=fdd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)), "first_stage")
+    vsd = synth.synth_state_dict(names(VideoAutoencoderKLResi(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)), "vae")
+    with torch.no_grad():
+        mean, logvar, _ = nets.vae_moments(fsd, dd, x)
+        assert rel_l2(mean, g["post_mean"]) < 1e-5 and rel_l2(logvar, g["post_logvar"]) < 1e-5
+        init = 0.18215 * (mean + torch.exp(0.5 * logvar) * noise["posterior"])
+        assert rel_l2(init, g["init"]) < 1e-5
+        full, resp, ori = osched.respaced_schedule(S)
+        xT = osched.q_sample_respace(init, torch.full((Tn,), 999, dtype=torch.long), full["sqrt_alphas_cumprod"],
+                                     full["sqrt_one_minus_alphas_cumprod"], noise["x_T"])
+        assert rel_l2(xT, g["xT"]) < 1e-5
+        ctx = synth.synth_tensor("ctx", (1, 77, 1024))
+        t0 = torch.tensor([ori[S - 1]] * Tn)
+        sc = nets.structcond_forward(ssd, scfg, g["init"], t0)
+        assert rel_l2(sc["8"], g["sc_8"]) < 1e-4
+        for k, v in sc.items():
+            assert abs(float(v.double().norm()) / float(g[f"sc_{k}_norm"][0]) - 1.0) < 1e-4, k
+        eps0 = nets.unet_forward(usd, ucfg, g["xT"], t0, ctx, sc)
+        assert rel_l2(eps0, g["eps0"]) < 1e-4
+        x0 = osamp.sample(usd, ucfg, ssd, scfg, ctx, g["init"], g["xT"], [noise["steps"][S - 1 - k] for k in range(S)], S)
+        assert rel_l2(x0, g["x0"]) < 1e-4
+        _, _, fea = nets.vae_moments(vsd, dd, x)
+        assert rel_l2(fea[0][:, ::8, ::8, ::8], g["fea0_s8"]) < 1e-4 and rel_l2(fea[1][:, ::8, ::4, ::4], g["fea1_s4"]) < 1e-4
+        dec = nets.vae_decode(vsd, dd, g["x0"] / 0.18215, fea)
+        assert rel_l2(dec[:, :, ::4, ::4], g["dec_s4"]) < 1e-4
+        assert abs(float(dec.double().norm()) / float(g["dec_norm"][0]) - 1.0) < 1e-4
+        out = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
+        assert rel_l2(out[:, :, ::4, ::4], g["out_s4"]) < 1e-4
+
+
 REF = os.environ.get("MGLD_REFERENCE", "/root/reference")
 
 

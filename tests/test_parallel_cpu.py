@@ -140,3 +140,20 @@ def test_frame_shard_replay_matches_recording():
         assert rp.worst == 0.0 and rp.pos == 2
     with pytest.raises(ValueError):
         parallel.FrameShard(5, 0, 2)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` (no torchrun around it, as the driver invokes it) must start the N ranks itself: the launcher is
+    re-executed under torch.distributed.run and rank 0 reports the world size the process group really had (gloo here; the GPU
+    path differs only in the backend)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-selftest"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["max_over_ranks_ok"] is True
