@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   // A wave waits only for ITS OWN stage-kt loads with a counted vmcnt (newer stages stay in flight across the
   // barrier), then the barrier makes every wave's stage kt visible and retires all reads of the buffer about to be
   // refilled.
-  static_assert(NST == 2 || NST == 3, "2 or 3 stages");
+  static_assert(NST >= 2 && NST <= 4, "2 .. 4 stages");
   // wave-uniform K position of the NEXT stage to issue; kept in this scope as plain scalars (SGPRs)
   int u_tap = __builtin_amdgcn_readfirstlane(s_tap), u_c0 = __builtin_amdgcn_readfirstlane(s_c0);
 #define MGLD_ADVANCE_TAP()                                                            \
@@ -478,10 +478,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     }
   int cur = 0;  // buffer of stage kt
   for (int kt = 0; kt < nk; ++kt) {
-    if (NST == 3 && kt + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JB) : "memory");   // one newer stage may stay outstanding
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+      const int ahead = min(NST - 2, nk - 1 - kt);                      // newer stages that may stay outstanding
+      if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (JA + JB)) : "memory");
+      else if (NST >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if constexpr (NST == 2) {
       __syncthreads();
@@ -979,7 +980,10 @@ inline int tile_order(const MgldIGemm* p, int gx, int gy) {
   if (o < 0) {
     // bytes each order re-reads beyond one XCD's L2: order 1 streams W into every XCD, order 2 streams A into every XCD
     const double a_bytes = 2.0 * p->M * (p->mode == MGLD_MODE_LINEAR ? p->K : p->Cin), w_bytes = 2.0 * p->N * p->K;
-    o = (gy > 1 && a_bytes >= w_bytes) ? 1 : (gx > 1 && gy >= 8 ? 2 : 0);
+    // measured (tools/igemm_bench.py lin, cold operands): neither order beats dispatch order on the UNet's projections (order 1
+    // -3 %, order 2 +-1 %): the re-reads they remove are served by the Infinity Cache at no cost in time.  Kept for A/B runs.
+    (void)a_bytes; (void)w_bytes;
+    o = 0;
   }
   if (o == 1 && ((gx & 7) || gy < 2)) o = 0;
   if (o == 2 && ((gy & 7) || gx < 2)) o = 0;
@@ -1016,9 +1020,30 @@ void launch_mode(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   else launch_fast<MODE, false, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
 }
 
+// ring depth of the LINEAR fast path: the short-K projections of the transformer blocks (K = C = 320 .. 1280: 5 .. 20 stages) run
+// one DMA round trip (~1 us under load) per stage with a 2-deep ring; a deeper ring keeps 2-3 stages in flight per block.
+// env MGLD_IGEMM_NST = 2 / 3 / 4 forces; p->tune = depth - 1 (tuning runs).
+inline int linear_ring_depth(const MgldIGemm* p, int BM, int BN) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("MGLD_IGEMM_NST"); force = e ? atoi(e) : 0; }
+  int nst = force ? force : 2;
+  if (p->tune > 0) nst = p->tune + 1;
+  if (nst < 2) nst = 2;
+  if (nst > 4) nst = 4;
+  while (nst > 2 && nst * (BM + BN) * ROWB > 160 * 1024) --nst;
+  const int nk = (p->K + BK - 1) / BK;
+  if (nst > nk) nst = nk < 2 ? 2 : nk;
+  return nst;
+}
+
 template <int BM, int BN, int WM, int WN, int NST = 2>
 int launch_cfg(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
-  if (p->mode == MGLD_MODE_LINEAR) launch_mode<MGLD_MODE_LINEAR, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
+  if (p->mode == MGLD_MODE_LINEAR && fast_ok(p) && splits <= 1) {
+    const int nst = linear_ring_depth(p, BM, BN);
+    if (nst == 4) launch_fast<MGLD_MODE_LINEAR, true, BM, BN, WM, WN, 4>(p, s, splits, kchunk);
+    else if (nst == 3) launch_fast<MGLD_MODE_LINEAR, true, BM, BN, WM, WN, 3>(p, s, splits, kchunk);
+    else launch_fast<MGLD_MODE_LINEAR, true, BM, BN, WM, WN, 2>(p, s, splits, kchunk);
+  } else if (p->mode == MGLD_MODE_LINEAR) launch_mode<MGLD_MODE_LINEAR, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
   else if (p->mode == MGLD_MODE_CONV3X3) launch_mode<MGLD_MODE_CONV3X3, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
   else launch_mode<MGLD_MODE_TCONV3, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
   if (splits > 1) {
@@ -1168,11 +1193,16 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   const int sc = p->up2 ? 2 : 1;
   if (p->Hout != sc * p->Hin || p->Wout != sc * p->Win || p->Wout < 16 || p->Hout < 8 || (p->M % (p->Hout * p->Wout))) return false;
   const int frames = p->M / (p->Hout * p->Wout), N = p->N, nh = p->Cin >> 5;
-  const int64_t t256 = (int64_t)frames * cdiv(p->Hout, 16) * cdiv(p->Wout, 16) * cdiv(N, 64);
+  // variant by measurement (tools/igemm_bench.py on MI355X, cold operands; profiles/r02_conv3q_variants.txt):
+  //   nearest-2x fold: the 8x16 tile (its low-res patch is 6x10 pixels: DMA-light already; the 16x16 tile only loses occupancy);
+  //   16x16 frames with N % 128 == 0: one 16x16 tile = the whole frame, 128 weight rows, 64x64 wave tiles;
+  //   W >= 32: 8x32 tiles (256 pixels, conflict-free fragment reads) while they still give ~2 blocks per CU, else 8x16 tiles run by
+  //   four waves of 64 pixels x 32 channels (3 blocks per CU).
+  const int64_t t832 = (int64_t)frames * cdiv(p->Hout, 8) * cdiv(p->Wout, 32) * cdiv(N, 64);
   int v;
-  if (p->up2) v = (t256 >= 448) ? 1 : 0;
-  else if (p->Wout == 16 && (N & 127) == 0) v = 2;        // 16x16 level: 128 weight rows (as the raster kernel)
-  else v = (t256 >= 448 && p->Hout >= 16) ? 1 : 0;
+  if (p->up2) v = 0;
+  else if (p->Wout == 16 && p->Hout == 16 && (N & 127) == 0) v = 3;
+  else v = (p->Wout >= 32 && t832 >= 448) ? 4 : 5;
   if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1)) v = force;
   if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2)) v = p->tune - 1;
   int ty, tx, bn, lds;

@@ -314,65 +314,84 @@ class LatentDiffusionVSRTextWT(nn.Module):
         """schedule steps per batched pass: at most STRUCTCOND_CHUNK and about 96 frames (bounds the arena of a pass)"""
         return max(1, min(self.STRUCTCOND_CHUNK, 96 // max(1, n_frames)))
 
-    def _precompute_structcond(self, eng, st, lat_act, S):
+    HOIST_TABLE_BUDGET = 24 << 30   # bytes of HBM the hoisted struct-cond + SPADE tables of ONE window may take (288 GB per GPU)
+
+    def _hoist_window(self, eng, lat_act, S):
+        """schedule steps per hoisting window: the per-step tables (struct-cond features of every scale + the SPADE gamma|beta of
+        the low-resolution blocks) are sized from the latent geometry and capped by HOIST_TABLE_BUDGET, so long schedules (the
+        CLI's default --ddpm_steps 1000), large patches or many frames are hoisted window by window instead of allocating
+        [S, ...] tables (132 GB of fp16 at 1000 steps x 45 latent tiles)."""
+        unet, sc_net = self.model.diffusion_model, self.structcond_stage_model
+        n, h, w = lat_act.n, lat_act.h, lat_act.w
+        per_step, hh, ww = 0, h, w
+        for _ in range(len(sc_net.input_block_chans)):
+            per_step += n * hh * ww * sc_net.out_channels * 2
+            hh, ww = max(1, hh // 2), max(1, ww // 2)
+        for blk, bh, bw in unet.resblock_geometry(h, w):
+            if bh * bw <= 1024:                                  # the blocks _precompute_spade hoists
+                per_step += n * bh * bw * 2 * blk.out_channels * 2
+        return int(max(1, min(S, self.HOIST_TABLE_BUDGET // max(1, per_step))))
+
+    def _precompute_structcond(self, eng, st, lat_act, i_high, i_low):
         """The reference evaluates structcond_stage_model(lat, t) inside every step (ddpm.py:4344-4350); its inputs are
-        the constant LR latent and the step's timestep, so all S evaluations are known before sampling starts.  They are
+        the constant LR latent and the step's timestep, so the evaluations are known before sampling starts.  They are
         run here as a few large batched passes (STRUCTCOND_CHUNK steps x frames per pass: big, efficient GEMMs instead of
-        ~350 latency-bound launches inside each step) into per-scale tables [S, frames*r*r, C]; a step then only copies its
-        slice (mgld_copy_step, indexed by the device-side step counter, so the captured step graph stays replayable)."""
+        ~350 latency-bound launches inside each step) into per-scale tables [window, frames*r*r, C] for the schedule indices
+        i_low..i_high of one hoisting window; a step then only copies its slice (mgld_copy_step, indexed by a device-side
+        window position that the step graph itself decrements, so the captured graph stays replayable across windows)."""
         sc_net = self.structcond_stage_model
         n, rows = lat_act.n, lat_act.rows
-        tables, dims = {}, {}
+        Wn = st["hoist_window"]
+        tables, dims = st.get("sc_tables", {}), st.get("sc_dims", {})
         chunk = self._sc_chunk(n)
-        for c0 in range(0, S, chunk):
-            k = min(chunk, S - c0)
+        cnt = i_high - i_low + 1
+        for c0 in range(0, cnt, chunk):
+            k = min(chunk, cnt - c0)
             eng.reset()
-            tv = st["coef"][c0:c0 + k, 6].contiguous()                      # network timesteps of schedule indices c0..c0+k-1
+            tv = st["coef"][i_low + c0:i_low + c0 + k, 6].contiguous()      # network timesteps of schedule indices i_low+c0 ..
             x = eng.arena.alloc((k * rows, lat_act.C), torch.float16)
             for j in range(k):
                 hip.copy2d(lat_act.v, x[j * rows:(j + 1) * rows])
             res = sc_net.run(eng, Act(x, k * n, lat_act.h, lat_act.w), tv, n)   # one embedding row per step: n frames each
             for key, a in res.items():
                 if key not in tables:
-                    tables[key] = torch.empty((S, n * a.hw, a.C), dtype=torch.float16, device=eng.device)
+                    tables[key] = torch.empty((Wn, n * a.hw, a.C), dtype=torch.float16, device=eng.device)
                     dims[key] = (a.h, a.w)
                 hip.copy2d(a.v, tables[key][c0:c0 + k].view(a.rows, a.C))
-        st["sc_tables"] = tables
-        st["sc_step"] = {key: (torch.empty_like(t[0]), dims[key]) for key, t in tables.items()}
+        st["sc_tables"], st["sc_dims"] = tables, dims
+        if "sc_step" not in st:
+            st["sc_step"] = {key: (torch.empty_like(t[0]), dims[key]) for key, t in tables.items()}
         st["sc_frames"] = n
+        st["win_idx"].fill_(i_high - i_low)                                   # window position of the step about to run
+        st["win"] = (i_high, i_low)
 
-    SPADE_TABLE_BUDGET = 16 << 30   # bytes of HBM the hoisted SPADE gamma/beta tables may take (288 GB per GPU)
-
-    def _precompute_spade(self, eng, st, S):
+    def _precompute_spade(self, eng, st):
         """The SPADE modulation of a ResBlockDual, [gamma|beta] = conv(relu(conv(struct_cond))) (spade.py:93-104,
         openaimodel.py:481-482), depends on the struct-cond features only — like them it is known for every step before
         sampling.  For the low-resolution blocks (<= 32x32 latents, where the in-step convolutions are small and
-        latency-bound) it is evaluated here in batched passes into per-block tables [S, frames*h*w, 2C]; the step's
-        spade_apply then indexes the table by the device-side step counter.  Called after the first (eager) step, which
-        records the struct-cond scale each block reads.  Tables are taken smallest-resolution first within the budget."""
+        latency-bound) it is evaluated here in batched passes into per-block tables [window, frames*h*w, 2C] for the current
+        hoisting window; the step's spade_apply then indexes the table by the device-side window position.  First called after
+        the first (eager) step, which records the struct-cond scale each block reads."""
         from .unet import ResBlockDual
         if "sc_tables" not in st:
             return
-        n = st["sc_frames"]
-        blocks = [m for m in self.model.diffusion_model.modules() if isinstance(m, ResBlockDual) and getattr(m, "_sc_key", None)]
-        cand = []
-        for blk in blocks:
-            fh, fw = st["sc_step"][blk._sc_key][1]
-            if fh * fw <= 1024:
-                cand.append((fh * fw, blk))
-        cand.sort(key=lambda t: t[0])
-        tables, used = {}, 0
-        for hw, blk in cand:
-            nbytes = S * n * hw * 2 * blk.out_channels * 2
-            if used + nbytes > self.SPADE_TABLE_BUDGET:
-                break
-            used += nbytes
-            tables[id(blk)] = (blk, torch.empty((S, n * hw, 2 * blk.out_channels), dtype=torch.float16, device=eng.device))
+        n, Wn = st["sc_frames"], st["hoist_window"]
+        i_high, i_low = st["win"]
+        if "spade_tabs" not in st:
+            blocks = [m for m in self.model.diffusion_model.modules() if isinstance(m, ResBlockDual) and getattr(m, "_sc_key", None)]
+            tabs = {}
+            for blk in blocks:
+                fh, fw = st["sc_step"][blk._sc_key][1]
+                if fh * fw <= 1024:
+                    tabs[id(blk)] = (blk, torch.empty((Wn, n * fh * fw, 2 * blk.out_channels), dtype=torch.float16, device=eng.device))
+            st["spade_tabs"] = tabs
+        tables = st["spade_tabs"]
         if not tables:
             return
         chunk = self._sc_chunk(n)
-        for c0 in range(0, S, chunk):
-            k = min(chunk, S - c0)
+        cnt = i_high - i_low + 1
+        for c0 in range(0, cnt, chunk):
+            k = min(chunk, cnt - c0)
             eng.reset()
             for blk, tab in tables.values():
                 src = st["sc_tables"][blk._sc_key]
@@ -380,7 +399,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 seg = Act(src[c0:c0 + k].view(k * n * fh * fw, src.shape[2]), k * n, fh, fw)
                 gb = blk.spade_modulation(eng, seg)
                 hip.copy2d(gb.v, tab[c0:c0 + k].view(gb.rows, gb.C))
-        st["spade"] = {key: (tab, tab.shape[1] * tab.shape[2], st["step_idx"]) for key, (blk, tab) in tables.items()}
+        st["spade"] = {key: (tab, tab.shape[1] * tab.shape[2], st["win_idx"]) for key, (blk, tab) in tables.items()}
 
     def _structcond_of_step(self, eng, st, lat_act):
         if "sc_tables" not in st:
@@ -388,7 +407,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
         out = {"__spade__": st["spade"]} if "spade" in st else {}
         for key, tab in st["sc_tables"].items():
             buf, (fh, fw) = st["sc_step"][key]
-            hip.copy_step(tab, buf, st["step_idx"])
+            hip.copy_step(tab, buf, st["win_idx"])
             eng.launches += 1
             out[key] = Act(buf, st["sc_frames"], fh, fw)
         return out
@@ -438,6 +457,8 @@ class LatentDiffusionVSRTextWT(nn.Module):
         else:
             hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], x, st["noise_stride"])
         hip.step_advance(st["step_idx"], -1)
+        if "sc_tables" in st:
+            hip.step_advance(st["win_idx"], -1)
 
     @torch.no_grad()
     def _sample_loop(self, cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
@@ -500,13 +521,20 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 st["lat_tiles"] = Act(la, len(tiles) * T_total, ts, ts)
                 st["wgt"] = self._gaussian_weights(ts, ts, 1)[0, 0].to(dev, torch.float32).contiguous()
                 st["acc"], st["cnt"], st["eps_canvas"] = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            lat_in = st["lat_act"] if tile is None else st["lat_tiles"]
+            hoist_spade = self.precompute_structcond and S > 1 and os.environ.get("MGLD_SPADE_PRECOMPUTE", "1") != "0"
             if self.precompute_structcond:
-                self._precompute_structcond(eng, st, st["lat_act"] if tile is None else st["lat_tiles"], S)
+                st["win_idx"] = torch.zeros(1, dtype=torch.int32, device=dev)
+                st["hoist_window"] = Wn = min(self._hoist_window(eng, lat_in, S), int(os.environ.get("MGLD_HOIST_WINDOW", S)))
             intermediates = [x.clone()]
             graph = None
             for k, i in enumerate(reversed(range(S))):
-                if k == 1 and self.precompute_structcond and S > 1 and os.environ.get("MGLD_SPADE_PRECOMPUTE", "1") != "0":
-                    self._precompute_spade(eng, st, S)          # after the eager first step (it records the block scales)
+                if self.precompute_structcond and k % Wn == 0:  # a new hoisting window: schedule indices i .. i-Wn+1
+                    self._precompute_structcond(eng, st, lat_in, i, max(0, i - Wn + 1))
+                    if hoist_spade and k > 0:
+                        self._precompute_spade(eng, st)
+                if k == 1 and hoist_spade:
+                    self._precompute_spade(eng, st)             # after the eager first step (it records the block scales)
                 if k == 0 or not use_graph:
                     self._step_body(eng, st)
                 else:

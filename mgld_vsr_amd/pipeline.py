@@ -91,6 +91,42 @@ class VSRPipeline:
         m.num_timesteps = 1000
         m.ori_timesteps = sorted(list(use))
 
+    def load_checkpoint(self, ckpt, vqgan_ckpt=None, context=None, verbose=True):
+        """Load the reference's checkpoints the way its script does (oldcanvas_tile.py:91-108, 296-329): the diffusion model's
+        `state_dict` goes, strict=False, into the model WITH ITS 1000-STEP SCHEDULE (the checkpoint stores betas / alphas_cumprod /
+        posterior_* at length 1000; strict=False does not forgive size mismatches), and only then is the schedule respaced to
+        `ddpm_steps`.  The text tower: when the checkpoint carries `cond_stage_model.model.*` (OpenCLIP text transformer) the tower
+        is built to its shapes so those weights are USED; without them a precomputed empty-prompt embedding must be given
+        (`context` [1,77,1024]) — a real checkpoint is never paired with the synthetic context silently.
+        Returns (missing_keys, unexpected_keys) of the diffusion model."""
+        m = self.model
+        sd = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, str) else ckpt
+        sd = sd["state_dict"] if "state_dict" in sd else sd
+        cs = m.cond_stage_model
+        tk = "cond_stage_model.model."
+        if any(k.startswith(tk) for k in sd):
+            if getattr(cs, "model", None) is None and hasattr(cs, "build_tower"):
+                layers = 1 + max(int(k[len(tk + "transformer.resblocks."):].split(".")[0]) for k in sd
+                                 if k.startswith(tk + "transformer.resblocks."))
+                cs.build_tower(layers=layers, vocab_size=sd[tk + "token_embedding.weight"].shape[0])
+        elif context is not None:
+            cs.set_context(context.float())
+        elif hasattr(cs, "set_context"):
+            cs.require_real_context = True               # forward() raises instead of inventing a context
+        m.register_schedule(given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.0120,
+                            cosine_s=8e-3)               # 1000-long buffers, as stored
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        self._setup_schedule(self.ddpm_steps)
+        if vqgan_ckpt is not None:
+            self.vq_model.init_from_ckpt(vqgan_ckpt)
+        if verbose:
+            print(f"[mgld] checkpoint: {len(sd)} entries, {len(missing)} missing, {len(unexpected)} unexpected keys")
+            for name, keys in (("missing", missing), ("unexpected", unexpected)):
+                if keys:
+                    print(f"[mgld]   {name}: " + ", ".join(list(keys)[:6]) + (" ..." if len(keys) > 6 else ""))
+        m._graph_key = None
+        return missing, unexpected
+
     def engine(self):
         from .engine import Engine
         if self.model._engine is None:

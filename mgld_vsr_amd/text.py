@@ -76,6 +76,18 @@ class FrozenOpenCLIPEmbedder(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
 
+    def build_tower(self, layers=24, vocab_size=None, heads=None):
+        """instantiate the text transformer after construction (checkpoint loading: the `cond_stage_model.model.*` entries need
+        parameters to land in)"""
+        if vocab_size is not None:
+            self.vocab_size = vocab_size
+        if heads is not None:
+            self.heads = heads
+        self.model = _TextTower(self.vocab_size, self.max_length, self.context_dim, layers, self.heads).eval()
+        for p in self.parameters():
+            p.requires_grad = False
+        return self
+
     def set_context(self, ctx):
         """install a precomputed empty-prompt embedding [1,77,context_dim]"""
         self._context = ctx
@@ -105,6 +117,9 @@ class FrozenOpenCLIPEmbedder(nn.Module):
         text = list(text) if isinstance(text, (list, tuple)) else [text]
         if self.model is None:
             if self._context is None:
+                if getattr(self, "require_real_context", False):
+                    raise RuntimeError("FrozenOpenCLIPEmbedder: real weights were loaded but neither a text tower (cond_stage_model.* "
+                                       "in the checkpoint) nor a precomputed context (set_context) is available")
                 warnings.warn("FrozenOpenCLIPEmbedder: no OpenCLIP weights on this path; using the synthetic constant context")
                 self._context = synth.synth_tensor("ctx", (1, self.max_length, self.context_dim))
             return self._context.repeat(len(text), 1, 1)

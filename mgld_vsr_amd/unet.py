@@ -538,6 +538,24 @@ class InflatedUNetModelDualcondV2(nn.Module, _TimeEmbedMixin):
             self._ctx_key = key
         return self._ctx_cache
 
+    def resblock_geometry(self, h, w):
+        """[(ResBlockDual, height, width)] of every residual block for an h x w latent (host-side planning: table sizes)"""
+        out, hh, ww = [], h, w
+        for blk in self.input_blocks:
+            for layer in blk:
+                if isinstance(layer, Downsample):
+                    hh, ww = hh // 2, ww // 2
+                elif isinstance(layer, ResBlockDual):
+                    out.append((layer, hh, ww))
+        out += [(layer, hh, ww) for layer in self.middle_block if isinstance(layer, ResBlockDual)]
+        for blk in self.output_blocks:
+            for layer in blk:
+                if isinstance(layer, ResBlockDual):
+                    out.append((layer, hh, ww))
+                elif isinstance(layer, Upsample):
+                    hh, ww = 2 * hh, 2 * ww
+        return out
+
     # ---- core: Acts in, Act out ----
     def run(self, eng, x, tvals, emb_rows, ctx_cache, struct_cond, out_eps=None):
         """x: Act [n,h,w,8] (latent channels zero-padded to 8); struct_cond: dict str(width)->Act; returns the fp32

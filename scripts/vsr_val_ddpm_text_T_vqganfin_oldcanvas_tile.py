@@ -1,19 +1,22 @@
 #!/usr/bin/env python
 """MI355X counterpart of the reference's README inference entry
 (scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py:133-556): same argument surface, same segmenting / padding /
-resizing rules, same per-segment call sequence — with the model work done by libmgld_hip.
+resizing rules, same per-segment call sequence — with the model work done by libmgld_hip.  Only the image file decode /
+encode (PIL) runs on the host; the bicubic pre-upsampling, reflect padding, quarter-resolution flow input, RAFT_SR flow
+estimation, occlusion masks, patch splitting / blending and the uint8 conversion run on the device (mgld_vsr_amd/preproc.py,
+raft.py, flowops.py).
 
-Differences that are deliberate (SURVEY.md §3.1 "known defects", §8(f)):
-  * optical flow: RAFT is outside this path.  Flows come from `--flows-path` (`<seq>/<segment>_flows.npy`, array
-    [2, T-1, 2, h/4, w/4] = (flows_forward_prop, flows_backward_prop) as `compute_flow` returns them); without it
-    the motion guidance is switched off (and said so);
+Differences that are deliberate (SURVEY.md §3.1 "known defects"):
+  * `--flows-path` (extension): precomputed flows (`<seq>/<segment>_flows.npy`, array [2, T-1, 2, h/4, w/4] =
+    (flows_forward_prop, flows_backward_prop) as `compute_flow` returns them) instead of RAFT_SR;
   * the reference's non-tiled branch reads `flow_f/flow_b/fwd_occ/bwd_occ` before assignment (:492-495); here the
     evident intent (`flows[0], flows[1], fwd_occs, bwd_occs`) is used;
   * the VAE config path that does not exist in the reference (:303) is replaced by `--vqgan_config`;
-  * host pre/post-processing (PNG decode, bicubic resize, reflect pad) stays on the host in torch — it is §8(f) row 2.
+  * seeding follows the reference: `seed_everything(opt.seed)` once at start (:280) and again per pixel patch in the
+    large-frame branch (:428) — on the device generator here, so the noise VALUES differ from a CUDA run of the reference
+    (they would between two GPU models as well); parity tests inject the noise instead.
 """
 import argparse
-import glob
 import os
 import sys
 
@@ -42,6 +45,7 @@ def read_image(path):
 
 
 # option names and defaults as in the reference script (:134-:262)
+IMAGE_EXTS = (".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".webp")
 REF_CONFIG = "configs/stable-diffusion/v1-inference.yaml"
 REF_CKPT = "checkpoints/stablevsr_025.ckpt"
 REF_VQGAN_CKPT = "checkpoints/vqgan_cfw_00011.ckpt"
@@ -113,9 +117,7 @@ def main():
     pipe = VSRPipeline(num_frames=opt.n_frames, ddpm_steps=opt.ddpm_steps, dec_w=opt.dec_w,
                        colorfix_type=opt.colorfix_type, synthetic_weights=opt.ckpt is None, configs=cfgs)
     if opt.ckpt:
-        sd = torch.load(opt.ckpt, map_location="cpu")
-        pipe.model.load_state_dict(sd["state_dict"] if "state_dict" in sd else sd, strict=False)
-        pipe._setup_schedule(opt.ddpm_steps)
+        pipe.load_checkpoint(opt.ckpt)                # 1000-step buffers first, respacing after; text tower from the checkpoint
     if opt.vqgan_ckpt:
         pipe.vq_model.init_from_ckpt(opt.vqgan_ckpt)
     os.makedirs(opt.outdir, exist_ok=True)
@@ -124,8 +126,11 @@ def main():
     for seq_idx, seq in enumerate(seq_names):
         if seq_idx % opt.n_gpus != opt.select_idx:   # the reference's process-level sharding (:337-339)
             continue
-        paths = sorted(glob.glob(os.path.join(opt.seqs_path, seq, "*.png")))
+        # every image file of the sequence directory, sorted by name (the reference takes sorted(os.listdir), :343)
+        paths = sorted(os.path.join(opt.seqs_path, seq, f) for f in os.listdir(os.path.join(opt.seqs_path, seq))
+                       if f.lower().endswith(IMAGE_EXTS))
         if not paths:
+            print(f"[mgld] {os.path.join(opt.seqs_path, seq)}: no image files ({', '.join(IMAGE_EXTS)}) - skipped")
             continue
         while len(paths) % opt.n_frames:             # repeat-last padding (:345-346)
             paths.append(paths[-1])
@@ -151,8 +156,9 @@ def main():
                 flows, masks = pipe.estimate_flows(seg)
             latents = []
 
-            def one(frames, fl, mk):
-                torch.manual_seed(opt.seed)                      # seed_everything(opt.seed) per (patch of a) segment (:430)
+            def one(frames, fl, mk, reseed=False):
+                if reseed:
+                    torch.manual_seed(opt.seed)                  # seed_everything(opt.seed) per pixel patch (:428)
                 h8_, w8_ = frames.shape[-2] // 8, frames.shape[-1] // 8
                 tl = None if (h8_ <= 64 and w8_ <= 64) else (64, opt.tile_overlap)   # one 64x64 tile == plain sampling
                 out_, lat_ = pipe.run_segment(frames, flows=fl, masks=mk, guidance_scale=opt.guidance_scale, tile=tl, clamp01=False,
@@ -168,7 +174,7 @@ def main():
                 # flows [1,T-1,2,h,w] / masks [1,T-1,1,h,w] -> 4-D [T-1,c,h,w] for the latent-resolution spliters
                 aux = [ImageSpliterTh(t[0], ps // 8, st // 8, sf=1) for t in (flows[0], flows[1], masks[0], masks[1])]
                 for (pch, idx), (ff_, _), (fb_, _), (fo_, _), (bo_, _) in zip(im_sp, *aux):
-                    im_sp.update(one(pch, (ff_[None], fb_[None]), (fo_[None], bo_[None])), idx)
+                    im_sp.update(one(pch, (ff_[None], fb_[None]), (fo_[None], bo_[None]), reseed=True), idx)
                 x_samples = im_sp.gather()
             else:
                 x_samples = one(seg, flows, masks)
@@ -183,7 +189,8 @@ def main():
             arrs = preproc.to_png_payload(out, ori_h, ori_w)                                  # crop + uint8 (:532-543)
             from PIL import Image
             for k in range(arrs.shape[0]):
-                Image.fromarray(arrs[k]).save(os.path.join(opt.outdir, seq, os.path.basename(paths[s0 + k])))
+                base = os.path.splitext(os.path.basename(paths[s0 + k]))[0]
+                Image.fromarray(arrs[k]).save(os.path.join(opt.outdir, seq, base + ".png"))       # '{}.png'.format(basename) (:541)
             if opt.latent_dir and len(latents) == 1:             # w_latent.py:389-397
                 os.makedirs(os.path.join(opt.latent_dir, seq), exist_ok=True)
                 lat = latents[0].cpu().numpy()

@@ -319,11 +319,11 @@ def test_conv3p_planner_routes_the_unet_convolutions():
         p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, sc * h, sc * w, 1, 1, 1, up2
         return hip.igemm_config(p) % 1000000
 
-    assert qcode(8, 320, 320, 64, 64) == 400001         # 16x16-pixel tiles (640 blocks): 64-pixel x 32-channel wave tiles
-    assert qcode(8, 640, 640, 32, 32) == 400000         # too few 256-pixel tiles for 256 CUs: 8x16 tiles
-    assert qcode(8, 1280, 1280, 16, 16) == 400002       # 16x16 level: 128 weight rows
-    assert qcode(8, 128, 128, 512, 512) == 400001       # the VAE's large levels (W > 64) stay on the patch path
-    assert qcode(8, 512, 512, 64, 64, up2=1) == 400001  # nearest-2x upsample folded into the tap offsets
+    assert qcode(8, 320, 320, 64, 64) == 400004         # 8x32-pixel tiles (640 blocks): 64-pixel x 32-channel wave tiles
+    assert qcode(8, 640, 640, 32, 32) == 400005         # too few 256-pixel tiles for 256 CUs: 8x16 tiles, four waves
+    assert qcode(8, 1280, 1280, 16, 16) == 400003       # 16x16 level: one tile per frame, 128 weight rows
+    assert qcode(8, 128, 128, 512, 512) == 400004       # the VAE's large levels (W > 64) stay on the patch path
+    assert qcode(8, 512, 512, 64, 64, up2=1) == 400000  # nearest-2x upsample folded into the tap offsets
     assert qcode(1, 64, 64, 8, 8, up2=1) == 400000
     assert qcode(8, 320, 320, 64, 64, tune=5) == 400004
     assert hip.conv3p_applies(8, 256, 256, 128, 128) and hip.conv3p_applies(5, 512, 512, 90, 120) and hip.conv3p_applies(8, 512, 512, 64, 64, True)
@@ -403,3 +403,52 @@ def test_text_oracle_matches_module_forward():
     assert {"model.token_embedding.weight", "model.positional_embedding", "model.transformer.resblocks.0.attn.in_proj_weight",
             "model.transformer.resblocks.2.mlp.c_proj.bias", "model.ln_final.weight", "model.text_projection",
             "model.logit_scale"} <= keys
+
+
+def _reduced_cfgs(n_frames=T):
+    from mgld_vsr_amd.pipeline import model_configs
+    return model_configs(n_frames, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                         struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                         vae_overrides=dict(ch=32, resolution=64), context_dim=64)
+
+
+def test_checkpoint_loads_before_respacing(tmp_path):
+    """the reference checkpoint stores the schedule buffers at length 1000 and the script loads it into the
+    1000-step model, respacing afterwards (oldcanvas_tile.py:91-108, 308-329).  VSRPipeline.load_checkpoint must take a
+    checkpoint with 1000-long buffers at any --ddpm_steps, must USE the `cond_stage_model.*` text-tower weights the checkpoint
+    carries (not the synthetic context), and must refuse to invent a context for real weights that come without a tower."""
+    from mgld_vsr_amd import synth
+    from mgld_vsr_amd.pipeline import VSRPipeline
+    from mgld_vsr_amd.util import instantiate_from_config
+    cfgs = _reduced_cfgs()
+    src = instantiate_from_config(cfgs[0])                       # constructed with the full 1000-step schedule
+    src.cond_stage_model.build_tower(layers=2, vocab_size=100, heads=2)
+    for name, mod in (("unet", src.model.diffusion_model), ("structcond", src.structcond_stage_model),
+                      ("first_stage", src.first_stage_model), ("clip", src.cond_stage_model)):
+        synth.fill_module_(mod, name)
+    sd = src.state_dict()
+    assert sd["betas"].shape == (1000,) and "cond_stage_model.model.token_embedding.weight" in sd
+    ck = tmp_path / "model.ckpt"
+    torch.save({"state_dict": sd, "global_step": 1}, ck)
+    pipe = VSRPipeline(num_frames=T, ddpm_steps=50, synthetic_weights=False, configs=cfgs)
+    assert pipe.model.betas.shape == (50,)
+    missing, unexpected = pipe.load_checkpoint(str(ck), verbose=False)
+    assert not unexpected and not [k for k in missing if not k.startswith("flownet_model.")]
+    m = pipe.model
+    assert m.betas.shape == (50,) and len(m.ori_timesteps) == 50 and m.ori_timesteps[-1] == 999      # respaced AFTER loading
+    assert pipe.sqrt_alphas_cumprod.shape == (1000,)
+    k = "model.diffusion_model.input_blocks.1.0.in_layers.2.weight"
+    assert torch.equal(m.state_dict()[k], sd[k])
+    tower = m.cond_stage_model.model
+    assert tower is not None and len(tower.transformer.resblocks) == 2
+    assert torch.equal(tower.token_embedding.weight, sd["cond_stage_model.model.token_embedding.weight"])
+    # real weights without a text tower and without a precomputed context: fail hard, never the synthetic context
+    sd2 = {k: v for k, v in sd.items() if not k.startswith("cond_stage_model.")}
+    pipe2 = VSRPipeline(num_frames=T, ddpm_steps=4, synthetic_weights=False, configs=cfgs)
+    pipe2.load_checkpoint({"state_dict": sd2}, verbose=False)
+    with pytest.raises(RuntimeError):
+        pipe2.model.cond_stage_model([""])
+    pipe3 = VSRPipeline(num_frames=T, ddpm_steps=4, synthetic_weights=False, configs=cfgs)
+    ctx = torch.randn(1, 77, 64)
+    pipe3.load_checkpoint({"state_dict": sd2}, context=ctx, verbose=False)
+    assert torch.equal(pipe3.model.cond_stage_model([""]), ctx)

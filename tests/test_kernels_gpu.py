@@ -44,6 +44,31 @@ def test_igemm_linear(hip, M, N, K):
     assert rel_l2(out.cpu().float(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("depth", [2, 3, 4])
+@pytest.mark.parametrize("M,N,K,act", [(32768, 320, 320, 0), (8192, 640, 640, 0), (2048, 1280, 1280, 3), (4096, 512, 128, 0),
+                                       (300, 200, 64, 0), (8192, 640, 320, 4), (1000, 2560, 704, 4)])
+def test_igemm_linear_ring_depth(hip, depth, M, N, K, act):
+    """LINEAR fast path with a 2 / 3 / 4-deep LDS ring (tune = depth - 1): counted vmcnt keeps depth - 2 stages in flight
+    across the stage barrier; K shorter than the ring, ragged M / N and the GEGLU epilogue included.  All depths must give the
+    same bits as depth 2 (same products, same summation order)."""
+    from mgld_vsr_amd.engine import pack_geglu
+    a, w, b = h16(rnd(M, K, seed=31)), h16(rnd(N, K, seed=32, scale=K ** -0.5)), rnd(N, seed=33)
+    pre = a.float() @ w.float().t() + b
+    if act == hip.ACT_GEGLU:
+        ref = pre[:, :N // 2] * F.gelu(pre[:, N // 2:])
+        w, b = pack_geglu(w, b)
+    else:
+        ref = F.silu(pre) if act == hip.ACT_SILU else pre
+    n_out = N // 2 if act == hip.ACT_GEGLU else N
+    out = torch.full((M, n_out), float("nan"), dtype=torch.half, device=DEV)
+    base = torch.empty_like(out)
+    hip.igemm(a.to(DEV), w.to(DEV), base, bias=b.to(DEV), act=act, tune=1)
+    hip.igemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV), act=act, tune=depth - 1)
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+    assert torch.equal(out, base)
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 1280, 11520), (2048, 640, 5760), (300, 200, 2048), (64, 1280, 23040),
                                    (2048, 1280, 5120), (1000, 384, 4096)])
 def test_igemm_splitk(hip, M, N, K):

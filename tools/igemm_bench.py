@@ -58,6 +58,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--variants", default="0", help="conv: comma list of `tune` values (0 = launcher's choice, id+1 forces conv3q variant id)")
+    ap.add_argument("--nst", default="0", help="lin: comma list of `tune` values (0 = launcher's choice, d-1 forces a d-deep LDS ring)")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", default=None)
@@ -67,9 +68,11 @@ def main():
     dev = "cuda"
     shapes = {"conv": CONV, "vae": VAE, "lin": LIN, "all": CONV + VAE + LIN}[args.what]
     variants = [int(v) for v in args.variants.split(",")]
+    nsts = [int(v) for v in args.nst.split(",")]
+    allv = sorted(set(variants) | set(nsts))
     e0, e1 = hip.Event(), hip.Event()
     out_rows = []
-    totals = {v: 0.0 for v in variants}
+    totals = {v: 0.0 for v in allv}
     for name, mode, M, N, K, Cin, H, W, act, up2, weight in shapes:
         sc = 2 if up2 else 1
         frames = M // (H * W * sc * sc) if mode == 1 else 0
@@ -91,12 +94,10 @@ def main():
                 hip.igemm(a, w, o, mode=1, bias=bias, conv=(Cin, H, W, sc * H, sc * W, 1, 1, 1, up2), tap_inner=2 if tiled else 0, N=N, K=K,
                           tune=tune)
             else:
-                hip.igemm(a, w, o, bias=bias, act=act)
+                hip.igemm(a, w, o, bias=bias, act=act, tune=tune)
         best = {}
         for r in range(args.rounds):
-            for v in variants:
-                if mode != 1 and v != variants[0]:
-                    continue
+            for v in (variants if mode == 1 else nsts):
                 if up2 and v > 2:
                     continue
                 launch(0, v)
@@ -109,7 +110,7 @@ def main():
                 best[v] = min(best.get(v, 1e30), us)
         p = hip.MgldIGemm()
         line = f"{name:26s} M={M:8d} N={N:5d} K={K:6d} "
-        for v in variants:
+        for v in allv:
             if v in best:
                 tf = 2.0 * M * N * K / (best[v] * 1e-6) / 1e12
                 totals[v] += best[v] * weight / 1e3
