@@ -258,6 +258,11 @@ int mgld_copy_step(const void* src, void* dst, int64_t bytes_per_step, const int
  * taps clamped, no antialias), fp32 planes [planes, h, w] -> [planes, oh, ow], result clamped to [lo, hi]
  * (pass -inf/+inf for none): the x4 pre-upsampling of the LR frames and the /4 downscale fed to the flow network. */
 int mgld_resize_bicubic(const float* x, float* y, int planes, int h, int w, int oh, int ow, float lo, float hi, void* stream);
+/* torchvision Resize + CenterCrop on a tensor, as scripts/vsr_val_ddpm_text_T_vqganfin_old.py:253-256,315 apply them
+ * (F.interpolate(mode="bilinear", align_corners=False), no antialias, to rh x rw; then the oh x ow window at (cy, cx)) in
+ * one pass: fp32 planes [planes, h, w] -> [planes, oh, ow] */
+int mgld_resize_bilinear_crop(const float* x, float* y, int planes, int h, int w, int rh, int rw, int oh, int ow, int cy, int cx,
+                              void* stream);
 /* F.pad(x, (0, ow-w, 0, oh-h), mode="reflect"): bottom / right reflect padding to the next multiple of 32 */
 int mgld_reflect_pad(const float* x, float* y, int planes, int h, int w, int oh, int ow, void* stream);
 /* F.pad(x, (pl, ow-w-pl, pt, oh-h-pt), mode="replicate") (RAFT InputPadder, raft_arch.py:27-28) */

@@ -773,6 +773,26 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
   }
 }
 
+// torch upsample_bilinear2d (align_corners=False, no antialias) with an optional centre-crop window: output pixel (oy, ox) of the
+// oh x ow window whose top-left corner sits at (cy, cx) of the rh x rw resized image
+__global__ __launch_bounds__(256) void bilinear_crop_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int h, int w,
+                                                            int oh, int ow, int cy, int cx, float sy, float sx) {
+  const int64_t total = (int64_t)planes * oh * ow;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % ow);
+    const int oy = (int)((i / ow) % oh);
+    const int pl = (int)(i / ((int64_t)ow * oh));
+    const float fy = fmaxf(sy * (oy + cy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * (ox + cx + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = x + (int64_t)pl * h * w;
+    const float top = p[(int64_t)y0 * w + x0] * (1.f - lx) + p[(int64_t)y0 * w + x1] * lx;
+    const float bot = p[(int64_t)y1 * w + x0] * (1.f - lx) + p[(int64_t)y1 * w + x1] * lx;
+    y[i] = top * (1.f - ly) + bot * ly;
+  }
+}
+
 // F.pad(mode="reflect") on the bottom / right edges (no edge repeat): index h+k reads h-2-k
 __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int h,
                                                           int w, int oh, int ow) {
@@ -820,6 +840,15 @@ extern "C" int mgld_resize_bicubic(const float* x, float* y, int planes, int h, 
   hipLaunchKernelGGL(bicubic_kernel, dim3(egrid((int64_t)planes * oh * ow)), dim3(256), 0, S_(stream), x, y, planes, h, w, oh,
                      ow, (float)h / (float)oh, (float)w / (float)ow, lo, hi);
   return mgld_check_launch("resize_bicubic");
+}
+
+extern "C" int mgld_resize_bilinear_crop(const float* x, float* y, int planes, int h, int w, int rh, int rw, int oh, int ow, int cy,
+                                         int cx, void* stream) {
+  MGLD_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && rh > 0 && rw > 0 && oh > 0 && ow > 0, "resize_bilinear_crop: bad args");
+  MGLD_REQUIRE(cy >= 0 && cx >= 0 && cy + oh <= rh && cx + ow <= rw, "resize_bilinear_crop: window outside the resized image");
+  hipLaunchKernelGGL(bilinear_crop_kernel, dim3(egrid((int64_t)planes * oh * ow)), dim3(256), 0, S_(stream), x, y, planes, h, w, oh, ow,
+                     cy, cx, (float)h / (float)rh, (float)w / (float)rw);
+  return mgld_check_launch("resize_bilinear_crop");
 }
 
 extern "C" int mgld_reflect_pad(const float* x, float* y, int planes, int h, int w, int oh, int ow, void* stream) {

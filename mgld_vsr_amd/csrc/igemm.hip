@@ -1020,9 +1020,11 @@ void launch_mode(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   else launch_fast<MODE, false, BM, BN, WM, WN, NST>(p, s, splits, kchunk);
 }
 
-// ring depth of the LINEAR fast path: the short-K projections of the transformer blocks (K = C = 320 .. 1280: 5 .. 20 stages) run
-// one DMA round trip (~1 us under load) per stage with a 2-deep ring; a deeper ring keeps 2-3 stages in flight per block.
-// env MGLD_IGEMM_NST = 2 / 3 / 4 forces; p->tune = depth - 1 (tuning runs).
+// ring depth of the LINEAR fast path.  Measured on the transformer blocks' projections (tools/igemm_bench.py lin --nst 1,2,3, MI355X,
+// profiles/r02_linear_ring_depth.txt): 3- and 4-deep rings (counted vmcnt, 1-2 stages in flight across the stage barrier) are SLOWER
+// than the 2-deep ring on every shape but M = 512 (178 -> 227 -> 260 ms per segment): what hides the DMA round trip is the number
+// of resident blocks per CU, and a deeper ring trades exactly that away.  Default 2; env MGLD_IGEMM_NST = 2 / 3 / 4 or
+// p->tune = depth - 1 select a deeper ring (tests, tuning runs).
 inline int linear_ring_depth(const MgldIGemm* p, int BM, int BN) {
   static int force = -1;
   if (force < 0) { const char* e = getenv("MGLD_IGEMM_NST"); force = e ? atoi(e) : 0; }

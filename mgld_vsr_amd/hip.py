@@ -60,7 +60,7 @@ EXPORTS = [
     "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
     "mgld_adain", "mgld_wavelet_reconstruction",
     "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize", "mgld_copy_step",
-    "mgld_resize_bicubic", "mgld_reflect_pad", "mgld_replicate_pad", "mgld_to_uint8_hwc",
+    "mgld_resize_bicubic", "mgld_resize_bilinear_crop", "mgld_reflect_pad", "mgld_replicate_pad", "mgld_to_uint8_hwc",
     "mgld_avgpool2", "mgld_corr_lookup", "mgld_gru_rh", "mgld_gru_gate", "mgld_flow_update", "mgld_convex_upsample",
     "mgld_add_relu",
 ]
@@ -525,6 +525,24 @@ def resize_bicubic(x, size, clamp=None):
     lo, hi = (-float("inf"), float("inf")) if clamp is None else clamp
     _chk(lib().mgld_resize_bicubic(_p(x), _p(y), n * c, h, w, oh, ow, C.c_float(lo), C.c_float(hi), stream_ptr()),
          "resize_bicubic")
+    return y
+
+
+def resize_center_crop(x, size):
+    """torchvision.transforms.Resize(size) + CenterCrop(size) on a tensor [n,c,h,w] (fp32, device): the smaller edge is resized to
+    `size` with bilinear interpolation (align_corners=False, no antialias: what torchvision 0.13/0.14 — the reference's pin —
+    does for tensors), the larger edge to int(size * long / short), then the central size x size window is cut (round half to even
+    on the offsets, as torchvision's center_crop)."""
+    _req_cuda(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    if w <= h:
+        rw, rh = size, int(size * h / w)
+    else:
+        rh, rw = size, int(size * w / h)
+    cy, cx = int(round((rh - size) / 2.0)), int(round((rw - size) / 2.0))
+    y = torch.empty(n, c, size, size, dtype=torch.float32, device=x.device)
+    _chk(lib().mgld_resize_bilinear_crop(_p(x), _p(y), n * c, h, w, rh, rw, size, size, cy, cx, stream_ptr()), "resize_bilinear_crop")
     return y
 
 

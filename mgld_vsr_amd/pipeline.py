@@ -156,7 +156,7 @@ class VSRPipeline:
 
     @torch.no_grad()
     def run_segment(self, frames, flows=None, masks=None, guidance_scale=-10.0, noise=None, tile=None, use_graph=True,
-                    return_latents=False, shard=None, gather=True, clamp01=True):
+                    return_latents=False, shard=None, gather=True, clamp01=True, init_from_vq=False):
         """frames: [T,3,H,W] in [-1,1] (the bicubically pre-upsampled LR segment, device or host);
         flows/masks as the reference passes them to sample(); noise: optional dict with 'posterior' [T,4,h,w],
         'x_T' [T,4,h,w], 'steps' [S,T,4,h,w].  Returns HR frames [T,3,H,W] in [0,1] on the device.
@@ -169,12 +169,12 @@ class VSRPipeline:
         eng.shard = shard
         try:
             return self._run_segment(eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents,
-                                     shard, gather, clamp01)
+                                     shard, gather, clamp01, init_from_vq)
         finally:
             eng.shard = None
 
     def _run_segment(self, eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents, shard, gather,
-                     clamp01=True):
+                     clamp01=True, init_from_vq=False):
         m, vq = self.model, self.vq_model
         noise = dict(noise or {})
         if shard is not None:
@@ -194,7 +194,11 @@ class VSRPipeline:
                 noise[k] = shard.local(noise[k], dim)
         x = frames.to(eng.device, torch.float32).contiguous()
         T = x.shape[0]
-        post = m.encode_first_stage(x)
+        enc_fea = None
+        if init_from_vq:
+            post, enc_fea = vq.encode(x)
+        else:
+            post = m.encode_first_stage(x)
         pn = noise.get("posterior")
         init_latent = m.get_first_stage_encoding(post, pn if pn is not None else torch.randn(post.mean.shape))
         ctx = m.cond_stage_model([""])
@@ -208,7 +212,8 @@ class VSRPipeline:
             samples = m.sample(**kw)
         else:
             samples = m.sample_canvas(tile_size=tile[0], tile_overlap=tile[1], batch_size_sample=1, **kw)
-        _, enc_fea = vq.encode(x)
+        if enc_fea is None:
+            _, enc_fea = vq.encode(x)
         x_samples = vq.decode(samples * (1.0 / m.scale_factor), enc_fea)
         if self.colorfix_type == "adain":
             x_samples = adaptive_instance_normalization(x_samples, x)

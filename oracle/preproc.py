@@ -35,3 +35,16 @@ def to_png_payload(out, ori_h, ori_w):
     """:523-543 — crop the padding, [0,1] -> uint8 HWC"""
     o = out[:, :, :ori_h, :ori_w]
     return (o.cpu().numpy().transpose(0, 2, 3, 1) * 255).astype(np.uint8)
+
+
+def resize_center_crop(x, size):
+    """torchvision.transforms.Resize(size) + CenterCrop(size) on a tensor as scripts/vsr_val_ddpm_text_T_vqganfin_old.py:253-256,315
+    apply them (torchvision 0.13 / 0.14 tensor path: bilinear, align_corners=False, no antialias; smaller edge -> size)."""
+    h, w = x.shape[-2:]
+    if w <= h:
+        nw, nh = size, int(size * h / w)
+    else:
+        nh, nw = size, int(size * w / h)
+    y = F.interpolate(x, size=[nh, nw], mode="bilinear", align_corners=False, antialias=False)
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    return y[..., top:top + size, left:left + size]

@@ -101,8 +101,14 @@ def parse(argv=None):
     return opt
 
 
-def main():
-    opt = parse()
+# test hooks (tests/test_cli_gpu.py): NOISE_HOOK(T, h, w, steps) -> the noise dict run_segment takes (the parity test replays the
+# draws of a captured reference run); CAPTURE: a list that receives, per sampled patch, its flows / masks / sampled latents
+NOISE_HOOK = None
+CAPTURE = None
+
+
+def main(argv=None):
+    opt = parse(argv)
     torch.manual_seed(opt.seed)
     cfgs = model_configs(opt.n_frames)
     if opt.config:
@@ -161,9 +167,12 @@ def main():
                     torch.manual_seed(opt.seed)                  # seed_everything(opt.seed) per pixel patch (:428)
                 h8_, w8_ = frames.shape[-2] // 8, frames.shape[-1] // 8
                 tl = None if (h8_ <= 64 and w8_ <= 64) else (64, opt.tile_overlap)   # one 64x64 tile == plain sampling
+                nz = NOISE_HOOK(frames.shape[0], h8_, w8_, opt.ddpm_steps) if NOISE_HOOK is not None else None
                 out_, lat_ = pipe.run_segment(frames, flows=fl, masks=mk, guidance_scale=opt.guidance_scale, tile=tl, clamp01=False,
-                                              return_latents=True)
+                                              return_latents=True, noise=nz)
                 latents.append(lat_)
+                if CAPTURE is not None:
+                    CAPTURE.append({"flows": fl, "masks": mk, "x0": lat_})
                 return out_
 
             if seg.shape[-2] > opt.vqgantile_size or seg.shape[-1] > opt.vqgantile_size:

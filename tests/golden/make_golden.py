@@ -313,6 +313,250 @@ def gen_fullwidth():
          **{f"sc_{k}_norm": nrm(v) for k, v in scd.items()}, sc_8=scd["8"])
 
 
+class _AD(dict):
+    """dict with attribute access (the scripts read `config.model`, instantiate_from_config reads it as a dict)"""
+    __getattr__ = dict.__getitem__
+
+    @staticmethod
+    def wrap(v):
+        return _AD({k: _AD.wrap(x) for k, x in v.items()}) if isinstance(v, dict) else v
+
+
+def _harness_env(tmp, resolution):
+    """What a run of one of the reference's entry scripts needs here beyond ref_import's stubs: reduced-width configs behind
+    OmegaConf.load, synthetic checkpoints in the reference's key layout, Module.cuda as a no-op.  Returns the ddpm module."""
+    ref_import.install()
+    stubs = types.ModuleType("golden_stubs")
+    stubs.StubCond, stubs.StubFlow = _StubCond, _StubFlow
+    sys.modules["golden_stubs"] = stubs
+    fs_dd = dict(VAE_DD_SMALL, resolution=resolution)
+    fs_dd.pop("num_frames")
+    dcfg = {"target": "ldm.models.diffusion.ddpm.LatentDiffusionVSRTextWT", "params": dict(
+        first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                            "params": {"embed_dim": 4, "ddconfig": fs_dd, "lossconfig": {"target": "torch.nn.Identity"}}},
+        cond_stage_config={"target": "golden_stubs.StubCond", "params": {"ctx_dim": UNET_SMALL["context_dim"]}},
+        structcond_stage_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedEncoderUNetModelWT", "params": dict(STRUCT_SMALL)},
+        flownet_config={"target": "basicsr.archs.raft_arch.RAFT_SR", "params": {"model": "normal", "load_path": None}},
+        num_frames=T, linear_start=0.00085, linear_end=0.0120, num_timesteps_cond=1, log_every_t=200, timesteps=1000,
+        first_stage_key="image", cond_stage_key="caption", image_size=resolution, channels=4, cond_stage_trainable=False,
+        conditioning_key="crossattn", scale_factor=0.18215, use_ema=False, time_replace=1000, use_usm=True,
+        unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.InflatedUNetModelDualcondV2", "params": dict(UNET_SMALL)})}
+    vcfg = {"target": "ldm.models.autoencoder.VideoAutoencoderKLResi", "params": dict(
+        embed_dim=4, fusion_w=1.0, freeze_dec=True, synthesis_data=False, version=1, lossconfig={"target": "torch.nn.Identity"},
+        ddconfig=dict(VAE_DD_SMALL, resolution=resolution))}
+
+    class OmegaConf:
+        @staticmethod
+        def load(path):
+            return _AD.wrap({"model": vcfg if "video_autoencoder" in str(path) or "video_vae" in str(path) else dcfg})
+    sys.modules["omegaconf"].OmegaConf = OmegaConf
+    if os.path.join(ref_import.REF, "scripts") not in sys.path:
+        sys.path.insert(0, os.path.join(ref_import.REF, "scripts"))        # `from util_image import ImageSpliterTh`
+    ddpm = ref_import.ref("ldm.models.diffusion.ddpm")
+    util = ref_import.ref("ldm.util")
+    model = util.instantiate_from_config(dcfg)
+    for mod, salt in ((model.model.diffusion_model, "unet"), (model.structcond_stage_model, "structcond"),
+                      (model.first_stage_model, "first_stage"), (model.flownet_model, "raft")):
+        synth.fill_module_(mod, salt)
+    torch.save({"state_dict": model.state_dict()}, os.path.join(tmp, "model.ckpt"))
+    vq = util.instantiate_from_config(vcfg)
+    synth.fill_module_(vq, "vae")
+    torch.save({"state_dict": vq.state_dict()}, os.path.join(tmp, "vqgan.ckpt"))
+    return ddpm
+
+
+def _harness_frames(tmp, salt, h, w, n):
+    """n smooth, textured, slowly translating LR frames [n,h,w,3] uint8 (so that RAFT has something to match), written as PNGs"""
+    from PIL import Image
+    base = torch.nn.functional.avg_pool2d(torch.sigmoid(synth.synth_tensor(salt, (1, 3, h + 16, w + 16), 1.8)), 5, 1, 2)
+    lr = torch.stack([base[0, :, 4 + 2 * k:4 + 2 * k + h, 6 + k:6 + k + w] for k in range(n)])
+    lr_u8 = (lr.clamp(0, 1) * 255).round().byte().permute(0, 2, 3, 1).numpy()
+    os.makedirs(os.path.join(tmp, "in", "seq0"))
+    for k in range(n):
+        Image.fromarray(lr_u8[k]).save(os.path.join(tmp, "in", "seq0", f"{k:04d}.png"))
+    return lr_u8
+
+
+class _Instrument:
+    """record every torch.randn / randn_like draw and the arguments / result of the sampler entry a script calls"""
+
+    def __init__(self, ddpm, entry):
+        self.ddpm, self.entry, self.draws, self.calls = ddpm, entry, [], []
+
+    def __enter__(self):
+        self.o = (torch.randn, torch.randn_like, getattr(self.ddpm.LatentDiffusionVSRTextWT, self.entry), torch.nn.Module.cuda, sys.argv)
+        o_randn, o_like, o_entry = self.o[:3]
+
+        def randn(*a, **k):
+            t = o_randn(*a, **k)
+            self.draws.append(t.clone())
+            return t
+
+        def randn_like(x, **k):
+            t = o_like(x, **k)
+            self.draws.append(t.clone())
+            return t
+
+        def entry(obj, **kw):
+            out = o_entry(obj, **kw)
+            self.calls.append({"x_T": kw["x_T"].clone(), "ff": kw["flows"][0].clone(), "fb": kw["flows"][1].clone(),
+                               "fo": kw["masks"][0].clone(), "bo": kw["masks"][1].clone(), "lat": kw["struct_cond"].clone(),
+                               "x0": out[0].clone(), "gscale": float(kw["guidance_scale"])})
+            return out
+        torch.randn, torch.randn_like = randn, randn_like
+        setattr(self.ddpm.LatentDiffusionVSRTextWT, self.entry, entry)
+        torch.nn.Module.cuda = lambda m, *a, **k: m
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self.o[0], self.o[1]
+        setattr(self.ddpm.LatentDiffusionVSRTextWT, self.entry, self.o[2])
+        torch.nn.Module.cuda, sys.argv = self.o[3], self.o[4]
+        return False
+
+
+def gen_harness():
+    """H4 (SURVEY 8(a), 8(c) "G9"): the reference's README entry script ITSELF —
+    scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py::main(), imported from the reference tree and run unmodified — on a tiny
+    PNG sequence, with reduced-width networks, synthetic checkpoints written to a temp dir and the third-party modules it cannot
+    import here stubbed (OmegaConf.load -> the reduced configs, Module.cuda -> no-op; the text tower -> a constant context).
+    3 LR frames of 136x136 (-> bicubic x4 = 544x544, already a multiple of 32), 2 DDPM steps, --vqgantile_size 512 /
+    --vqgantile_stride 32 so that the script takes its large-frame branch (2x2 pixel patches of 512^2 through the whole sampler,
+    aggregation sampling with one 64x64 latent tile each; the small-frame branch of the reference raises UnboundLocalError,
+    SURVEY 3.1), RAFT flows, dec_w 0.5, AdaIN.  The fixture holds the LR frames, the noise the script drew (identical for every
+    patch: it re-seeds per patch), per-patch x_T / flows / masks / x_0 and the uint8 HR frames it wrote.  ~1 min: not part of
+    the default run (`make_golden.py harness`)."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="mgld_harness_")
+    Tn, S, LR = T, 2, 136
+    ddpm = _harness_env(tmp, 512)
+    lr_u8 = _harness_frames(tmp, "harness/img", LR, LR, Tn)
+    script = ref_import.ref("scripts.vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile")
+    with _Instrument(ddpm, "sample_canvas") as ins:
+        sys.argv = ["x", "--seqs-path", os.path.join(tmp, "in"), "--outdir", os.path.join(tmp, "out"), "--ddpm_steps", str(S), "--n_frames",
+                    str(Tn), "--config", "diffusion.yaml", "--ckpt", os.path.join(tmp, "model.ckpt"), "--vqgan_ckpt",
+                    os.path.join(tmp, "vqgan.ckpt"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type", "adain", "--vqgantile_size", "512",
+                    "--vqgantile_stride", "32", "--upscale", "4"]
+        with torch.enable_grad():                       # (the generator runs under set_grad_enabled(False); the script manages grad itself)
+            script.main()
+    draws, calls = ins.draws, ins.calls
+    hr = np.stack([np.asarray(Image.open(os.path.join(tmp, "out", "seq0", f"{k:04d}.png")).convert("RGB")) for k in range(Tn)])
+    assert len(calls) == 4 and len(draws) == 4 * (2 + S), (len(calls), len(draws))
+    per = 2 + S
+    for c in range(1, 4):                               # the script re-seeds per patch: every patch sees the same noise
+        for j in range(per):
+            assert torch.equal(draws[c * per + j], draws[j])
+    # (HR frames: every second pixel + per-frame channel means of the full frames; 2.6 MB of uint8 otherwise)
+    out = {"lr_u8": lr_u8, "hr_u8_s2": hr[:, ::2, ::2], "hr_mean": hr.reshape(Tn, -1, 3).astype(np.float64).mean(1),
+           "hr_shape": np.array(hr.shape), "noise_posterior": draws[0], "noise_xT": draws[1],
+           "noise_steps_loop_order": torch.stack(draws[2:2 + S])}
+    for c, rec in enumerate(calls):
+        for k, v in rec.items():
+            if k == "gscale":
+                continue
+            if c == 0 or k in ("x0",):
+                out[f"p{c}_{k}"] = v
+            else:
+                out[f"p{c}_{k}_norm"] = np.array([float(v.double().norm())])
+    save("g_harness", **out)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+def gen_harness_old():
+    """H4, the two fixed-size entry scripts: scripts/vsr_val_ddpm_text_T_vqganfin_old.py::main() and ..._w_latent.py::main() of the
+    reference, run unmodified (same stubbing as gen_harness; torchvision's Resize / CenterCrop — a third-party dependency absent
+    here — stand in as the tensor code path of torchvision 0.13/0.14, the reference's pin: bilinear, align_corners=False, no
+    antialias, smaller edge -> size; torch.cuda.Event / synchronize -> no-ops).  7 frames of 150x110 (-> Lanczos 128x96 -> Resize(64)
+    -> 85x64 -> CenterCrop 64), n_frames 3 (the 7th frame is dropped: no repeat-last padding in these scripts), 2 DDPM steps,
+    full-resolution RAFT flows resized by 1/8, dec_w 0.5, AdaIN.  `make_golden.py harness_old`."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    ref_import.install()
+    torchvision = sys.modules["torchvision"]          # ref_import's stand-in module
+    Tn, S, NF = T, 2, 7
+    out = {}
+
+    class Resize:
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, img):
+            h, w = img.shape[-2:]
+            if w <= h:
+                nw, nh = self.size, int(self.size * h / w)
+            else:
+                nh, nw = self.size, int(self.size * w / h)
+            return torch.nn.functional.interpolate(img, size=[nh, nw], mode="bilinear", align_corners=False, antialias=False)
+
+    class CenterCrop:
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, img):
+            h, w = img.shape[-2:]
+            top, left = int(round((h - self.size) / 2.0)), int(round((w - self.size) / 2.0))
+            return img[..., top:top + self.size, left:left + self.size]
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+    torchvision.transforms.Resize, torchvision.transforms.CenterCrop, torchvision.transforms.Compose = Resize, CenterCrop, Compose
+
+    class _Ev:
+        def __init__(self, *a, **k):
+            pass
+
+        def record(self):
+            pass
+
+        def elapsed_time(self, other):
+            return 0.0
+    o_ev, o_sync = torch.cuda.Event, torch.cuda.synchronize
+    torch.cuda.Event, torch.cuda.synchronize = _Ev, (lambda *a, **k: None)
+    try:
+        for tag, modname in (("old", "scripts.vsr_val_ddpm_text_T_vqganfin_old"), ("wlat", "scripts.vsr_val_ddpm_text_T_vqganfin_w_latent")):
+            tmp = tempfile.mkdtemp(prefix="mgld_harness_old_")
+            ddpm = _harness_env(tmp, 64)
+            lr_u8 = _harness_frames(tmp, "harness_old/img", 110, 150, NF)
+            script = ref_import.ref(modname)
+            with _Instrument(ddpm, "sample") as ins:
+                sys.argv = ["x", "--seqs-path", os.path.join(tmp, "in"), "--outdir", os.path.join(tmp, "out"), "--ddpm_steps", str(S),
+                            "--n_frames", str(Tn), "--config", "diffusion.yaml", "--ckpt", os.path.join(tmp, "model.ckpt"), "--vqgan_ckpt",
+                            os.path.join(tmp, "vqgan.ckpt"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type", "adain", "--input_size", "64"]
+                if tag == "wlat":
+                    sys.argv += ["--latent-dir", os.path.join(tmp, "lat")]
+                with torch.enable_grad():
+                    script.main()
+            names = sorted(os.listdir(os.path.join(tmp, "out", "seq0")))
+            assert names == [f"{k:04d}.png" for k in range(6)] and len(ins.calls) == 2, (names, len(ins.calls))
+            hr = np.stack([np.asarray(Image.open(os.path.join(tmp, "out", "seq0", f)).convert("RGB")) for f in names])
+            per = 2 + S                                  # posterior noise, x_T noise, one draw per step; seeded once: segments differ
+            assert len(ins.draws) == 2 * per
+            out["lr_u8"] = lr_u8
+            out[f"{tag}_hr_u8"] = hr
+            out[f"{tag}_gscale"] = np.array([c["gscale"] for c in ins.calls])
+            for sgi, rec in enumerate(ins.calls):
+                d = ins.draws[sgi * per:(sgi + 1) * per]
+                out[f"{tag}_s{sgi}_noise_posterior"], out[f"{tag}_s{sgi}_noise_xT"] = d[0], d[1]
+                out[f"{tag}_s{sgi}_noise_steps_loop_order"] = torch.stack(d[2:])
+                for k in ("x_T", "ff", "fb", "fo", "bo", "lat", "x0"):
+                    out[f"{tag}_s{sgi}_{k}"] = rec[k]
+            if tag == "wlat":
+                out["wlat_npy"] = np.stack([np.load(os.path.join(tmp, "lat", "seq0", f"{k:04d}.npy")) for k in range(6)])
+            shutil.rmtree(tmp, ignore_errors=True)
+    finally:
+        torch.cuda.Event, torch.cuda.synchronize = o_ev, o_sync
+    save("g_harness_old", **out)
+
+
 def gen_raft():
     """RAFT_SR ('normal') of the reference on synthetic weights: two 3-frame clips of 40x56 LR frames (padding path of
     InputPadder exercised: 40 is a multiple of 8, 56 is; use 44x60 instead) -> compute_flow-style pairs, 4 iterations."""

@@ -39,6 +39,144 @@ def test_cli_runs_on_png_sequence(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_reproduces_a_run_of_the_reference_script(tmp_path):
+    """H4: tests/golden/g_harness.npz holds a run of the REFERENCE's own script main() (reduced nets, 3 LR frames 136x136 -> 544x544,
+    2 DDPM steps, its large-frame branch: 2x2 pixel patches of 512^2, RAFT flows, aggregation sampling, dec_w 0.5, AdaIN; generated
+    by tests/golden/make_golden.py::gen_harness).  The CLI counterpart, fed the same PNGs, the same (synthetic) weights and the
+    noise the script drew, must write the same HR frames, and hand the sampler the same flows / masks / latents per patch."""
+    import importlib.util
+    import torch
+    import yaml
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL
+    from mgld_vsr_amd.pipeline import model_configs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g_harness.npz"))
+    seq = tmp_path / "in" / "seq0"
+    seq.mkdir(parents=True)
+    for k in range(T):
+        Image.fromarray(g["lr_u8"][k]).save(seq / f"{k:04d}.png")
+    dcfg, vcfg = model_configs(T, unet_overrides={k: v for k, v in UNET_SMALL.items() if k != "num_frames"},
+                               struct_overrides={k: v for k, v in STRUCT_SMALL.items() if k != "num_frames"},
+                               vae_overrides=dict(ch=VAE_DD_SMALL["ch"], resolution=512), context_dim=UNET_SMALL["context_dim"])
+    for name, cfg in (("diffusion.yaml", dcfg), ("vae.yaml", vcfg)):
+        with open(tmp_path / name, "w") as fh:
+            yaml.safe_dump({"model": cfg}, fh)
+    spec = importlib.util.spec_from_file_location("mgld_cli_tile", os.path.join(ROOT, "scripts", "vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    S = 2
+    loop = torch.from_numpy(g["noise_steps_loop_order"])          # the script's draws, loop order i = S-1 .. 0
+
+    def noise(Tn, h, w, steps):
+        assert (Tn, h, w, steps) == (T, 64, 64, S)
+        return {"posterior": torch.from_numpy(g["noise_posterior"]), "x_T": torch.from_numpy(g["noise_xT"]), "steps": torch.flip(loop, dims=[0])}
+    cli.NOISE_HOOK, cli.CAPTURE = noise, []
+    cli.main(["--seqs-path", str(tmp_path / "in"), "--outdir", str(tmp_path / "out"), "--ddpm_steps", str(S), "--n_frames", str(T),
+              "--config", str(tmp_path / "diffusion.yaml"), "--vqgan_config", str(tmp_path / "vae.yaml"), "--seed", "42", "--dec_w", "0.5",
+              "--colorfix_type", "adain", "--vqgantile_size", "512", "--vqgantile_stride", "32", "--upscale", "4"])
+    assert len(cli.CAPTURE) == 4                                   # 2 x 2 pixel patches, the reference's patch order
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    c0 = cli.CAPTURE[0]
+    m = {"harness_flow_f": rel(c0["flows"][0].cpu().numpy(), g["p0_ff"]), "harness_flow_b": rel(c0["flows"][1].cpu().numpy(), g["p0_fb"]),
+         "harness_mask_flips": float(np.mean(c0["masks"][0].cpu().numpy() != g["p0_fo"]) + np.mean(c0["masks"][1].cpu().numpy() != g["p0_bo"]))}
+    for c in range(4):
+        m[f"harness_x0_patch{c}"] = rel(cli.CAPTURE[c]["x0"].cpu().numpy(), g[f"p{c}_x0"])
+    hr = np.stack([np.asarray(Image.open(tmp_path / "out" / "seq0" / f"{k:04d}.png").convert("RGB")) for k in range(T)])
+    assert hr.shape == tuple(g["hr_shape"]) and hr.dtype == np.uint8
+    d = hr[:, ::2, ::2].astype(np.int32) - g["hr_u8_s2"].astype(np.int32)
+    m["harness_hr_mean_abs_lsb"], m["harness_hr_max_abs_lsb"] = float(np.abs(d).mean()), float(np.abs(d).max())
+    m["harness_hr_rel_l2"] = rel(hr[:, ::2, ::2], g["hr_u8_s2"])
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "harness_metrics.json"), "w") as fh:
+            json.dump(m, fh, indent=1, sort_keys=True)
+    assert max(m["harness_flow_f"], m["harness_flow_b"]) < 5e-3 and m["harness_mask_flips"] < 2e-2, m
+    assert max(m[f"harness_x0_patch{c}"] for c in range(4)) < 3e-3, m
+    # uint8 frames: the float images agree to ~1e-3, so a pixel differs (by one level) only where its value sits next to a
+    # rounding boundary
+    assert m["harness_hr_mean_abs_lsb"] < 0.6 and m["harness_hr_rel_l2"] < 8e-3, m
+    assert np.abs(hr.reshape(T, -1, 3).astype(np.float64).mean(1) - g["hr_mean"]).max() < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["old", "wlat"])
+def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
+    """H4: tests/golden/g_harness_old.npz holds runs of the reference's scripts/vsr_val_ddpm_text_T_vqganfin_old.py::main() and
+    ..._w_latent.py::main() (make_golden.py::gen_harness_old: 7 frames 150x110 -> Lanczos 128x96 -> Resize(64) + CenterCrop(64),
+    n_frames 3, trailing frame dropped, full-resolution RAFT flows resized by 1/8, their different occlusion-check order and
+    guidance scale, plain model.sample, dec_w 0.5, AdaIN; w_latent also dumps <frame>.npy latents).  The counterparts
+    (mgld_vsr_amd/cli_simple.py) must reproduce frames, per-segment flows / masks / latents and the .npy dump."""
+    import torch
+    import yaml
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL
+    from mgld_vsr_amd import cli_simple
+    from mgld_vsr_amd.pipeline import model_configs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g_harness_old.npz"))
+    seq = tmp_path / "in" / "seq0"
+    seq.mkdir(parents=True)
+    for k in range(g["lr_u8"].shape[0]):
+        Image.fromarray(g["lr_u8"][k]).save(seq / f"{k:04d}.png")
+    dcfg, vcfg = model_configs(T, unet_overrides={k: v for k, v in UNET_SMALL.items() if k != "num_frames"},
+                               struct_overrides={k: v for k, v in STRUCT_SMALL.items() if k != "num_frames"},
+                               vae_overrides=dict(ch=VAE_DD_SMALL["ch"], resolution=64), context_dim=UNET_SMALL["context_dim"])
+    for name, cfg in (("diffusion.yaml", dcfg), ("vae.yaml", vcfg)):
+        with open(tmp_path / name, "w") as fh:
+            yaml.safe_dump({"model": cfg}, fh)
+    S, seg = 2, [0]
+
+    def noise(Tn, h, w, steps):
+        k = seg[0]
+        seg[0] += 1
+        loop = torch.from_numpy(g[f"{tag}_s{k}_noise_steps_loop_order"])
+        return {"posterior": torch.from_numpy(g[f"{tag}_s{k}_noise_posterior"]), "x_T": torch.from_numpy(g[f"{tag}_s{k}_noise_xT"]),
+                "steps": torch.flip(loop, dims=[0])}
+    cli_simple.NOISE_HOOK, cli_simple.CAPTURE = noise, []
+    argv = ["--seqs-path", str(tmp_path / "in"), "--outdir", str(tmp_path / "out"), "--ddpm_steps", str(S), "--n_frames", str(T), "--config",
+            str(tmp_path / "diffusion.yaml"), "--vqgan_config", str(tmp_path / "vae.yaml"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type",
+            "adain", "--input_size", "64"]
+    if tag == "wlat":
+        argv += ["--latent-dir", str(tmp_path / "lat")]
+    try:
+        cli_simple.main(argv, w_latent=(tag == "wlat"))
+    finally:
+        cap, cli_simple.NOISE_HOOK, cli_simple.CAPTURE = cli_simple.CAPTURE, None, None
+    assert sorted(os.listdir(tmp_path / "out" / "seq0")) == [f"{k:04d}.png" for k in range(6)] and len(cap) == 2     # 7th frame dropped
+    assert list(g[f"{tag}_gscale"]) == ([-1.0, -1.0] if tag == "wlat" else [-10.0, -10.0])
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    m = {}
+    for k in range(2):
+        m[f"{tag}_flow_s{k}"] = max(rel(cap[k]["flows"][0].cpu().numpy(), g[f"{tag}_s{k}_ff"]), rel(cap[k]["flows"][1].cpu().numpy(), g[f"{tag}_s{k}_fb"]))
+        m[f"{tag}_mask_flips_s{k}"] = float(np.mean(cap[k]["masks"][0].cpu().numpy() != g[f"{tag}_s{k}_fo"]) +
+                                           np.mean(cap[k]["masks"][1].cpu().numpy() != g[f"{tag}_s{k}_bo"]))
+        m[f"{tag}_x0_s{k}"] = rel(cap[k]["x0"].cpu().numpy(), g[f"{tag}_s{k}_x0"])
+    hr = np.stack([np.asarray(Image.open(tmp_path / "out" / "seq0" / f"{k:04d}.png").convert("RGB")) for k in range(6)])
+    d = hr.astype(np.int32) - g[f"{tag}_hr_u8"].astype(np.int32)
+    m[f"{tag}_hr_mean_abs_lsb"], m[f"{tag}_hr_rel_l2"] = float(np.abs(d).mean()), rel(hr, g[f"{tag}_hr_u8"])
+    if tag == "wlat":
+        lat = np.stack([np.load(tmp_path / "lat" / "seq0" / f"{k:04d}.npy") for k in range(6)])
+        assert lat.shape == g["wlat_npy"].shape
+        m["wlat_npy"] = rel(lat, g["wlat_npy"])
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, f"harness_{tag}_metrics.json"), "w") as fh:
+            json.dump(m, fh, indent=1, sort_keys=True)
+    assert all(m[f"{tag}_flow_s{k}"] < 5e-3 and m[f"{tag}_mask_flips_s{k}"] < 2e-2 and m[f"{tag}_x0_s{k}"] < 3e-3 for k in range(2)), m
+    assert m[f"{tag}_hr_mean_abs_lsb"] < 0.6 and m[f"{tag}_hr_rel_l2"] < 8e-3, m
+    assert tag != "wlat" or m["wlat_npy"] < 3e-3, m
+
+
+@pytest.mark.gpu
 def test_bench_json_line_contract():
     """bench.py prints exactly ONE JSON line with the driver's keys, the roofline object of the dominant kernel and (when
     asked) the CPU baseline; run here on the reduced-width nets (a plumbing check — `config.reduced_width` says so)."""

@@ -194,6 +194,17 @@ def test_preproc_png_payload(hip):
     assert (got == ref).all()                                   # integer payload: bit-exact
 
 
+@pytest.mark.parametrize("h,w,size", [(128, 192, 64), (96, 64, 64), (160, 160, 96), (64, 96, 64)])
+def test_resize_center_crop(hip, h, w, size):
+    """the fixed-size scripts' Resize(input_size) + CenterCrop(input_size) (old.py:253-256) as one device kernel vs torch"""
+    from oracle import preproc as opre
+    x = rnd(2, 3, h, w, seed=91)
+    got = hip.resize_center_crop(x.to(DEV), size).cpu()
+    ref = opre.resize_center_crop(x, size)
+    assert got.shape == ref.shape == (2, 3, size, size)
+    assert float((got - ref).abs().max()) < 2e-6
+
+
 def test_image_spliter_device_vs_reference_fixture(hip):
     """scripts.util_image.ImageSpliterTh on device tensors (crop / accumulate / normalise kernels) against outputs of the
     REFERENCE class captured in tests/golden/g_spliter.npz (iteration order, index tuples, uniform-count gather; sf 1 and 2),
