@@ -199,6 +199,14 @@ class LatentDiffusionVSRTextWT(nn.Module):
             raise NotImplementedError(type(encoder_posterior))
         return self.scale_factor * z
 
+    @torch.no_grad()
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        """ddpm.py:3786-3850 (KL first stage, no split_input_params): first_stage_model.decode(z / scale_factor)"""
+        if predict_cids:
+            raise NotImplementedError("predict_cids belongs to VQ first stages; the VSR model's first stage is a KL autoencoder")
+        self.engine()
+        return self.first_stage_model.decode(z * (1.0 / self.scale_factor))
+
     def get_learned_conditioning(self, c):
         return self.cond_stage_model(c)
 
@@ -556,6 +564,106 @@ class LatentDiffusionVSRTextWT(nn.Module):
         if return_intermediates:
             return out, intermediates
         return out
+
+    # ---- single-step API (ddpm.py:4157-4189, 4191-4322, 4325-4380, 4383-4442) ---------------------------------------------
+    # Inside `sample` / `sample_canvas` a step exists only as a captured launch sequence; these are the same launches issued
+    # eagerly, one network evaluation per call, for callers that drive their own loop.
+    def _eps_canvas(self, x, c, struct_cond, t_in, tile_size, tile_overlap, tile_weights):
+        """aggregation of the tile predictions (ddpm.py:4205-4300): every tile through the struct-cond encoder + UNet in ONE
+        batched pass, Gaussian-weighted accumulation, normalisation"""
+        eng = self.engine()
+        dev = eng.device
+        x = x.to(dev, torch.float32).contiguous()
+        lat = struct_cond.to(dev, torch.float32).contiguous()
+        Tn, ch, h, w = x.shape
+        tiles = self._tile_origins(h, w, tile_size, tile_overlap)
+        xt = torch.empty(len(tiles) * Tn, ch, tile_size, tile_size, device=dev)
+        lt = torch.empty_like(xt)
+        for k, (y0, x0) in enumerate(tiles):
+            hip.crop(x, xt[k * Tn:(k + 1) * Tn], y0, x0)
+            hip.crop(lat, lt[k * Tn:(k + 1) * Tn], y0, x0)
+        tv = t_in.reshape(-1)[:1].to(dev)
+        sc = self.structcond_stage_model(lt, tv)
+        et = self.apply_model(xt, tv, c, sc)
+        wgt = tile_weights[0, 0].to(dev, torch.float32).contiguous() if tile_weights.dim() == 4 else tile_weights.to(dev, torch.float32).contiguous()
+        acc, cnt = torch.zeros_like(x), torch.zeros_like(x)
+        for k, (y0, x0) in enumerate(tiles):
+            hip.tile_accumulate(et[k * Tn:(k + 1) * Tn].contiguous(), wgt, acc, cnt, y0, x0)
+        return hip.tile_normalize(acc, cnt, torch.empty_like(x))
+
+    def _posterior_from_eps(self, x, t, eps, clip_denoised, return_x0):
+        x = x.to(eps.device, torch.float32)
+        x_recon = self.predict_start_from_noise(x, t=t, noise=eps)
+        if clip_denoised:
+            x_recon.clamp_(-1., 1.)
+        mean, var, logvar = self.q_posterior(x_start=x_recon, x_t=x, t=t)
+        return (mean, var, logvar, x_recon) if return_x0 else (mean, var, logvar)
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, c, struct_cond, t, clip_denoised, return_codebook_ids=False, quantize_denoised=False, return_x0=False,
+                        score_corrector=None, corrector_kwargs=None, t_replace=None):
+        """ddpm.py:4157-4189.  struct_cond: the dict the struct-cond encoder returned for this step."""
+        self._check_unsupported(score_corrector=score_corrector, return_codebook_ids=return_codebook_ids or None,
+                                quantize_denoised=quantize_denoised or None)
+        eps = self.apply_model(x, t if t_replace is None else t_replace, c, struct_cond)
+        return self._posterior_from_eps(x, t, eps, clip_denoised, return_x0)
+
+    @torch.no_grad()
+    def p_mean_variance_canvas(self, x, c, struct_cond, t, clip_denoised, return_codebook_ids=False, quantize_denoised=False,
+                               return_x0=False, score_corrector=None, corrector_kwargs=None, t_replace=None, tile_size=64,
+                               tile_overlap=32, batch_size=4, tile_weights=None):
+        """ddpm.py:4191-4322.  struct_cond: the LR latent (the struct-cond encoder runs per tile inside)."""
+        assert tile_weights is not None
+        self._check_unsupported(score_corrector=score_corrector, return_codebook_ids=return_codebook_ids or None,
+                                quantize_denoised=quantize_denoised or None)
+        eps = self._eps_canvas(x, c, struct_cond, t if t_replace is None else t_replace, tile_size, tile_overlap, tile_weights)
+        return self._posterior_from_eps(x, t, eps, clip_denoised, return_x0)
+
+    def _finish_p_sample(self, x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise):
+        mean, logvar = outputs[0], outputs[2]
+        b = x.shape[0] // self.num_frames
+        if noise is None:
+            noise = torch.randn(x.shape, device=mean.device)                   # noise_like (util.py:265-268)
+        noise = noise.to(mean.device, torch.float32) * temperature
+        nonzero = (1 - (t == 0).float()).reshape(b, *((1,) * (x.dim() - 1))).to(mean.device)
+        latents = mean + nonzero * (0.5 * logvar).exp() * noise
+        if flows is not None:                                                  # (:4367-4373) latents -= s * logvar * dL/dlatents
+            eng = self.engine()
+            ff, fb, fo, bo = self._flows_to_device(eng, flows, masks)
+            Tn, ch, h, w = latents.shape
+            coef = torch.zeros(1, 8, device=eng.device)
+            coef[0, 4] = logvar.reshape(-1)[0]
+            out = torch.empty_like(latents)
+            work = torch.empty(hip.guidance_work_bytes(Tn, ch, h, w), dtype=torch.uint8, device=eng.device)
+            hip.guidance(latents.contiguous(), ff, fb, fo, bo, coef, torch.zeros(1, dtype=torch.int32, device=eng.device),
+                         float(guidance_scale), out, work)
+            latents = out
+        return (latents, outputs[3]) if return_x0 else latents
+
+    @torch.no_grad()
+    def p_sample(self, x, c, struct_cond, t, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, clip_denoised=False,
+                 repeat_noise=False, return_codebook_ids=False, quantize_denoised=False, return_x0=False, temperature=1.,
+                 noise_dropout=0., score_corrector=None, corrector_kwargs=None, t_replace=None, noise=None):
+        """ddpm.py:4325-4380: one reverse step.  Extra kwarg `noise`: the step's Gaussian draw (the reference draws it inside)."""
+        self._check_unsupported(lr_images=lr_images, repeat_noise=repeat_noise or None, noise_dropout=noise_dropout or None)
+        outputs = self.p_mean_variance(x=x, c=c, struct_cond=struct_cond, t=t, clip_denoised=clip_denoised,
+                                       return_codebook_ids=return_codebook_ids, quantize_denoised=quantize_denoised, return_x0=return_x0,
+                                       score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, t_replace=t_replace)
+        return self._finish_p_sample(x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise)
+
+    @torch.no_grad()
+    def p_sample_canvas(self, x, c, struct_cond, t, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, clip_denoised=False,
+                        repeat_noise=False, return_codebook_ids=False, quantize_denoised=False, return_x0=False, temperature=1.,
+                        noise_dropout=0., score_corrector=None, corrector_kwargs=None, t_replace=None, tile_size=64, tile_overlap=32,
+                        batch_size=4, tile_weights=None, noise=None):
+        """ddpm.py:4383-4442"""
+        self._check_unsupported(lr_images=lr_images, repeat_noise=repeat_noise or None, noise_dropout=noise_dropout or None)
+        outputs = self.p_mean_variance_canvas(x=x, c=c, struct_cond=struct_cond, t=t, clip_denoised=clip_denoised,
+                                              return_codebook_ids=return_codebook_ids, quantize_denoised=quantize_denoised,
+                                              return_x0=return_x0, score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
+                                              t_replace=t_replace, tile_size=tile_size, tile_overlap=tile_overlap, batch_size=batch_size,
+                                              tile_weights=tile_weights)
+        return self._finish_p_sample(x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise)
 
     def _check_unsupported(self, **kw):
         for k, v in kw.items():

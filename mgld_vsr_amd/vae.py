@@ -171,6 +171,52 @@ class Encoder(nn.Module):
         return h, fea
 
 
+class Decoder(nn.Module):
+    """model.py:575-690, the image decoder of AutoencoderKL (`decode_first_stage`; the VSR scripts decode with the video VAE, this
+    one serves `LatentDiffusionVSRTextWT.decode_first_stage` / `AutoencoderKL.decode`)."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0, resamp_with_conv=True,
+                 in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False, use_linear_attn=False, attn_type="vanilla",
+                 **ignorekwargs):
+        super().__init__()
+        assert not attn_resolutions and not give_pre_end and not tanh_out and not use_linear_attn
+        self.ch, self.num_resolutions, self.num_res_blocks, self.out_ch = ch, len(ch_mult), num_res_blocks, out_ch
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, 1, 1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+            up = nn.Module()
+            up.block, up.attn = block, nn.ModuleList()
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+            self.up.insert(0, up)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
+
+    def run(self, eng, z):
+        h = _conv3(eng, self.conv_in, z)
+        h = self.mid.block_1.run(eng, h)
+        h = self.mid.attn_1.run(eng, h)
+        h = self.mid.block_2.run(eng, h)
+        for lvl in reversed(range(self.num_resolutions)):
+            for blk in self.up[lvl].block:
+                h = blk.run(eng, h)
+            if lvl != 0:
+                h = self.up[lvl].upsample.run(eng, h)
+        t = _gn(eng, self.norm_out, h, True)
+        out = Act(eng.arena.alloc((h.rows, self.out_ch), torch.float32), h.n, h.h, h.w)
+        return _conv3(eng, self.conv_out, t, out=out)
+
+
 class ResBlock(nn.Module):
     """model.py:1312-1335 (fusion-layer residual block: GN/swish/conv x2, 1x1 conv_out on the skip)."""
 
@@ -366,7 +412,8 @@ class _AutoencoderBase(nn.Module):
 
 
 class AutoencoderKL(_AutoencoderBase):
-    """ldm/models/autoencoder.py:299 — only the encode path is on the VSR hot path (init latent, ddpm.py:3906-3943)."""
+    """ldm/models/autoencoder.py:299 — encode is on the VSR hot path (init latent, ddpm.py:3906-3943); decode (:361) backs
+    `decode_first_stage`."""
 
     def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=[], image_key="image",
                  colorize_nlabels=None, monitor=None, **kw):
@@ -374,16 +421,24 @@ class AutoencoderKL(_AutoencoderBase):
         self.embed_dim = embed_dim
         with _meta_module():
             self.encoder = Encoder(**ddconfig)
+            self.decoder = Decoder(**ddconfig)
             self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
             self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self._finish_init()
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys)
 
-    def load_state_dict(self, sd, strict=True):
-        # public SD checkpoints also hold decoder.* weights of the image decoder, unused by the VSR path
-        own = set(self.state_dict().keys())
-        return super().load_state_dict({k: v for k, v in sd.items() if k in own or not k.startswith("decoder.")}, strict=strict)
+    @torch.no_grad()
+    def decode(self, z):
+        """autoencoder.py:361-364: post_quant_conv -> Decoder.  z [n, embed_dim, h, w] -> [n, 3, 8h, 8w] fp32 on the device."""
+        eng = self.engine()
+        eng.reset()
+        za = eng.from_nchw(z.to(eng.device, torch.float32))
+        wq = eng.weight("c1", (self.post_quant_conv.weight,), lambda t: pack_conv1x1(t, za.C))
+        zq = eng.act(za.n, za.h, za.w, 8)
+        zq.v.zero_()
+        eng.linear(za, wq, eng.f32("b", self.post_quant_conv.bias), out=zq.cols(0, self.post_quant_conv.out_channels))
+        return eng.to_nchw(self.decoder.run(eng, zq), self.decoder.out_ch)
 
     @torch.no_grad()
     def encode(self, x, return_encfea=False):

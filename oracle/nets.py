@@ -392,3 +392,21 @@ def vae_decode(sd, ddconfig, z, enc_fea, fusion_w=1.0, num_fuse_block=2):
         if lvl != 0:
             h = conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), p.sub(f"up.{lvl}.upsample.conv"), padding=1)
     return conv(swish(gn(h, p.sub("norm_out"), 1e-6)), p.sub("conv_out"), padding=1)
+
+
+def vae_image_decode(sd, ddconfig, z, prefix=""):
+    """AutoencoderKL.decode (autoencoder.py:361-364) -> Decoder.forward (model.py:648-690): the image decoder behind
+    decode_first_stage (ddpm.py:3786)."""
+    n_res, nrb = len(ddconfig["ch_mult"]), ddconfig["num_res_blocks"]
+    z = conv(z, SD(sd, prefix + "post_quant_conv."))
+    p = SD(sd, prefix + "decoder.")
+    h = conv(z, p.sub("conv_in"), padding=1)
+    h = vae_resnet(h, p.sub("mid.block_1"))
+    h = vae_attn(h, p.sub("mid.attn_1"))
+    h = vae_resnet(h, p.sub("mid.block_2"))
+    for lvl in reversed(range(n_res)):
+        for b in range(nrb + 1):
+            h = vae_resnet(h, p.sub(f"up.{lvl}.block.{b}"))
+        if lvl != 0:
+            h = conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), p.sub(f"up.{lvl}.upsample.conv"), padding=1)
+    return conv(swish(gn(h, p.sub("norm_out"), 1e-6)), p.sub("conv_out"), padding=1)

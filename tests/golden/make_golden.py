@@ -266,6 +266,47 @@ def gen_sample(model, ddpm):
     save("g_sample", **out)
 
 
+def gen_pstep(model, ddpm):
+    """The single-step API (ddpm.py:4157-4189, 4325-4380, 4191-4322, 4383-4442) and decode_first_stage (:3786) of the reference on the
+    reduced model: one p_mean_variance / p_sample (guided) at schedule index 2 of a 4-step schedule, one p_sample_canvas on a 24x24
+    latent with 16/8 tiles, and first_stage_model.decode through decode_first_stage."""
+    uf = ref_import.ref("scripts.util_flow")
+    S, i = 4, 2
+    respace(model, S)
+    ctx = model.cond_stage_model([""])
+    out = {}
+    for tag, (h, w) in (("plain", (16, 16)), ("canvas", (24, 24))):
+        x = synth.synth_tensor(f"pstep/{tag}/x", (T, 4, h, w))
+        lat = synth.synth_tensor(f"pstep/{tag}/lat", (T, 4, h, w), 0.5)
+        nz = synth.synth_tensor(f"pstep/{tag}/noise", (T, 4, h, w))
+        ff, fb = synth.smooth_flow(f"pstep/{tag}/ff", T - 1, h, w), synth.smooth_flow(f"pstep/{tag}/fb", T - 1, h, w)
+        focc, bocc = uf.forward_backward_consistency_check(fb, ff)
+        flows, masks = (ff[None], fb[None]), (focc[None, :, None], bocc[None, :, None])
+        ts = torch.full((1,), i, dtype=torch.long)
+        t_rep = torch.tensor([model.ori_timesteps[i]] * T).long()
+        orig = ddpm.noise_like
+        ddpm.noise_like = lambda shape, device, repeat=False: nz
+        try:
+            if tag == "plain":
+                sc = model.structcond_stage_model(lat, t_rep)
+                mean, var, logvar, x0 = model.p_mean_variance(x=x, c=ctx, struct_cond=sc, t=ts, clip_denoised=False, return_x0=True, t_replace=t_rep)
+                z = model.p_sample(x, ctx, sc, ts, guidance_scale=-10.0, flows=flows, masks=masks, t_replace=t_rep)
+            else:
+                tw = model._gaussian_weights(16, 16, 1)
+                mean, var, logvar, x0 = model.p_mean_variance_canvas(x=x, c=ctx, struct_cond=lat, t=ts, clip_denoised=False, return_x0=True,
+                                                                     t_replace=t_rep[:1], tile_size=16, tile_overlap=8, batch_size=1, tile_weights=tw)
+                z = model.p_sample_canvas(x, ctx, lat, ts, guidance_scale=-10.0, flows=flows, masks=masks, t_replace=t_rep[:1], tile_size=16,
+                                          tile_overlap=8, batch_size=1, tile_weights=tw)
+        finally:
+            ddpm.noise_like = orig
+        out.update({f"{tag}_x": x, f"{tag}_lat": lat, f"{tag}_noise": nz, f"{tag}_ff": ff, f"{tag}_fb": fb, f"{tag}_focc": focc, f"{tag}_bocc": bocc,
+                    f"{tag}_mean": mean, f"{tag}_var": var, f"{tag}_logvar": logvar, f"{tag}_x0": x0, f"{tag}_z": z})
+    zl = synth.synth_tensor("pstep/dec/z", (T, 4, 8, 8))
+    out["dec_z"], out["dec_out"] = zl, model.decode_first_stage(zl)
+    out["ctx"] = ctx
+    save("g_pstep", **out)
+
+
 def gen_fullwidth():
     """G10: BASELINE configs[0] at FULL width through the reference's own classes — one 512x512 frame (T = 1,
     latent 64x64), 4 DDPM steps, no flows: first-stage encode -> q_sample_respace -> model.sample -> video-VAE encode /
@@ -605,10 +646,11 @@ def gen_signatures():
     want = {
         "ldm/models/diffusion/ddpm.py": {"LatentDiffusionVSRTextWT": ["sample", "sample_canvas", "p_sample_loop", "p_sample_loop_canvas", "compute_flow",
                                                                       "compute_temporal_condition_v4", "apply_model", "get_learned_conditioning",
-                                                                      "encode_first_stage", "_gaussian_weights"],
+                                                                      "encode_first_stage", "_gaussian_weights", "p_sample", "p_sample_canvas",
+                                                                      "p_mean_variance", "p_mean_variance_canvas", "decode_first_stage"],
                                          "DDPM": ["q_sample", "q_sample_respace", "predict_start_from_noise", "q_posterior", "register_schedule"]},
         "ldm/modules/diffusionmodules/openaimodel.py": {"InflatedUNetModelDualcondV2": ["forward"], "InflatedEncoderUNetModelWT": ["forward"]},
-        "ldm/models/autoencoder.py": {"VideoAutoencoderKLResi": ["encode", "decode", "init_from_ckpt"], "AutoencoderKL": ["encode", "init_from_ckpt"]},
+        "ldm/models/autoencoder.py": {"VideoAutoencoderKLResi": ["encode", "decode", "init_from_ckpt"], "AutoencoderKL": ["encode", "decode", "init_from_ckpt"]},
         "ldm/modules/encoders/modules.py": {"FrozenOpenCLIPEmbedder": ["__init__", "freeze", "forward", "encode", "encode_with_transformer"]},
         "scripts/util_image.py": {"ImageSpliterTh": ["__init__", "extract_starts", "update", "gather"]},
         "basicsr/archs/raft_arch.py": {"RAFT_SR": ["__init__", "forward"]},
@@ -659,7 +701,11 @@ def gen_spliter():
 if __name__ == "__main__":
     if len(sys.argv) > 1:            # e.g. `make_golden.py raft`: regenerate selected fixtures only
         for what in sys.argv[1:]:
-            globals()["gen_" + what]()
+            fn = globals()["gen_" + what]
+            if what == "pstep":
+                fn(*build_ref_model())
+            else:
+                fn()
         sys.exit(0)
     gen_raft()
     gen_flow()
@@ -671,3 +717,4 @@ if __name__ == "__main__":
     gen_unet(model)
     gen_first_stage(model)
     gen_sample(model, ddpm)
+    gen_pstep(model, ddpm)

@@ -155,6 +155,39 @@ def test_sample_small_vs_golden(hip, tag):
     assert torch.isfinite(loss)
 
 
+def test_single_step_api_and_decode_first_stage_vs_golden(hip):
+    """p_mean_variance / p_sample / p_mean_variance_canvas / p_sample_canvas (ddpm.py:4157-4442) as eager single steps and
+    decode_first_stage (ddpm.py:3786 -> AutoencoderKL.decode) against the reference's outputs (g_pstep.npz)"""
+    g = G("g_pstep")
+    model = _small_model()
+    S, i = 4, 2
+    _respace(model, S)
+    ts = torch.full((1,), i, dtype=torch.long)
+    t_rep = torch.tensor([model.ori_timesteps[i]] * T)
+    for tag in ("plain", "canvas"):
+        x, lat, nz = g[f"{tag}_x"], g[f"{tag}_lat"], g[f"{tag}_noise"]
+        flows, masks = (g[f"{tag}_ff"][None], g[f"{tag}_fb"][None]), (g[f"{tag}_focc"][None, :, None], g[f"{tag}_bocc"][None, :, None])
+        if tag == "plain":
+            sc = model.structcond_stage_model(lat.cuda(), t_rep.cuda())
+            mean, var, logvar, x0 = model.p_mean_variance(x=x, c=g["ctx"], struct_cond=sc, t=ts, clip_denoised=False, return_x0=True,
+                                                         t_replace=t_rep)
+            z = model.p_sample(x, g["ctx"], sc, ts, guidance_scale=-10.0, flows=flows, masks=masks, t_replace=t_rep, noise=nz)
+        else:
+            tw = model._gaussian_weights(16, 16, 1)
+            mean, var, logvar, x0 = model.p_mean_variance_canvas(x=x, c=g["ctx"], struct_cond=lat, t=ts, clip_denoised=False, return_x0=True,
+                                                                t_replace=t_rep[:1], tile_size=16, tile_overlap=8, batch_size=1, tile_weights=tw)
+            z = model.p_sample_canvas(x, g["ctx"], lat, ts, guidance_scale=-10.0, flows=flows, masks=masks, t_replace=t_rep[:1], tile_size=16,
+                                      tile_overlap=8, batch_size=1, tile_weights=tw, noise=nz)
+        assert record(f"pstep_{tag}_x0", rel_l2(x0, g[f"{tag}_x0"])) < 2e-3
+        assert record(f"pstep_{tag}_mean", rel_l2(mean, g[f"{tag}_mean"])) < 2e-3
+        assert abs(float(logvar.reshape(-1)[0]) - float(g[f"{tag}_logvar"].reshape(-1)[0])) < 1e-6
+        assert abs(float(var.reshape(-1)[0]) - float(g[f"{tag}_var"].reshape(-1)[0])) < 1e-9
+        assert record(f"pstep_{tag}_z", rel_l2(z, g[f"{tag}_z"])) < 2e-3
+    dec = model.decode_first_stage(g["dec_z"].cuda())
+    assert dec.shape == g["dec_out"].shape
+    assert record("first_stage_image_decode", rel_l2(dec, g["dec_out"])) < 2.5e-3
+
+
 def test_sample_hoisting_windows_are_equivalent(hip, monkeypatch):
     """the struct-cond / SPADE tables hoisted out of the step are built window by window under a memory budget
     (ddpm._hoist_window; the CLI's default 1000-step schedule would otherwise need [1000, ...] tables): a 7-step guided sample

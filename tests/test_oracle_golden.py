@@ -184,6 +184,42 @@ def test_text_tower_golden():
 
 
 
+def test_single_step_and_image_decode_golden():
+    """oracle vs the reference's single-step API (p_mean_variance / p_sample / the canvas variants) and decode_first_stage (g_pstep.npz)"""
+    g, gu, gf = G("g_pstep"), G("g_unet"), G("g_first_stage")
+    usd, ssd = sd_from(gu, "unet_params", "unet"), sd_from(gu, "struct_params", "structcond")
+    S, i = 4, 2
+    _, buf, ori = osched.respaced_schedule(S)
+    for tag, tile in (("plain", None), ("canvas", (16, 8))):
+        x, lat, nz = g[f"{tag}_x"], g[f"{tag}_lat"], g[f"{tag}_noise"]
+        flows, masks = (g[f"{tag}_ff"][None], g[f"{tag}_fb"][None]), (g[f"{tag}_focc"][None, :, None], g[f"{tag}_bocc"][None, :, None])
+        with torch.no_grad():
+            if tile is None:
+                eps = osamp.eps_model(usd, UNET_SMALL, ssd, STRUCT_SMALL, x, lat, ori[i], g["ctx"])
+            else:
+                ts, ov = tile
+                wgt = osamp.gaussian_weights(ts, ts)
+                acc, cnt = torch.zeros_like(x), torch.zeros_like(x)
+                for (y0, x0) in osamp.tile_origins(x.shape[2], x.shape[3], ts, ov):
+                    e = osamp.eps_model(usd, UNET_SMALL, ssd, STRUCT_SMALL, x[:, :, y0:y0 + ts, x0:x0 + ts], lat[:, :, y0:y0 + ts, x0:x0 + ts],
+                                        ori[i], g["ctx"])
+                    acc[:, :, y0:y0 + ts, x0:x0 + ts] += e * wgt
+                    cnt[:, :, y0:y0 + ts, x0:x0 + ts] += wgt
+                eps = acc / cnt
+            x0 = buf["sqrt_recip_alphas_cumprod"][i] * x - buf["sqrt_recipm1_alphas_cumprod"][i] * eps
+            mean = buf["posterior_mean_coef1"][i] * x0 + buf["posterior_mean_coef2"][i] * x
+            assert rel_l2(x0, g[f"{tag}_x0"]) < 1e-5 and rel_l2(mean, g[f"{tag}_mean"]) < 1e-5
+            assert abs(float(buf["posterior_log_variance_clipped"][i]) - float(g[f"{tag}_logvar"].reshape(-1)[0])) < 1e-6
+            z, logvar = osched.p_step(buf, i, x, eps, nz)
+            z, _ = oflow.guidance_update(z, flows, masks, T, -10.0, logvar)
+            assert rel_l2(z, g[f"{tag}_z"]) < 1e-5
+    fsd = sd_from(gf, "params", "first_stage")
+    dd = dict(VAE_DD_SMALL)
+    with torch.no_grad():
+        dec = nets.vae_image_decode(fsd, dd, g["dec_z"] / 0.18215)
+    assert rel_l2(dec, g["dec_out"]) < 1e-5
+
+
 def fullwidth_c1_inputs():
     """inputs of the config-1 full-width case (tests/golden/make_golden.py::gen_fullwidth), regenerated from the synth recipes"""
     Tn, S, H, h = 1, 4, 512, 64
