@@ -62,11 +62,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None, help="comma list of substrings: run only the shapes whose name contains one of them")
     args = ap.parse_args()
     hip.lib()
     hip.ensure_workspace()
     dev = "cuda"
     shapes = {"conv": CONV, "vae": VAE, "lin": LIN, "all": CONV + VAE + LIN}[args.what]
+    if args.only:
+        shapes = [sh for sh in shapes if any(o.replace("_", " ") in sh[0] for o in args.only.split(","))]
     variants = [int(v) for v in args.variants.split(",")]
     nsts = [int(v) for v in args.nst.split(",")]
     allv = sorted(set(variants) | set(nsts))
