@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--frame-shard", action="store_true",
                     help="N>1: split the frames of ONE segment over the ranks (halo exchange / all-gather over RCCL, strong "
                          "scaling of a single segment) instead of one segment per rank")
+    ap.add_argument("--tile-shard", action="store_true",
+                    help="N>1 with --tile: split the latent tiles of ONE segment's aggregation sampling over the ranks (one all-gather "
+                         "of the tiles' eps per step; BASELINE configs[3]) instead of one segment per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
@@ -303,6 +306,12 @@ def main():
     kw = dict(flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH)
     if shard is not None:
         kw.update(shard=shard, gather=True)
+    if args.tile_shard and args.tile and world > 1:
+        frames, noise, flows, masks = make_inputs(pipe, args, 0)     # every rank builds the SAME clip
+        h8 = args.size // 8
+        n_tiles = len(pipe.model._tile_origins(h8, h8, TILE[0], TILE[1]))
+        shard = parallel.TileShard(n_tiles, rank, world)
+        kw = dict(flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH, tile_shard=shard)
 
     def step():
         if args.raft and args.guidance:
@@ -330,7 +339,8 @@ def main():
                                f"+ temporal video decoder + AdaIN, flow-guided warp {'on' if args.guidance else 'off'}{', aggregation sampling 64/32' if args.tile else ''}; "
                                + ("one segment, frames sharded over the GPUs" if shard is not None else "one segment per GPU"),
                    "frames_per_segment": args.frames,
-                   "parallelism": f"frame-sharded x{world}" if shard is not None else f"segment-parallel x{world}", "finite": ok,
+                   "parallelism": (f"tile-sharded x{world}" if args.tile_shard and shard is not None else f"frame-sharded x{world}")
+                   if shard is not None else f"segment-parallel x{world}", "finite": ok,
                    "reduced_width": bool(args.small)},
         "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
                                                           GFLOP_DEC_PER_FRAME) / 1e3 / (dt / args.steps), 1),

@@ -434,19 +434,28 @@ class LatentDiffusionVSRTextWT(nn.Module):
             ts = st["tile_size"]
             nt = len(st["tiles"])
             T, c = x.shape[0], x.shape[1]
-            xt = eng.arena.alloc((nt * T, c, ts, ts), torch.float32)
-            for k, (y0, x0) in enumerate(st["tiles"]):
-                hip.crop(x, xt[k * T:(k + 1) * T], y0, x0)
-            xa = eng.from_nchw(xt)
-            sc = self._structcond_of_step(eng, st, st["lat_tiles"])
-            e = unet.run(eng, xa, st["tvals"], None, st["ctx"], sc)
-            et = eng.arena.alloc((nt * T, c, ts, ts), torch.float32)
-            hip.nhwc_to_nchw(e.v, et)
+            tsh = eng.tile_shard
+            mine = list(enumerate(st["tiles"])) if tsh is None else list(enumerate(st["tiles"]))[tsh.k0:tsh.k1]
+            nl = len(mine) if tsh is None else tsh.per          # local tile slots (zero-padded to `per` when sharded)
+            xt = eng.arena.alloc((max(1, len(mine)) * T, c, ts, ts), torch.float32)
+            for j, (k, (y0, x0)) in enumerate(mine):
+                hip.crop(x, xt[j * T:(j + 1) * T], y0, x0)
+            et = eng.arena.alloc((nl * T, c, ts, ts), torch.float32)
+            if mine:
+                xa = eng.from_nchw(xt[:len(mine) * T])
+                sc = self._structcond_of_step(eng, st, st["lat_tiles"])
+                e = unet.run(eng, xa, st["tvals"], None, st["ctx"], sc)
+                hip.nhwc_to_nchw(e.v, et[:len(mine) * T])
+            if tsh is not None:
+                if len(mine) < nl:
+                    et[len(mine) * T:].zero_()
+                et = tsh.gather(et)                              # every tile's eps on every rank (one exchange per step)
             acc, cnt = st["acc"], st["cnt"]
             acc.zero_()
             cnt.zero_()
             for k, (y0, x0) in enumerate(st["tiles"]):
-                hip.tile_accumulate(et[k * T:(k + 1) * T], st["wgt"], acc, cnt, y0, x0)
+                j = k if tsh is None else tsh.slot(k)
+                hip.tile_accumulate(et[j * T:(j + 1) * T], st["wgt"], acc, cnt, y0, x0)
             eps = st["eps_canvas"]
             hip.tile_normalize(acc, cnt, eps)
         if st["guided"]:
@@ -521,12 +530,19 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 ts, ov = tile
                 tiles = self._tile_origins(h, w, ts, ov)
                 st["tiles"], st["tile_size"] = tiles, ts
-                lt = torch.empty(len(tiles) * T_total, c, ts, ts, device=dev)
-                for k, (y0, x0) in enumerate(tiles):
+                tsh = eng.tile_shard
+                if tsh is not None:
+                    if tsh.n_tiles != len(tiles):
+                        raise ValueError(f"tile shard built for {tsh.n_tiles} tiles, this canvas has {len(tiles)}")
+                    use_graph = use_graph and tsh.world == 1     # the tile exchange sits between the launches of a step
+                own = tiles if tsh is None else tiles[tsh.k0:tsh.k1]
+                n_own = max(1, len(own))
+                lt = torch.zeros(n_own * T_total, c, ts, ts, device=dev)
+                for k, (y0, x0) in enumerate(own):
                     hip.crop(lat, lt[k * T_total:(k + 1) * T_total], y0, x0)
-                la = torch.empty(len(tiles) * T_total * ts * ts, 8, dtype=torch.float16, device=dev)
+                la = torch.empty(n_own * T_total * ts * ts, 8, dtype=torch.float16, device=dev)
                 hip.nchw_to_nhwc(lt, la, 8)
-                st["lat_tiles"] = Act(la, len(tiles) * T_total, ts, ts)
+                st["lat_tiles"] = Act(la, n_own * T_total, ts, ts)
                 st["wgt"] = self._gaussian_weights(ts, ts, 1)[0, 0].to(dev, torch.float32).contiguous()
                 st["acc"], st["cnt"], st["eps_canvas"] = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
             lat_in = st["lat_act"] if tile is None else st["lat_tiles"]

@@ -179,6 +179,7 @@ class Engine:
         self._c3p_geo, self._c3p_w = {}, {}     # patch-conv applicability per geometry / tiled weights per packed tensor
         self.launches = 0
         self.shard = None   # parallel.FrameShard when the frames of one segment are split over ranks
+        self.tile_shard = None   # parallel.TileShard when the latent tiles of aggregation sampling are split over ranks
         # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
         self._splitk_ws = hip.ensure_workspace(workspace_bytes) if self.device.type == "cuda" else None
 

@@ -127,6 +127,11 @@ class DistComm:
                 req.wait()
 
 
+    def gather_tiles(self, t, shard):
+        """[per*rows, ...] (this rank's tiles, zero-padded to `per` tiles) -> [world*per*rows, ...] in rank order"""
+        return self.all_gather(t, shard)
+
+
 class RecordingComm:
     """World-size-1 transport that keeps a copy of every tensor handed to it: the full-clip reference trace that
     ReplayComm serves to a virtual rank (single-GPU validation of the sharded math, tests/test_nets_gpu.py)."""
@@ -142,6 +147,10 @@ class RecordingComm:
         self.trace.append(("halo", x.detach().clone()))
         recv_left.zero_()
         recv_right.zero_()
+
+    def gather_tiles(self, t, shard):
+        self.trace.append(("tiles", t.detach().clone()))
+        return t
 
 
 class ReplayComm:
@@ -177,6 +186,42 @@ class ReplayComm:
             recv_right.copy_(full[hi:hi + rows_per_frame])
         else:
             recv_right.zero_()
+
+
+    def gather_tiles(self, t, shard):
+        k, full = self.trace[self.pos]
+        self.pos += 1
+        assert k == "tiles", f"communication sequence diverged: expected {k}, got tiles"
+        rows = t.shape[0] // shard.per                       # rows of one tile
+        valid = (shard.k1 - shard.k0) * rows
+        mine = full[shard.k0 * rows:shard.k0 * rows + valid]
+        den = float(mine.float().norm()) + 1e-30
+        self.worst = max(self.worst, float((t[:valid].float() - mine.float()).norm()) / den)
+        out = torch.zeros((shard.world * shard.per * rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[:full.shape[0]] = full
+        return out
+
+
+class TileShard:
+    """Aggregation sampling (sample_canvas, ddpm.py:4191-4322) over ranks — BASELINE configs[3], SURVEY 8(e) "Tiled path": the
+    overlapping latent tiles of a step are independent (struct-cond encoder + UNet) clips.  Rank r evaluates tiles [k0, k1) of the
+    reference's tile order; ONE all-gather per step brings every tile's eps to every rank, which then stitches the canvas with the
+    Gaussian weights and runs the (tiny) posterior + guidance on the whole canvas, replicated.  Tiles are dealt in contiguous
+    blocks of `per` = ceil(n_tiles / world); the last ranks' missing tiles are zero padding in the exchange."""
+
+    def __init__(self, n_tiles, rank, world, comm=None):
+        self.n_tiles, self.rank, self.world = int(n_tiles), int(rank), int(world)
+        self.per = -(-self.n_tiles // self.world)
+        self.k0 = min(self.rank * self.per, self.n_tiles)
+        self.k1 = min(self.k0 + self.per, self.n_tiles)
+        self.comm = comm if comm is not None else DistComm()
+
+    def slot(self, k):
+        """position of global tile k in the gathered buffer (in tiles)"""
+        return (k // self.per) * self.per + (k % self.per)
+
+    def gather(self, t):
+        return self.comm.gather_tiles(t, self)
 
 
 class FrameShard:

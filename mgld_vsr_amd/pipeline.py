@@ -156,7 +156,7 @@ class VSRPipeline:
 
     @torch.no_grad()
     def run_segment(self, frames, flows=None, masks=None, guidance_scale=-10.0, noise=None, tile=None, use_graph=True,
-                    return_latents=False, shard=None, gather=True, clamp01=True, init_from_vq=False):
+                    return_latents=False, shard=None, gather=True, clamp01=True, init_from_vq=False, tile_shard=None):
         """frames: [T,3,H,W] in [-1,1] (the bicubically pre-upsampled LR segment, device or host);
         flows/masks as the reference passes them to sample(); noise: optional dict with 'posterior' [T,4,h,w],
         'x_T' [T,4,h,w], 'steps' [S,T,4,h,w].  Returns HR frames [T,3,H,W] in [0,1] on the device.
@@ -169,14 +169,27 @@ class VSRPipeline:
         eng.shard = shard
         try:
             return self._run_segment(eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents,
-                                     shard, gather, clamp01, init_from_vq)
+                                     shard, gather, clamp01, init_from_vq, tile_shard)
         finally:
             eng.shard = None
+            eng.tile_shard = None
 
     def _run_segment(self, eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents, shard, gather,
-                     clamp01=True, init_from_vq=False):
+                     clamp01=True, init_from_vq=False, tile_shard=None):
         m, vq = self.model, self.vq_model
         noise = dict(noise or {})
+        fs = None          # frame split of the VAE work around a tile-sharded sampler
+        if tile_shard is not None:
+            if tile is None or shard is not None:
+                raise ValueError("tile_shard belongs to aggregation sampling (tile=...) and excludes frame sharding of the sampler")
+            if tile_shard.world > 1 and frames.shape[0] % tile_shard.world == 0:
+                from .parallel import FrameShard
+                fs = FrameShard(frames.shape[0], tile_shard.rank, tile_shard.world)
+            lat_shape = (frames.shape[0], 4, frames.shape[2] // 8, frames.shape[3] // 8)
+            g = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)       # the same draws on every rank
+            for k, shp in (("posterior", lat_shape), ("x_T", lat_shape), ("steps", (self.ddpm_steps,) + lat_shape)):
+                if noise.get(k) is None:
+                    noise[k] = torch.randn(shp, generator=g)
         if shard is not None:
             if tile is not None:
                 raise NotImplementedError("frame sharding and aggregation sampling are separate multi-GPU schemes")
@@ -195,12 +208,16 @@ class VSRPipeline:
         x = frames.to(eng.device, torch.float32).contiguous()
         T = x.shape[0]
         enc_fea = None
-        if init_from_vq:
-            post, enc_fea = vq.encode(x)
-        else:
-            post = m.encode_first_stage(x)
         pn = noise.get("posterior")
-        init_latent = m.get_first_stage_encoding(post, pn if pn is not None else torch.randn(post.mean.shape))
+        if fs is not None:         # first-stage encode of this rank's frames, latents of the whole clip by all-gather
+            post = m.encode_first_stage(fs.local(x).contiguous())
+            init_latent = fs.all_gather(m.get_first_stage_encoding(post, fs.local(pn)).contiguous())
+        else:
+            if init_from_vq:
+                post, enc_fea = vq.encode(x)
+            else:
+                post = m.encode_first_stage(x)
+            init_latent = m.get_first_stage_encoding(post, pn if pn is not None else torch.randn(post.mean.shape))
         ctx = m.cond_stage_model([""])
         n0 = noise.get("x_T")
         n0 = torch.randn_like(init_latent) if n0 is None else n0.to(eng.device)
@@ -211,10 +228,19 @@ class VSRPipeline:
         if tile is None:
             samples = m.sample(**kw)
         else:
-            samples = m.sample_canvas(tile_size=tile[0], tile_overlap=tile[1], batch_size_sample=1, **kw)
+            eng.tile_shard = tile_shard
+            try:
+                samples = m.sample_canvas(tile_size=tile[0], tile_overlap=tile[1], batch_size_sample=1, **kw)
+            finally:
+                eng.tile_shard = None
+        if fs is not None:         # video VAE on this rank's frames: the 13 temporal convolutions exchange one-frame halos
+            eng.shard = fs
+            x, z_loc = fs.local(x).contiguous(), fs.local(samples).contiguous()
+        else:
+            z_loc = samples
         if enc_fea is None:
             _, enc_fea = vq.encode(x)
-        x_samples = vq.decode(samples * (1.0 / m.scale_factor), enc_fea)
+        x_samples = vq.decode(z_loc * (1.0 / m.scale_factor), enc_fea)
         if self.colorfix_type == "adain":
             x_samples = adaptive_instance_normalization(x_samples, x)
         elif self.colorfix_type == "wavelet":
@@ -224,4 +250,6 @@ class VSRPipeline:
         out = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0) if clamp01 else x_samples
         if shard is not None and gather and shard.world > 1:
             out, samples = shard.all_gather(out), shard.all_gather(samples)
+        if fs is not None:
+            out = fs.all_gather(out.contiguous())
         return (out, samples) if return_latents else out

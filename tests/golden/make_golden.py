@@ -509,9 +509,11 @@ def gen_harness_old():
     """H4, the two fixed-size entry scripts: scripts/vsr_val_ddpm_text_T_vqganfin_old.py::main() and ..._w_latent.py::main() of the
     reference, run unmodified (same stubbing as gen_harness; torchvision's Resize / CenterCrop — a third-party dependency absent
     here — stand in as the tensor code path of torchvision 0.13/0.14, the reference's pin: bilinear, align_corners=False, no
-    antialias, smaller edge -> size; torch.cuda.Event / synchronize -> no-ops).  7 frames of 150x110 (-> Lanczos 128x96 -> Resize(64)
-    -> 85x64 -> CenterCrop 64), n_frames 3 (the 7th frame is dropped: no repeat-last padding in these scripts), 2 DDPM steps,
-    full-resolution RAFT flows resized by 1/8, dec_w 0.5, AdaIN.  `make_golden.py harness_old`."""
+    antialias, smaller edge -> size; torch.cuda.Event / synchronize -> no-ops).  7 frames of 224x160 (Lanczos leaves them as they
+    are: both sides are multiples of 32 -> Resize(128) -> 179x128 -> CenterCrop 128), n_frames 3 (the 7th frame is dropped: no
+    repeat-last padding in these scripts), 2 DDPM steps, full-resolution RAFT flows resized by 1/8, dec_w 0.5, AdaIN.  (128 px is
+    the smallest frame the reference's RAFT handles: at 64 px its 4-level correlation pyramid ends in a 1x1 level whose
+    coordinate normalisation divides by W - 1 = 0 and the flows come out NaN.)  `make_golden.py harness_old`."""
     import shutil
     import tempfile
     from PIL import Image
@@ -565,13 +567,13 @@ def gen_harness_old():
     try:
         for tag, modname in (("old", "scripts.vsr_val_ddpm_text_T_vqganfin_old"), ("wlat", "scripts.vsr_val_ddpm_text_T_vqganfin_w_latent")):
             tmp = tempfile.mkdtemp(prefix="mgld_harness_old_")
-            ddpm = _harness_env(tmp, 64)
-            lr_u8 = _harness_frames(tmp, "harness_old/img", 110, 150, NF)
+            ddpm = _harness_env(tmp, 128)
+            lr_u8 = _harness_frames(tmp, "harness_old/img", 160, 224, NF)
             script = ref_import.ref(modname)
             with _Instrument(ddpm, "sample") as ins:
                 sys.argv = ["x", "--seqs-path", os.path.join(tmp, "in"), "--outdir", os.path.join(tmp, "out"), "--ddpm_steps", str(S),
                             "--n_frames", str(Tn), "--config", "diffusion.yaml", "--ckpt", os.path.join(tmp, "model.ckpt"), "--vqgan_ckpt",
-                            os.path.join(tmp, "vqgan.ckpt"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type", "adain", "--input_size", "64"]
+                            os.path.join(tmp, "vqgan.ckpt"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type", "adain", "--input_size", "128"]
                 if tag == "wlat":
                     sys.argv += ["--latent-dir", os.path.join(tmp, "lat")]
                 with torch.enable_grad():
@@ -582,6 +584,7 @@ def gen_harness_old():
             per = 2 + S                                  # posterior noise, x_T noise, one draw per step; seeded once: segments differ
             assert len(ins.draws) == 2 * per
             out["lr_u8"] = lr_u8
+            assert bool(torch.isfinite(ins.calls[0]["ff"]).all())
             out[f"{tag}_hr_u8"] = hr
             out[f"{tag}_gscale"] = np.array([c["gscale"] for c in ins.calls])
             for sgi, rec in enumerate(ins.calls):

@@ -96,7 +96,9 @@ def test_cli_reproduces_a_run_of_the_reference_script(tmp_path):
         with open(os.path.join(out, "harness_metrics.json"), "w") as fh:
             json.dump(m, fh, indent=1, sort_keys=True)
     assert max(m["harness_flow_f"], m["harness_flow_b"]) < 5e-3 and m["harness_mask_flips"] < 2e-2, m
-    assert max(m[f"harness_x0_patch{c}"] for c in range(4)) < 3e-3, m
+    # (a 2-step schedule multiplies the first step's eps error by sqrt(1/abar_999 - 1) ~ 14 in the x0 prediction: the latents of
+    # this run agree to ~1.5e-2, not to the ~1e-3 of the 50-step schedules; the frames — what the script writes — to 2e-3)
+    assert max(m[f"harness_x0_patch{c}"] for c in range(4)) < 3e-2, m
     # uint8 frames: the float images agree to ~1e-3, so a pixel differs (by one level) only where its value sits next to a
     # rounding boundary
     assert m["harness_hr_mean_abs_lsb"] < 0.6 and m["harness_hr_rel_l2"] < 8e-3, m
@@ -107,7 +109,7 @@ def test_cli_reproduces_a_run_of_the_reference_script(tmp_path):
 @pytest.mark.parametrize("tag", ["old", "wlat"])
 def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
     """H4: tests/golden/g_harness_old.npz holds runs of the reference's scripts/vsr_val_ddpm_text_T_vqganfin_old.py::main() and
-    ..._w_latent.py::main() (make_golden.py::gen_harness_old: 7 frames 150x110 -> Lanczos 128x96 -> Resize(64) + CenterCrop(64),
+    ..._w_latent.py::main() (make_golden.py::gen_harness_old: 7 frames 224x160 -> Resize(128) (179x128) + CenterCrop(128),
     n_frames 3, trailing frame dropped, full-resolution RAFT flows resized by 1/8, their different occlusion-check order and
     guidance scale, plain model.sample, dec_w 0.5, AdaIN; w_latent also dumps <frame>.npy latents).  The counterparts
     (mgld_vsr_amd/cli_simple.py) must reproduce frames, per-segment flows / masks / latents and the .npy dump."""
@@ -125,7 +127,7 @@ def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
         Image.fromarray(g["lr_u8"][k]).save(seq / f"{k:04d}.png")
     dcfg, vcfg = model_configs(T, unet_overrides={k: v for k, v in UNET_SMALL.items() if k != "num_frames"},
                                struct_overrides={k: v for k, v in STRUCT_SMALL.items() if k != "num_frames"},
-                               vae_overrides=dict(ch=VAE_DD_SMALL["ch"], resolution=64), context_dim=UNET_SMALL["context_dim"])
+                               vae_overrides=dict(ch=VAE_DD_SMALL["ch"], resolution=128), context_dim=UNET_SMALL["context_dim"])
     for name, cfg in (("diffusion.yaml", dcfg), ("vae.yaml", vcfg)):
         with open(tmp_path / name, "w") as fh:
             yaml.safe_dump({"model": cfg}, fh)
@@ -140,7 +142,7 @@ def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
     cli_simple.NOISE_HOOK, cli_simple.CAPTURE = noise, []
     argv = ["--seqs-path", str(tmp_path / "in"), "--outdir", str(tmp_path / "out"), "--ddpm_steps", str(S), "--n_frames", str(T), "--config",
             str(tmp_path / "diffusion.yaml"), "--vqgan_config", str(tmp_path / "vae.yaml"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type",
-            "adain", "--input_size", "64"]
+            "adain", "--input_size", "128"]
     if tag == "wlat":
         argv += ["--latent-dir", str(tmp_path / "lat")]
     try:
@@ -171,9 +173,9 @@ def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
         import json
         with open(os.path.join(out, f"harness_{tag}_metrics.json"), "w") as fh:
             json.dump(m, fh, indent=1, sort_keys=True)
-    assert all(m[f"{tag}_flow_s{k}"] < 5e-3 and m[f"{tag}_mask_flips_s{k}"] < 2e-2 and m[f"{tag}_x0_s{k}"] < 3e-3 for k in range(2)), m
+    assert all(m[f"{tag}_flow_s{k}"] < 5e-3 and m[f"{tag}_mask_flips_s{k}"] < 2e-2 and m[f"{tag}_x0_s{k}"] < 3e-2 for k in range(2)), m
     assert m[f"{tag}_hr_mean_abs_lsb"] < 0.6 and m[f"{tag}_hr_rel_l2"] < 8e-3, m
-    assert tag != "wlat" or m["wlat_npy"] < 3e-3, m
+    assert tag != "wlat" or m["wlat_npy"] < 3e-2, m
 
 
 @pytest.mark.gpu

@@ -309,7 +309,7 @@ def test_conv3p_planner_routes_the_unet_convolutions():
                      ((8, 328, 320, 64, 64), {}),                  # Cin % 32 != 0
                      ((8, 96, 64, 16, 16), dict(tap_inner=1))]:    # (64-block, tap, c) order needs Cin % 64 == 0
         assert code(*args, **kw) < 300000, (args, kw)
-    assert not hip.conv3p_applies(8, 1280, 1280, 8, 8)
+    assert hip.conv3p_applies(8, 1280, 1280, 8, 8) and not hip.conv3p_applies(8, 1280, 1280, 4, 4)
 
     # tiled weights (tap_inner = 2, what the engine feeds): the 2-D-tile patch kernel, code 400000 + variant id
     def qcode(frames, cin, cout, h, w, up2=0, tune=0):
@@ -327,7 +327,8 @@ def test_conv3p_planner_routes_the_unet_convolutions():
     assert qcode(1, 64, 64, 8, 8, up2=1) == 400000
     assert qcode(8, 320, 320, 64, 64, tune=5) == 400004
     assert hip.conv3p_applies(8, 256, 256, 128, 128) and hip.conv3p_applies(5, 512, 512, 90, 120) and hip.conv3p_applies(8, 512, 512, 64, 64, True)
-    assert qcode(8, 1280, 1280, 8, 8) < 300000 and qcode(8, 320, 4, 64, 64) < 300000
+    assert qcode(8, 1280, 1280, 8, 8) == 400006         # 8x8 level: one 8x8 tile per frame (split along the channel slices on a GPU)
+    assert qcode(8, 320, 4, 64, 64) < 300000 and qcode(8, 64, 64, 8, 12) < 300000
 
 
 def _spliter_case(ImageSpliterTh, g, sf, to_dev=lambda t: t):

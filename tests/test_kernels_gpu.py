@@ -343,10 +343,38 @@ def test_igemm_conv3x3_tile2d_upsample(hip, variant, n, cin, cout, h, w):
     assert rel_l2(_from_tok(out.cpu().float(), n, 2 * h, 2 * w), ref) < 1e-3
 
 
+@pytest.mark.parametrize("n,cin,cout,epi", [(8, 1280, 1280, 2), (3, 512, 512, 1), (2, 256, 128, 0), (1, 128, 2560, 0), (5, 64, 96, 0)])
+def test_igemm_conv3x3_tile2d_8x8(hip, n, cin, cout, epi):
+    """conv3q on the 8x8 UNet level (one 8x8 tile per frame, 128 weight rows, K split over the channel slices) vs conv2d"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    h = w = 8
+    x = h16(rnd(n, cin, h, w, seed=190))
+    wt = h16(rnd(cout, cin, 3, 3, seed=191, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=192)
+    ref = F.conv2d(x.float(), wt.float(), b, padding=1)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    kw = {}
+    if epi == 1:
+        r = h16(rnd(n * h * w, cout, seed=193))
+        kw = dict(resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+        ref = 0.5 * F.silu(ref) + 2.0 * _from_tok(r.float(), n, h, w)
+    elif epi == 2:
+        emb = rnd(n, cout, seed=194)
+        kw = dict(rowvec=emb.to(DEV), rows_per_frame=h * w)
+        ref = ref + emb[:, :, None, None]
+    assert hip.conv3p_applies(n, cin, cout, h, w)
+    out = torch.full((n * h * w, cout), float("nan"), dtype=torch.half, device=DEV)
+    hip.igemm(_to_tok(x).to(DEV), tile_conv3p(wk, cin, False), out, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=(cin, h, w, h, w, 1, 1, 1, 0),
+              tap_inner=2, N=cout, K=9 * cin, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
+
+
 def test_igemm_tiled_weights_rejected_off_the_patch_path(hip):
     """tap_inner = 2 is only defined for problems the patch kernel takes: anything else must fail loudly"""
     from mgld_vsr_amd.engine import tile_conv3p
-    n, cin, cout, h, w = 1, 64, 64, 8, 8            # W = 8: im2col path
+    n, cin, cout, h, w = 1, 64, 64, 4, 4            # 4x4 frames: im2col path
     assert not hip.conv3p_applies(n, cin, cout, h, w)
     x = _to_tok(h16(rnd(n, cin, h, w, seed=75))).to(DEV)
     wk = h16(rnd(cout, 9 * cin, seed=76)).to(DEV)

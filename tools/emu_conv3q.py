@@ -122,11 +122,14 @@ def lds_conflicts(TY, TX, WM, UP2):
 
 if __name__ == "__main__":
     cases = [(8, 16, 64, 32, 32, False), (16, 16, 64, 64, 32, False), (8, 16, 128, 64, 32, False), (16, 16, 128, 64, 64, False),
-             (8, 32, 64, 64, 32, False), (8, 16, 64, 64, 32, False), (8, 16, 64, 32, 32, True), (16, 16, 64, 64, 32, True)]
+             (8, 32, 64, 64, 32, False), (8, 16, 64, 64, 32, False), (8, 16, 64, 32, 32, True), (16, 16, 64, 64, 32, True),
+             (8, 8, 128, 32, 32, False)]
     for c in cases:
         TY, TX, BN, WM, WN, UP2 = c
         sc = 2 if UP2 else 1
         Hin, Win = (24 // sc) * 1, (40 // sc) * 1          # ragged in both directions for every tile shape
+        if TX == 8:
+            Hin = Win = 8
         tiles = (-(-Hin * sc // TY)) * (-(-Win * sc // TX))
         e = sum(check(*c, frames=2, Hin=Hin, Win=Win, Cin=64, N=96, tile_m=tm, tile_n=tn) for tm in (0, tiles - 1, tiles, 2 * tiles - 1)
                 for tn in range(-(-96 // BN)))
