@@ -224,15 +224,17 @@ def roofline(pipe, args, frames, noise, flows, masks):
 
 
 def cpu_baseline(args):
-    """Oracle (CPU restatement, fp32, 32 torch threads) on a bounded sample: ONE frame at 512x512 through one
-    DDPM step (struct-cond + UNet), one VAE encode and one VAE video decode; extrapolated to the 50-step pipeline."""
+    """Oracle (CPU restatement, fp32, up to 32 torch threads) on a bounded sample of the same workload: a TWO-frame 512x512 clip
+    (so the temporal modules — Conv3d over T, temporal attention — run) through one DDPM step (struct-cond + UNet), one VAE encode
+    and one VAE video decode; extrapolated linearly in steps to the 50-step pipeline (every step is identical work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
     from mgld_vsr_amd import synth
     from oracle import nets as onets
     cores = min(32, os.cpu_count() or 1)   # more threads than this thrash on the small per-layer problems
     torch.set_num_threads(cores)
-    ucfg, scfg, vdd = dict(UNET_FULL, num_frames=1), dict(STRUCT_FULL, num_frames=1), dict(VAE_DD_FULL, num_frames=1)
+    Tc = 2
+    ucfg, scfg, vdd = dict(UNET_FULL, num_frames=Tc), dict(STRUCT_FULL, num_frames=Tc), dict(VAE_DD_FULL, num_frames=Tc)
     from ldm.models.autoencoder import VideoAutoencoderKLResi
     from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
 
@@ -243,10 +245,10 @@ def cpu_baseline(args):
     vsd = synth.synth_state_dict(names(VideoAutoencoderKLResi(ddconfig=vdd, lossconfig={"target": "torch.nn.Identity"},
                                                               embed_dim=4)), "vae")
     h = args.size // 8
-    x, lat = synth.synth_tensor("cpu/x", (1, 4, h, h)), synth.synth_tensor("cpu/lat", (1, 4, h, h), 0.5)
+    x, lat = synth.synth_tensor("cpu/x", (Tc, 4, h, h)), synth.synth_tensor("cpu/lat", (Tc, 4, h, h), 0.5)
     ctx = synth.synth_tensor("ctx", (1, 77, 1024))
-    img = synth.synth_tensor("cpu/img", (1, 3, args.size, args.size), 0.5)
-    t = torch.tensor([541])
+    img = synth.synth_tensor("cpu/img", (Tc, 3, args.size, args.size), 0.5)
+    t = torch.tensor([541] * Tc)
     with torch.no_grad():
         t0 = time.time()
         sc = onets.structcond_forward(ssd, scfg, lat, t)
@@ -258,11 +260,11 @@ def cpu_baseline(args):
         t0 = time.time()
         onets.vae_decode(vsd, vdd, x, fea)
         t_dec = time.time() - t0
-    per_frame = args.ddpm_steps * t_step + 2 * t_enc + t_dec
+    per_frame = (args.ddpm_steps * t_step + 2 * t_enc + t_dec) / Tc
     return {"value": round(1.0 / per_frame, 5), "unit": "HR frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 on 1 frame {args.size}x{args.size}: 1 DDPM step (struct-cond+UNet) {t_step:.2f}s, "
+            "sample": f"oracle fp32 on a {Tc}-frame {args.size}x{args.size} clip: 1 DDPM step (struct-cond+UNet) {t_step:.2f}s, "
                       f"1 VAE encode {t_enc:.2f}s, 1 VAE video-decode {t_dec:.2f}s; extrapolated to "
-                      f"{args.ddpm_steps} steps + 2 encodes + 1 decode per frame"}
+                      f"{args.ddpm_steps} steps + 2 encodes + 1 decode"}
 
 
 TILE = None

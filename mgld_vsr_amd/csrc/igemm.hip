@@ -32,6 +32,10 @@ namespace {
 #endif
 constexpr int ABL = MGLD_IGEMM_ABLATE;
 
+#ifndef MGLD_IGEMM_PF
+#define MGLD_IGEMM_PF 1         // LDS fragment prefetch distance of igemm_kernel's k loop (k-steps ahead); 2 in A/B builds
+#endif
+constexpr int IG_PF = MGLD_IGEMM_PF;
 constexpr int BK = 64;          // k depth per stage (fp16 elements) = 128 B per tile row
 constexpr int ROWB = BK * 2;    // bytes per tile row in LDS
 
@@ -502,8 +506,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     const char* sb = smem + cur * STAGE;
     cur = (cur + 1 == NST) ? 0 : cur + 1;
     if constexpr (ABL & 128) continue;  // ablation build (timing only): no LDS reads, no MFMA
-    // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run (two register sets, static indices)
-    f16x8 fa[2][MI], fw[2][NI];
+    // fragments of k-step ks+IG_PF are fetched from LDS while the MFMAs of k-step ks run (IG_PF + 1 register sets, static indices)
+    f16x8 fa[IG_PF + 1][MI], fw[IG_PF + 1][NI];
     auto load_frags = [&](int ks, int set) {
       const int cl = ks * 2 + lhi;
 #pragma unroll
@@ -511,21 +515,22 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) fw[set][ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
     };
-    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < IG_PF; ++ks) load_frags(ks, ks);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + 1 < BK / 16) load_frags(ks + 1, (ks + 1) & 1);
+      if (ks + IG_PF < BK / 16) load_frags(ks + IG_PF, (ks + IG_PF) % (IG_PF + 1));
       if constexpr (ABL & 32) {  // ablation build: keep the LDS reads, skip the matrix pipe
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[ks & 1][mi]));
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[ks % (IG_PF + 1)][mi]));
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ks & 1][ni]));
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ks % (IG_PF + 1)][ni]));
       } else {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks & 1][ni], fa[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks % (IG_PF + 1)][ni], fa[ks % (IG_PF + 1)][mi], acc[ni][mi], 0, 0, 0);
       }
     }
   }
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
 // and tap (dy, dx) of output pixel (y, x) reads low-res pixel ((y+dy-1)>>1, (x+dx-1)>>1); zero padding of the upsampled image falls on
 // out-of-image low-res pixels.  256-pixel tiles (16x16, 8x32) run eight waves of 64 pixels x 32 channels: 3 fragment reads per 2 MFMAs
 // instead of 2 per 1 and half the weight bytes per FLOP of the 128-pixel tiles.  Weights: the tiled layout of tap_inner = 2 only.
-template <int TY, int TX, int BN, int WM, int WN, bool UP2>
+template <int TY, int TX, int BN, int WM, int WN, bool UP2, int PF = 1>
 __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kernel(const MgldIGemm p, float* __restrict__ ws, int hchunk,
                                                                                   int tiles_x, int tiles_y) {
   constexpr int BM = TY * TX;
@@ -893,7 +898,9 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
       else if (more) issue_b(cur ^ 1, h + 1, 0);
       const int abase = pa * A_BYTES;
       const int bb = B_BASE + cur * B_BYTES;
-      f16x8 fa[2][MI], fw[2][NI];
+      // fragments of step u + PF are fetched from LDS while the MFMAs of step u run (PF + 1 register sets, static indices);
+      // PF = 2 gives a ds_read_b128 two MFMA groups (~128 issue cycles) instead of one to land
+      f16x8 fa[PF + 1][MI], fw[PF + 1][NI];
       auto load = [&](const int u, const int set) {
         const int dxi = u >> 1, kx = (u & 1) << 5;           // second 16-channel step: logical chunk ^ 2 = byte offset ^ 32
 #pragma unroll
@@ -901,15 +908,16 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fw[set][ni] = *(const f16x8*)(smem + bb + dxi * BSUB + (w_off[ni] ^ kx));
       };
-      load(0, 0);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) load(u, u);
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
-        if (u + 1 < 6) load(u + 1, (u + 1) & 1);
+        if (u + PF < 6) load(u + PF, (u + PF) % (PF + 1));
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u & 1][ni], fa[u & 1][mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u % (PF + 1)][ni], fa[u % (PF + 1)][mi], acc[ni][mi], 0, 0, 0);
       }
       cur ^= 1;
     }
@@ -1165,7 +1173,8 @@ int launch_conv3p(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
 //   0: 8x16 x 64, 32x32 (8 waves)      1: 16x16 x 64, 64x32 (8 waves)     2: 8x16 x 128, 64x32 (8 waves)
 //   3: 16x16 x 128, 64x64 (8 waves)    4: 8x32 x 64, 64x32 (8 waves)      5: 8x16 x 64, 64x32 (4 waves)
 //   6: 8x8 x 128, 32x32 (8 waves): the 8x8 UNet level, one tile per frame
-constexpr int Q3_NVAR = 7;
+//   7: as 4 with fragments prefetched two steps ahead       8: as 5 with fragments prefetched two steps ahead
+constexpr int Q3_NVAR = 9;
 template <int TY, int TX, int BN, int WM, int WN, bool UP2>
 constexpr int conv3q_lds() {
   constexpr int PW = UP2 ? TX / 2 + 2 : TX + 2, PH = UP2 ? TY / 2 + 2 : TY + 2;
@@ -1181,6 +1190,8 @@ inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
     case 4: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 32, false>(); break;
     case 5: *ty = 8; *tx = 16; *bn = 64; *lds = conv3q_lds<8, 16, 64, 64, 32, false>(); break;
     case 6: *ty = 8; *tx = 8; *bn = 128; *lds = conv3q_lds<8, 8, 128, 32, 32, false>(); break;
+    case 7: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 32, false>(); break;
+    case 8: *ty = 8; *tx = 16; *bn = 64; *lds = conv3q_lds<8, 16, 64, 64, 32, false>(); break;
     default: *ty = 8; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<8, 16, 64, 32, 32, true>() : conv3q_lds<8, 16, 64, 32, 32, false>(); break;
   }
 }
@@ -1211,6 +1222,7 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   else v = (p->Wout >= 32 && t832 >= 448) ? 4 : 5;
   if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1) && p->Wout >= 16 && force != 6) v = force;
   if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2) && p->Wout >= 16 && p->tune != 7) v = p->tune - 1;
+  if (v >= 7 && p->Wout < 32 && v == 7) v = 8;
   int ty, tx, bn, lds;
   q3_geom(v, &ty, &tx, &bn, &lds, p->up2 != 0);
   const int64_t tiles = (int64_t)frames * cdiv(p->Hout, ty) * cdiv(p->Wout, tx) * cdiv(N, bn);
@@ -1225,19 +1237,19 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   return true;
 }
 
-template <int TY, int TX, int BN, int WM, int WN, bool UP2>
+template <int TY, int TX, int BN, int WM, int WN, bool UP2, int PF = 1>
 int launch_conv3q(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
   constexpr int lds = conv3q_lds<TY, TX, BN, WM, WN, UP2>();
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3q_kernel<TY, TX, BN, WM, WN, UP2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const int frames = p->M / (p->Hout * p->Wout);
   const int tiles_x = cdiv(p->Wout, TX), tiles_y = cdiv(p->Hout, TY);
   dim3 grid(frames * tiles_x * tiles_y, cdiv(p->N, BN), splits > 1 ? splits : 1);
   constexpr int THREADS = 64 * (TY * TX / WM) * (BN / WN);
-  hipLaunchKernelGGL((conv3q_kernel<TY, TX, BN, WM, WN, UP2>), grid, dim3(THREADS), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk,
+  hipLaunchKernelGGL((conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF>), grid, dim3(THREADS), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk,
                      tiles_x, tiles_y);
   if (splits > 1) {
     const int64_t total = (int64_t)p->M * ((p->N + 3) >> 2);
@@ -1257,6 +1269,8 @@ int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int h
     case 4: return launch_conv3q<8, 32, 64, 64, 32, false>(p, s, splits, hchunk);
     case 5: return launch_conv3q<8, 16, 64, 64, 32, false>(p, s, splits, hchunk);
     case 6: return launch_conv3q<8, 8, 128, 32, 32, false>(p, s, splits, hchunk);
+    case 7: return launch_conv3q<8, 32, 64, 64, 32, false, 2>(p, s, splits, hchunk);
+    case 8: return launch_conv3q<8, 16, 64, 64, 32, false, 2>(p, s, splits, hchunk);
     default: return launch_conv3q<8, 16, 64, 32, 32, false>(p, s, splits, hchunk);
   }
 }
@@ -1284,8 +1298,9 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
   MGLD_REQUIRE(p && buf && buflen > 0, "igemm_kernel_name: null");
   int cfg, splits, kchunk;
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
-    static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32}};
-    snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false");
+    static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}};
+    snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s, %d>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false",
+             cfg >= 7 ? 2 : 1);
     return splits;
   }
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) {

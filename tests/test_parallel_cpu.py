@@ -142,6 +142,63 @@ def test_frame_shard_replay_matches_recording():
         parallel.FrameShard(5, 0, 2)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# tile sharding of aggregation sampling (parallel.TileShard, BASELINE configs[3]): the per-step exchange of the tiles' eps
+# ----------------------------------------------------------------------------------------------------------------------
+def _tile_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mgld_vsr_amd import parallel
+    parallel.init(backend="gloo")
+    n_tiles, T, c, ts = 9, 2, 4, 6
+    sh = parallel.TileShard(n_tiles, rank, world)
+    # every tile's "eps" encodes its global tile index; missing tiles of the last ranks are zero padding
+    loc = torch.zeros(sh.per * T, c, ts, ts)
+    for j, k in enumerate(range(sh.k0, sh.k1)):
+        loc[j * T:(j + 1) * T] = float(k + 1)
+    full = sh.gather(loc)
+    got = [float(full[sh.slot(k) * T, 0, 0, 0]) for k in range(n_tiles)]
+    ret[rank] = (got, sh.k0, sh.k1, tuple(full.shape))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tile_shard_gather(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tile_worker, args=(world, port, ret), nprocs=world, join=True)
+    per = -(-9 // world)
+    covered = []
+    for r in range(world):
+        got, k0, k1, shape = ret[r]
+        assert got == [float(k + 1) for k in range(9)]        # every rank sees every tile, addressed by slot(k)
+        assert shape == (world * per * 2, 4, 6, 6)
+        covered += list(range(k0, k1))
+    assert covered == list(range(9))                           # contiguous blocks, every tile exactly once
+
+
+def test_tile_shard_replay_matches_recording():
+    sys.path.insert(0, ROOT)
+    from mgld_vsr_amd import parallel
+    n_tiles, rows = 9, 3
+    full = torch.randn(n_tiles * rows, 5)
+    rec = parallel.RecordingComm()
+    assert parallel.TileShard(n_tiles, 0, 1, rec).gather(full) is full
+    for world in (2, 4):
+        for rank in range(world):
+            rp = parallel.ReplayComm(rec.trace)
+            sh = parallel.TileShard(n_tiles, rank, world, rp)
+            loc = torch.zeros(sh.per * rows, 5)
+            loc[:(sh.k1 - sh.k0) * rows] = full[sh.k0 * rows:sh.k1 * rows]
+            out = sh.gather(loc)
+            assert out.shape[0] == world * sh.per * rows and rp.worst == 0.0
+            for k in range(n_tiles):
+                assert torch.equal(out[sh.slot(k) * rows:(sh.slot(k) + 1) * rows], full[k * rows:(k + 1) * rows])
+
+
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus N` (no torchrun around it, as the driver invokes it) must start the N ranks itself: the launcher is
     re-executed under torch.distributed.run and rank 0 reports the world size the process group really had (gloo here; the GPU
