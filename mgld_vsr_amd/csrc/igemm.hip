@@ -1173,8 +1173,8 @@ int launch_conv3p(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
 //   0: 8x16 x 64, 32x32 (8 waves)      1: 16x16 x 64, 64x32 (8 waves)     2: 8x16 x 128, 64x32 (8 waves)
 //   3: 16x16 x 128, 64x64 (8 waves)    4: 8x32 x 64, 64x32 (8 waves)      5: 8x16 x 64, 64x32 (4 waves)
 //   6: 8x8 x 128, 32x32 (8 waves): the 8x8 UNet level, one tile per frame
-//   7: as 4 with fragments prefetched two steps ahead       8: as 5 with fragments prefetched two steps ahead
-constexpr int Q3_NVAR = 9;
+// (fragments prefetched TWO steps ahead — template parameter PF = 2 — measured identical to PF = 1 on every shape: not instantiated)
+constexpr int Q3_NVAR = 7;
 template <int TY, int TX, int BN, int WM, int WN, bool UP2>
 constexpr int conv3q_lds() {
   constexpr int PW = UP2 ? TX / 2 + 2 : TX + 2, PH = UP2 ? TY / 2 + 2 : TY + 2;
@@ -1190,8 +1190,6 @@ inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
     case 4: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 32, false>(); break;
     case 5: *ty = 8; *tx = 16; *bn = 64; *lds = conv3q_lds<8, 16, 64, 64, 32, false>(); break;
     case 6: *ty = 8; *tx = 8; *bn = 128; *lds = conv3q_lds<8, 8, 128, 32, 32, false>(); break;
-    case 7: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 32, false>(); break;
-    case 8: *ty = 8; *tx = 16; *bn = 64; *lds = conv3q_lds<8, 16, 64, 64, 32, false>(); break;
     default: *ty = 8; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<8, 16, 64, 32, 32, true>() : conv3q_lds<8, 16, 64, 32, 32, false>(); break;
   }
 }
@@ -1210,19 +1208,19 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   if (p->Wout < 16 && (p->up2 || p->Wout != 8 || p->Hout != 8)) return false;     // below 16 pixels: only the 8x8 level
   const int frames = p->M / (p->Hout * p->Wout), N = p->N, nh = p->Cin >> 5;
   // variant by measurement (tools/igemm_bench.py on MI355X, cold operands; profiles/r02_conv3q_variants.txt):
-  //   nearest-2x fold: the 8x16 tile (its low-res patch is 6x10 pixels: DMA-light already; the 16x16 tile only loses occupancy);
+  //   nearest-2x fold: 16x16 tiles (low-res patch 10x10) while they give ~2 blocks per CU (209 vs 241 us on 640 -> 640 at 32 -> 64), else 8x16;
   //   16x16 frames with N % 128 == 0: one 16x16 tile = the whole frame, 128 weight rows, 64x64 wave tiles;
   //   W >= 32: 8x32 tiles (256 pixels, conflict-free fragment reads) while they still give ~2 blocks per CU, else 8x16 tiles run by
   //   four waves of 64 pixels x 32 channels (3 blocks per CU).
   const int64_t t832 = (int64_t)frames * cdiv(p->Hout, 8) * cdiv(p->Wout, 32) * cdiv(N, 64);
+  const int64_t t256 = (int64_t)frames * cdiv(p->Hout, 16) * cdiv(p->Wout, 16) * cdiv(N, 64);
   int v;
-  if (p->up2) v = 0;
+  if (p->up2) v = (t256 >= 448) ? 1 : 0;
   else if (p->Wout == 8) v = 6;
   else if (p->Wout == 16 && p->Hout == 16 && (N & 127) == 0) v = 3;
   else v = (p->Wout >= 32 && t832 >= 448) ? 4 : 5;
   if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1) && p->Wout >= 16 && force != 6) v = force;
   if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2) && p->Wout >= 16 && p->tune != 7) v = p->tune - 1;
-  if (v >= 7 && p->Wout < 32 && v == 7) v = 8;
   int ty, tx, bn, lds;
   q3_geom(v, &ty, &tx, &bn, &lds, p->up2 != 0);
   const int64_t tiles = (int64_t)frames * cdiv(p->Hout, ty) * cdiv(p->Wout, tx) * cdiv(N, bn);
@@ -1269,8 +1267,6 @@ int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int h
     case 4: return launch_conv3q<8, 32, 64, 64, 32, false>(p, s, splits, hchunk);
     case 5: return launch_conv3q<8, 16, 64, 64, 32, false>(p, s, splits, hchunk);
     case 6: return launch_conv3q<8, 8, 128, 32, 32, false>(p, s, splits, hchunk);
-    case 7: return launch_conv3q<8, 32, 64, 64, 32, false, 2>(p, s, splits, hchunk);
-    case 8: return launch_conv3q<8, 16, 64, 64, 32, false, 2>(p, s, splits, hchunk);
     default: return launch_conv3q<8, 16, 64, 32, 32, false>(p, s, splits, hchunk);
   }
 }
@@ -1298,9 +1294,9 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
   MGLD_REQUIRE(p && buf && buflen > 0, "igemm_kernel_name: null");
   int cfg, splits, kchunk;
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
-    static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}};
+    static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32}};
     snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s, %d>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false",
-             cfg >= 7 ? 2 : 1);
+             1);
     return splits;
   }
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) {
