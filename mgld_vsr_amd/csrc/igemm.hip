@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   // A wave waits only for ITS OWN stage-kt loads with a counted vmcnt (newer stages stay in flight across the
   // barrier), then the barrier makes every wave's stage kt visible and retires all reads of the buffer about to be
   // refilled.
-  static_assert(NST >= 2 && NST <= 4, "2 .. 4 stages");
+  static_assert(NST == 0 || (NST >= 2 && NST <= 4), "2 .. 4 DMA stages, or 0 = register-staged tiles (two LDS buffers)");
   // wave-uniform K position of the NEXT stage to issue; kept in this scope as plain scalars (SGPRs)
   int u_tap = __builtin_amdgcn_readfirstlane(s_tap), u_c0 = __builtin_amdgcn_readfirstlane(s_c0);
 #define MGLD_ADVANCE_TAP()                                                            \
@@ -474,6 +474,69 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
       u_tap = wrap_ ? u_tap + 1 : u_tap;                                              \
     }                                                                                 \
   }
+  // MFMAs of one 64-deep stage held in the LDS buffer `sb`
+  auto compute_stage = [&](const char* sb) {
+    if constexpr (ABL & 128) return;  // ablation build (timing only): no LDS reads, no MFMA
+    // fragments of k-step ks+IG_PF are fetched from LDS while the MFMAs of k-step ks run (IG_PF + 1 register sets, static indices)
+    f16x8 fa[IG_PF + 1][MI], fw[IG_PF + 1][NI];
+    auto load_frags = [&](int ks, int set) {
+      const int cl = ks * 2 + lhi;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[set][mi] = *(const f16x8*)(sb + a_off[mi] + ((cl ^ a_key[mi]) << 4));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fw[set][ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
+    };
+#pragma unroll
+    for (int ks = 0; ks < IG_PF; ++ks) load_frags(ks, ks);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks + IG_PF < BK / 16) load_frags(ks + IG_PF, (ks + IG_PF) % (IG_PF + 1));
+      if constexpr (ABL & 32) {  // ablation build: keep the LDS reads, skip the matrix pipe
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[ks % (IG_PF + 1)][mi]));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ks % (IG_PF + 1)][ni]));
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks % (IG_PF + 1)][ni], fa[ks % (IG_PF + 1)][mi], acc[ni][mi], 0, 0, 0);
+      }
+    }
+  };
+  if constexpr (NST == 0) {
+    // ---- register-staged tiles (LINEAR fast path only): global_load_dwordx4 -> VGPRs -> ds_write_b128 into the same swizzled
+    // LDS image the DMA path builds.  The LDS-DMA instruction costs a wave 60-185 issue cycles per KiB (MI355X_MICROARCH.md), which
+    // caps a CU at ~20-35 B/clk of staging traffic — the measured bound of the short-K projections; plain vector loads stream at
+    // the L1 rate and the ds_write pass rides under the other blocks' MFMAs.
+    static_assert(NST != 0 || (FAST && MODE == MGLD_MODE_LINEAR), "register staging: LINEAR fast path");
+    f16x8 ra[JA], rw[JB];
+    auto gload = [&]() {
+#pragma unroll
+      for (int j = 0; j < JA; ++j) { ra[j] = *(const f16x8*)fa_ptr[j]; fa_ptr[j] += fa_step[j]; }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) { rw[j] = *(const f16x8*)fw_ptr[j]; fw_ptr[j] += fw_step[j]; }
+    };
+    auto sstore = [&](int buf) {
+      char* sbase = smem + buf * STAGE + wave * 1024 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < JA; ++j) *(f16x8*)(sbase + j * (NW * 1024)) = ra[j];
+#pragma unroll
+      for (int j = 0; j < JB; ++j) *(f16x8*)(sbase + BM * ROWB + j * (NW * 1024)) = rw[j];
+    };
+    gload();
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) gload();                 // next stage in flight under this stage's MFMAs
+      compute_stage(smem + cur * STAGE);
+      if (kt + 1 < nk) sstore(cur ^ 1);         // (that buffer was last read in stage kt-1: every wave has passed the barrier since)
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) {
@@ -505,34 +568,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     }
     const char* sb = smem + cur * STAGE;
     cur = (cur + 1 == NST) ? 0 : cur + 1;
-    if constexpr (ABL & 128) continue;  // ablation build (timing only): no LDS reads, no MFMA
-    // fragments of k-step ks+IG_PF are fetched from LDS while the MFMAs of k-step ks run (IG_PF + 1 register sets, static indices)
-    f16x8 fa[IG_PF + 1][MI], fw[IG_PF + 1][NI];
-    auto load_frags = [&](int ks, int set) {
-      const int cl = ks * 2 + lhi;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) fa[set][mi] = *(const f16x8*)(sb + a_off[mi] + ((cl ^ a_key[mi]) << 4));
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fw[set][ni] = *(const f16x8*)(sb + w_off[ni] + ((cl ^ w_key[ni]) << 4));
-    };
-#pragma unroll
-    for (int ks = 0; ks < IG_PF; ++ks) load_frags(ks, ks);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + IG_PF < BK / 16) load_frags(ks + IG_PF, (ks + IG_PF) % (IG_PF + 1));
-      if constexpr (ABL & 32) {  // ablation build: keep the LDS reads, skip the matrix pipe
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[ks % (IG_PF + 1)][mi]));
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ks % (IG_PF + 1)][ni]));
-      } else {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks % (IG_PF + 1)][ni], fa[ks % (IG_PF + 1)][mi], acc[ni][mi], 0, 0, 0);
-      }
-    }
+    compute_stage(sb);
+  }
   }
 
   tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, RowMapLinear{bm0, M}, bn0, wm, wn, wave, lane, acc, smem);
@@ -1000,7 +1037,7 @@ inline int tile_order(const MgldIGemm* p, int gx, int gy) {
 
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
 void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
-  constexpr int LDS = NST * (BM + BN) * ROWB;
+  constexpr int LDS = (NST == 0 ? 2 : NST) * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)igemm_kernel<MODE, FAST, BM, BN, WM, WN, NST>,
@@ -1037,7 +1074,7 @@ inline int linear_ring_depth(const MgldIGemm* p, int BM, int BN) {
   static int force = -1;
   if (force < 0) { const char* e = getenv("MGLD_IGEMM_NST"); force = e ? atoi(e) : 0; }
   int nst = force ? force : 2;
-  if (p->tune > 0) nst = p->tune + 1;
+  if (p->tune > 0 && p->tune < 9) nst = p->tune + 1;
   if (nst < 2) nst = 2;
   if (nst > 4) nst = 4;
   while (nst > 2 && nst * (BM + BN) * ROWB > 160 * 1024) --nst;
@@ -1049,6 +1086,13 @@ inline int linear_ring_depth(const MgldIGemm* p, int BM, int BN) {
 template <int BM, int BN, int WM, int WN, int NST = 2>
 int launch_cfg(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   if (p->mode == MGLD_MODE_LINEAR && fast_ok(p) && splits <= 1) {
+    static int rs = -1;   // env MGLD_IGEMM_RS = 1: register-staged tiles on the LINEAR fast path (p->tune = 9 selects them per launch)
+    if (rs < 0) { const char* e = getenv("MGLD_IGEMM_RS"); rs = e ? atoi(e) : 0; }
+    if ((rs && p->tune == 0) || p->tune == 9) {
+      launch_fast<MGLD_MODE_LINEAR, true, BM, BN, WM, WN, 0>(p, s, splits, kchunk);
+      if (splits > 1) {}
+      return mgld_check_launch("igemm");
+    }
     const int nst = linear_ring_depth(p, BM, BN);
     if (nst == 4) launch_fast<MGLD_MODE_LINEAR, true, BM, BN, WM, WN, 4>(p, s, splits, kchunk);
     else if (nst == 3) launch_fast<MGLD_MODE_LINEAR, true, BM, BN, WM, WN, 3>(p, s, splits, kchunk);

@@ -44,13 +44,14 @@ def test_igemm_linear(hip, M, N, K):
     assert rel_l2(out.cpu().float(), ref) < 1e-3
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4])
+@pytest.mark.parametrize("depth", [2, 3, 4, 10])
 @pytest.mark.parametrize("M,N,K,act", [(32768, 320, 320, 0), (8192, 640, 640, 0), (2048, 1280, 1280, 3), (4096, 512, 128, 0),
                                        (300, 200, 64, 0), (8192, 640, 320, 4), (1000, 2560, 704, 4)])
 def test_igemm_linear_ring_depth(hip, depth, M, N, K, act):
     """LINEAR fast path with a 2 / 3 / 4-deep LDS ring (tune = depth - 1): counted vmcnt keeps depth - 2 stages in flight
-    across the stage barrier; K shorter than the ring, ragged M / N and the GEGLU epilogue included.  All depths must give the
-    same bits as depth 2 (same products, same summation order)."""
+    across the stage barrier; K shorter than the ring, ragged M / N and the GEGLU epilogue included.  depth 10 (tune 9) is the
+    register-staged variant (global_load -> VGPR -> ds_write, two LDS buffers).  All must give the same bits as depth 2 (same
+    products, same summation order)."""
     from mgld_vsr_amd.engine import pack_geglu
     a, w, b = h16(rnd(M, K, seed=31)), h16(rnd(N, K, seed=32, scale=K ** -0.5)), rnd(N, seed=33)
     pre = a.float() @ w.float().t() + b
