@@ -83,6 +83,146 @@ struct RowMap2D {       // a TY x TX pixel tile of one frame, raster order insid
   }
 };
 
+// ---- epilogue row pass ------------------------------------------------------------------------------------------------
+enum { EPI_GENERIC = 0, EPI_PLAIN_NONE = 1, EPI_PLAIN_SILU = 2, EPI_GEGLU = 3, EPI_SLAB = 4 };
+
+__device__ __forceinline__ f32x2 pk(float a, float b) { return f32x2{a, b}; }
+__device__ __forceinline__ f32x2 silu2(f32x2 x) {
+  const f32x2 t = x * pk(-1.4426950408889634f, -1.4426950408889634f);
+  const f32x2 d = pk(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])) + pk(1.f, 1.f);
+  return x * pk(__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]));
+}
+// exact-GELU of a pair: erf(z) = sign(z) (1 - 2^(t q(t))), t = min(|z|, 4), q a degree-5 polynomial fitted to log2(erfc(t)) / t on [0, 4]
+// (weighted minimax, tools/fit_erf.py; |erf error| <= 2.9e-7 in fp32 Horner: fp32 round-off level, three orders below the fp16 rounding of
+// the stored product).  One transcendental (v_exp_f32) per element; the polynomial runs as v_pk_fma_f32 on the pair.
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  const f32x2 z = x * pk(0.70710678118654752440f, 0.70710678118654752440f);
+  const f32x2 t = pk(fminf(fabsf(z[0]), 4.f), fminf(fabsf(z[1]), 4.f));
+  f32x2 q = t * pk(1.4204740e-04f, 1.4204740e-04f) + pk(-3.6643003e-03f, -3.6643003e-03f);
+  q = q * t + pk(3.0896224e-02f, 3.0896224e-02f);
+  q = q * t + pk(-1.4969946e-01f, -1.4969946e-01f);
+  q = q * t + pk(-9.1816545e-01f, -9.1816545e-01f);
+  q = q * t + pk(-1.6279250e+00f, -1.6279250e+00f);
+  q = q * t;
+  const f32x2 e = pk(1.f, 1.f) - pk(__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1]));
+  const f32x2 hx = x * pk(0.5f, 0.5f);
+  return hx + hx * pk(copysignf(e[0], z[0]), copysignf(e[1], z[1]));
+}
+
+// one 32-row slice of a wave's tile: rows r0 + prow of the fp32 patch -> bias / row vector / activation / residual -> global.
+// KIND is compile-time, everything it excludes is not in the instruction stream.
+template <int KIND, typename RowMap>
+__device__ __forceinline__ void epi_rows(const MgldIGemm& p, const RowMap rmap, const float* patch, const int LDW, const int rbase,
+                                         const int rpi, const int prow, const int pcv, const int n, const int Nout, const bool full,
+                                         const float (&bcol)[8], const float (&bgate)[8], const f16* __restrict__ R, char* outp,
+                                         const int64_t cbase, const int ldo, const bool of32, const int act, const float alpha, const bool geglu) {
+  for (int r0 = 0; r0 < 32; r0 += rpi) {
+    const int row = r0 + prow;
+    const int m = row < 32 ? rmap(rbase + row) : -1;
+    if (m < 0 || n >= Nout) continue;
+    const f32x4 a0 = *(const f32x4*)(patch + row * LDW + pcv);
+    const f32x4 a1 = *(const f32x4*)(patch + row * LDW + pcv + 4);
+    if constexpr (KIND == EPI_SLAB) {           // split-K: raw fp32 partial sums into this split's slab
+      float* cp = (float*)outp + cbase + (int64_t)m * ldo + n;
+      if (full && ((((uintptr_t)cp) & 15) == 0)) {
+        *(f32x4*)cp = a0;
+        *(f32x4*)(cp + 4) = a1;
+      } else {
+        const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = v[j];
+      }
+    } else if constexpr (KIND == EPI_PLAIN_NONE || KIND == EPI_PLAIN_SILU || KIND == EPI_GEGLU) {
+      f32x2 v[4] = {pk(a0[0], a0[1]), pk(a0[2], a0[3]), pk(a1[0], a1[1]), pk(a1[2], a1[3])};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += pk(bcol[2 * j], bcol[2 * j + 1]);
+      if constexpr (KIND == EPI_GEGLU) {
+        const f32x4 g0 = *(const f32x4*)(patch + row * LDW + 32 + pcv);
+        const f32x4 g1 = *(const f32x4*)(patch + row * LDW + 32 + pcv + 4);
+        const f32x2 g[4] = {pk(g0[0], g0[1]), pk(g0[2], g0[3]), pk(g1[0], g1[1]), pk(g1[2], g1[3])};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gelu2(g[j] + pk(bgate[2 * j], bgate[2 * j + 1]));
+      } else {
+        if (p.rowvec) {
+          const float* rv = p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec + n;
+          if (full && ((((uintptr_t)rv) & 15) == 0)) {
+            const f32x4 r0v = *(const f32x4*)rv, r1v = *(const f32x4*)(rv + 4);
+            v[0] += pk(r0v[0], r0v[1]); v[1] += pk(r0v[2], r0v[3]); v[2] += pk(r1v[0], r1v[1]); v[3] += pk(r1v[2], r1v[3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j >> 1][j & 1] += rv[j];
+          }
+        }
+        if constexpr (KIND == EPI_PLAIN_SILU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = silu2(v[j]);
+        }
+      }
+      f16* cp = (f16*)outp + cbase + (int64_t)m * ldo + n;
+      if (R) {
+        const f16* rp = R + (int64_t)m * p.ldr + n;
+        const f32x2 beta2 = pk(p.beta, p.beta);
+        if (full && ((((uintptr_t)rp) & 15) == 0)) {
+          const f16x8 rr = *(const f16x8*)rp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += beta2 * pk((float)rr[2 * j], (float)rr[2 * j + 1]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j >> 1][j & 1] += p.beta * (float)rp[j];
+        }
+      }
+      if (full && ((((uintptr_t)cp) & 15) == 0)) {
+        *(f16x8*)cp = f16x8{(f16)v[0][0], (f16)v[0][1], (f16)v[1][0], (f16)v[1][1], (f16)v[2][0], (f16)v[2][1], (f16)v[3][0], (f16)v[3][1]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j >> 1][j & 1];
+      }
+    } else {
+      float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      if (geglu) {
+        const f32x4 g0 = *(const f32x4*)(patch + row * LDW + 32 + pcv);
+        const f32x4 g1 = *(const f32x4*)(patch + row * LDW + 32 + pcv + 4);
+        const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] + bcol[j]) * gelu_f(g[j] + bgate[j]) * alpha;
+      } else {
+        const float bm = p.bias_m ? p.bias_m[m] : 0.f;
+        float rvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.rowvec) {
+          const float* rv = p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec + n;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < Nout) rvv[j] = rv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bm + bcol[j] + rvv[j], act) * alpha;
+      }
+      if (R) {
+        const f16* rp = R + (int64_t)m * p.ldr + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * (float)rp[j];
+      }
+      if (of32) {
+        float* cp = (float*)outp + cbase + (int64_t)m * ldo + n;
+        if (full && ((((uintptr_t)cp) & 15) == 0)) {
+          *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = v[j];
+        }
+      } else {
+        f16* cp = (f16*)outp + cbase + (int64_t)m * ldo + n;
+        if (full && ((((uintptr_t)cp) & 15) == 0)) {
+          *(f16x8*)cp = f16x8{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j];
+        }
+      }
+    }
+  }
+}
+
 // ---- shared tile epilogue (used by igemm_kernel, conv3p_kernel and conv3q_kernel) ---------------------------------
 template <int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restrict__ ws, const bool splitk, const int kz, const int bz,
@@ -128,6 +268,10 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
       if (geglu && nb + 32 + j < N) bgate[j] = p.bias[nb + 32 + j];
     }
   }
+  int kind = EPI_GENERIC;
+  if (splitk) kind = EPI_SLAB;
+  else if (geglu) kind = (alpha == 1.f && !of32) ? EPI_GEGLU : EPI_GENERIC;
+  else if (!of32 && !p.bias_m && alpha == 1.f && (act == MGLD_ACT_NONE || act == MGLD_ACT_SILU)) kind = act == MGLD_ACT_SILU ? EPI_PLAIN_SILU : EPI_PLAIN_NONE;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     // ---- phase 1: raw accumulators -> patch[row = l31][col] ----
@@ -138,69 +282,18 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
         *(f32x4*)(patch + l31 * LDW + ni * 32 + rg * 8 + lhi * 4) =
             f32x4{acc[ni][mi][rg * 4], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
     // ---- phase 2: patch rows -> epilogue math -> global, 8 columns (16 B of fp16 / 32 B of fp32) per lane ----
-    for (int r0 = 0; r0 < 32; r0 += rpi) {
-      const int row = r0 + prow;
-      const int m = row < 32 ? rmap(wm * WM + mi * 32 + row) : -1;
-      if (m >= 0 && n < Nout) {
-        const f32x4 a0 = *(const f32x4*)(patch + row * LDW + pcv);
-        const f32x4 a1 = *(const f32x4*)(patch + row * LDW + pcv + 4);
-        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        if (geglu) {
-          const f32x4 g0 = *(const f32x4*)(patch + row * LDW + 32 + pcv);
-          const f32x4 g1 = *(const f32x4*)(patch + row * LDW + 32 + pcv + 4);
-          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (v[j] + bcol[j]) * gelu_f(g[j] + bgate[j]) * alpha;
-        } else if (!splitk) {
-          const float bm = p.bias_m ? p.bias_m[m] : 0.f;
-          float rvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (p.rowvec) {
-            const float* rv = p.rowvec + (int64_t)(m / p.rows_per_frame) * p.ld_rowvec + n;
-            if (full && ((((uintptr_t)rv) & 15) == 0)) {
-              const f32x4 r0v = *(const f32x4*)rv, r1v = *(const f32x4*)(rv + 4);
-              rvv[0] = r0v[0]; rvv[1] = r0v[1]; rvv[2] = r0v[2]; rvv[3] = r0v[3];
-              rvv[4] = r1v[0]; rvv[5] = r1v[1]; rvv[6] = r1v[2]; rvv[7] = r1v[3];
-            } else {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) if (n + j < Nout) rvv[j] = rv[j];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bm + bcol[j] + rvv[j], act) * alpha;
-        }
-        if (R) {
-          const f16* rp = R + (int64_t)m * p.ldr + n;
-          if (full && ((((uintptr_t)rp) & 15) == 0)) {
-            const f16x8 rr = *(const f16x8*)rp;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += p.beta * (float)rr[j];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * (float)rp[j];
-          }
-        }
-        if (of32) {
-          float* cp = (float*)outp + cbase + (int64_t)m * ldo + n;
-          if (full && ((((uintptr_t)cp) & 15) == 0)) {
-            *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
-            *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = v[j];
-          }
-        } else {
-          f16* cp = (f16*)outp + cbase + (int64_t)m * ldo + n;
-          if (full && ((((uintptr_t)cp) & 15) == 0)) {
-            *(f16x8*)cp = f16x8{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j];
-          }
-        }
-      }
+    // The variant (plain fp16 epilogue with a compile-time activation / GEGLU / raw split-K slab / everything else) is picked by
+    // ONE block-uniform switch per 32-row slice; inside, the arithmetic is straight-line packed fp32 (v_pk_add/mul/fma_f32).
+    // Short-K launches (K = 320..1280: 5-20 k-steps) spend more issue slots here than in the k loop, so a per-element
+    // runtime `act` switch (4 scalar branches per element) was the dominant cost of the transformer blocks' projections.
+    switch (kind) {
+      case EPI_PLAIN_NONE: epi_rows<EPI_PLAIN_NONE>(p, rmap, patch, LDW, wm * WM + mi * 32, rpi, prow, pcv, n, Nout, full, bcol, bgate, R, outp, cbase, ldo, of32, act, alpha, geglu); break;
+      case EPI_PLAIN_SILU: epi_rows<EPI_PLAIN_SILU>(p, rmap, patch, LDW, wm * WM + mi * 32, rpi, prow, pcv, n, Nout, full, bcol, bgate, R, outp, cbase, ldo, of32, act, alpha, geglu); break;
+      case EPI_GEGLU: epi_rows<EPI_GEGLU>(p, rmap, patch, LDW, wm * WM + mi * 32, rpi, prow, pcv, n, Nout, full, bcol, bgate, R, outp, cbase, ldo, of32, act, alpha, geglu); break;
+      case EPI_SLAB: epi_rows<EPI_SLAB>(p, rmap, patch, LDW, wm * WM + mi * 32, rpi, prow, pcv, n, Nout, full, bcol, bgate, R, outp, cbase, ldo, of32, act, alpha, geglu); break;
+      default: epi_rows<EPI_GENERIC>(p, rmap, patch, LDW, wm * WM + mi * 32, rpi, prow, pcv, n, Nout, full, bcol, bgate, R, outp, cbase, ldo, of32, act, alpha, geglu); break;
     }
   }
-
 }
 
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
