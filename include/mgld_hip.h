@@ -142,6 +142,14 @@ int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, con
                      const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
                      int frames, int rows_per_frame, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
                      void* stream);
+/* Statistics + apply in ONE launch for small frames (rows_per_frame <= 256: the UNet's 16x16 / 8x8 levels), plain
+ * (gb == NULL: y = act(GN(x))) or SPADE (gb, skip given: the mgld_spade_apply formula).  Same arithmetic as
+ * mgld_gn_stats + mgld_gn_apply / mgld_spade_apply (fp32 per-channel sums, fp64 per-group combine); mgld_gn_fused_applies
+ * tells whether a shape is covered (whole-group windows of <= 128 channels). */
+int mgld_gn_fused_applies(int rows_per_frame, int C, int groups);
+int mgld_gn_fused(const void* x, int ldx, float eps, const float* gamma, const float* beta, const void* gb, int ldgb,
+                  const void* skip, int ldskip, void* y, int ldy, int frames, int rows_per_frame, int C, int groups, int silu,
+                  const int32_t* gb_step_idx, int64_t gb_step_stride, void* stream);
 /* gb_step_idx != NULL: `gb` is a table holding the modulation of EVERY schedule step (it depends on the struct-cond features
  * only, not on the sample); the kernel reads slice gb + gb_step_idx[0]*gb_step_stride (elements), the index living in device
  * memory so a captured step replays unchanged. */

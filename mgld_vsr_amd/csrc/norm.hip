@@ -181,6 +181,105 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   }
 }
 
+// ---- small frames (<= 256 rows): statistics + apply in ONE launch --------------------------------------------------------
+// grid (channel windows, frames), 256 threads.  A block owns a window of whole groups (Cb channels, a multiple of 8) of one frame
+// for ALL of its rows: the rows are loaded once into registers (<= GNF_R vector rows per thread), reduced per channel in fp32 and
+// per group in fp64 exactly like gn_partial_kernel / gn_group_stats, and normalised from the registers.  The 16x16 / 8x8 levels of
+// the UNet (and the struct-cond encoder's) are launch-bound: this halves their GroupNorm launches and reads the tensor once.
+constexpr int GNF_R = 16;
+template <bool SPADE>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x, int ldx, float eps, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const f16* __restrict__ gb, int ldgb,
+                                                       const f16* __restrict__ skip, int ldskip, f16* __restrict__ y, int ldy, int rows,
+                                                       int C, int groups, int silu, int Cb, const int* __restrict__ step_idx,
+                                                       int64_t gb_step_stride) {
+  __shared__ float sred[256 * 8 * 2];          // [rpi][Cb][2] : rpi * Cb = 256/NV * NV*8 <= 2048 channels-slots
+  __shared__ float st[GN_MAX_GROUPS][2];       // (mean, rstd) of this window's groups
+  if (SPADE && step_idx) gb += (int64_t)step_idx[0] * gb_step_stride;
+  const int c_off = blockIdx.x * Cb;
+  const int Cw = min(Cb, C - c_off);
+  const int NV = Cw >> 3;
+  const int cg = C / groups;
+  const int frame = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int rpi = 256 / NV;
+  const int rr = tid / NV, v = tid - rr * NV;
+  const bool active = rr < rpi;
+  const int64_t fbase = (int64_t)frame * rows;
+  const int c0 = c_off + v * 8;
+  f16x8 d[GNF_R];
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (active) {
+    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < GNF_R; ++k) {
+      const int r = rr + k * rpi;
+      d[k] = (r < rows) ? *(const f16x8*)(x + (fbase + r) * ldx + c0) : z8;
+    }
+#pragma unroll
+    for (int k = 0; k < GNF_R; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)d[k][j]; s[j] += f; q[j] += f * f; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sred[((rr * Cw) + v * 8 + j) * 2] = s[j];
+      sred[((rr * Cw) + v * 8 + j) * 2 + 1] = q[j];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < Cw; c += 256) {   // fold the rpi row slots into slot 0 (column c is touched by this thread only)
+    float ss = 0.f, qq = 0.f;
+    for (int r = 0; r < rpi; ++r) { ss += sred[(r * Cw + c) * 2]; qq += sred[(r * Cw + c) * 2 + 1]; }
+    sred[c * 2] = ss; sred[c * 2 + 1] = qq;
+  }
+  __syncthreads();
+  for (int g = tid; g < Cw / cg; g += 256) {
+    double sd = 0.0, qd = 0.0;
+    for (int i = 0; i < cg; ++i) { sd += (double)sred[(g * cg + i) * 2]; qd += (double)sred[(g * cg + i) * 2 + 1]; }
+    const double n = (double)rows * cg;
+    const double mean = sd / n;
+    double var = qd / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    st[g][0] = (float)mean;
+    st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (!active) return;
+  float sa[8], sb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    const int g = (c - c_off) / cg;
+    sa[j] = st[g][1] * gamma[c];
+    sb[j] = beta[c] - st[g][0] * sa[j];
+  }
+#pragma unroll
+  for (int k = 0; k < GNF_R; ++k) {
+    const int r = rr + k * rpi;
+    if (r < rows) {
+      const int64_t row = fbase + r;
+      f16x8 gm, bt, sk;
+      if (SPADE) {
+        gm = *(const f16x8*)(gb + row * ldgb + c0);
+        bt = *(const f16x8*)(gb + row * ldgb + C + c0);
+        sk = *(const f16x8*)(skip + row * ldskip + c0);
+      }
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)d[k][j] * sa[j] + sb[j];
+        if (SPADE) f = f * (1.f + (float)gm[j]) + (float)bt[j] + (float)sk[j];
+        else if (silu == 1) f = silu_f(f);
+        else if (silu == 2) f = fmaxf(f, 0.f);
+        o[j] = (f16)f;
+      }
+      *(f16x8*)(y + row * ldy + c0) = o;
+    }
+  }
+}
+
 // ---- LayerNorm: one wave per token row ---------------------------------------------------------------------
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, int ldx, const float* __restrict__ gamma,
@@ -309,6 +408,39 @@ extern "C" int mgld_spade_apply(const void* h, int ldh, const double* gsums, flo
                      mgld_gn_chunks(rows), eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy,
                      rows, C, groups, 0, Cb, gb_step_idx, gb_step_stride);
   return mgld_check_launch("spade_apply");
+}
+
+// window of the single-launch GroupNorm: the smallest whole-group, multiple-of-8 channel window; 0 = shape not covered
+static int fused_window(int rows, int C, int groups) {
+  if (rows <= 0 || rows > 256 || groups <= 0 || C % groups || (C & 7)) return 0;
+  const int cg = C / groups;
+  int unit = cg;
+  while (unit & 7) unit += cg;
+  if (unit > C || C % unit || unit > 128) return 0;      // NV <= 16 -> >= 16 rows per pass -> <= GNF_R passes for 256 rows
+  const int rpi = 256 / (unit >> 3);
+  if ((rows + rpi - 1) / rpi > GNF_R) return 0;
+  return unit;
+}
+
+extern "C" int mgld_gn_fused_applies(int rows_per_frame, int C, int groups) { return fused_window(rows_per_frame, C, groups) > 0; }
+
+extern "C" int mgld_gn_fused(const void* x, int ldx, float eps, const float* gamma, const float* beta, const void* gb, int ldgb,
+                             const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C, int groups, int silu,
+                             const int32_t* gb_step_idx, int64_t gb_step_stride, void* stream) {
+  MGLD_REQUIRE(x && gamma && beta && y, "gn_fused: null pointer");
+  MGLD_REQUIRE((ldx & 7) == 0 && (ldy & 7) == 0 && groups <= GN_MAX_GROUPS && frames > 0, "gn_fused: alignment");
+  const int Cb = fused_window(rows, C, groups);
+  MGLD_REQUIRE(Cb > 0, "gn_fused: shape not covered (mgld_gn_fused_applies)");
+  const dim3 grid(C / Cb, frames);
+  if (gb) {
+    MGLD_REQUIRE(skip && (ldgb & 7) == 0 && (ldskip & 7) == 0, "gn_fused: SPADE operands");
+    hipLaunchKernelGGL((gn_fused_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, eps, gamma, beta,
+                       (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb, gb_step_idx, gb_step_stride);
+  } else {
+    hipLaunchKernelGGL((gn_fused_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, eps, gamma, beta,
+                       nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb, nullptr, (int64_t)0);
+  }
+  return mgld_check_launch("gn_fused");
 }
 
 extern "C" int mgld_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int rows,

@@ -5,6 +5,8 @@ The reference drives one CUDA stream from a Python loop through nn.Module.forwar
 nn.Modules only own parameters (checkpoint-compatible names); their forward() emits C-ABI launches on token-major
 (NHWC) fp16 buffers.
 """
+import os
+
 import torch
 
 from . import hip
@@ -168,6 +170,7 @@ class Engine:
     """Owns the arena, the packed-weight cache and the op helpers every network forward is written in."""
 
     GROUPS = 32
+    GN_FUSED = os.environ.get("MGLD_GN_FUSED", "1") != "0"    # single-launch GroupNorm for frames of <= 256 rows
 
     def __init__(self, device="cuda", chunk_bytes=1 << 30, workspace_bytes=256 << 20):
         hip.lib()  # fail loudly if the HIP library is missing
@@ -316,8 +319,12 @@ class Engine:
         return out
 
     def gn_stats(self, x, eps, groups=None):
-        """One launch: per-chunk group sums (fp64).  Returns (gsums, eps); the apply kernels finish the reduction."""
+        """One launch: per-chunk group sums (fp64).  Returns (gsums, eps); the apply kernels finish the reduction.
+        Small frames (hip.gn_fused_applies: the 16x16 / 8x8 levels) return (None, eps): their consumer runs statistics + apply
+        as ONE launch (mgld_gn_fused), so nothing is computed here."""
         g = groups or self.GROUPS
+        if self.GN_FUSED and hip.gn_fused_applies(x.hw, x.C, g):
+            return None, float(eps)
         gsums = self.arena.alloc((x.n, hip.gn_chunks(x.hw), g, 2), torch.float64)
         hip.gn_stats(x.v, x.n, x.hw, g, gsums)
         self.launches += 1
@@ -327,7 +334,10 @@ class Engine:
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C)
         gsums, eps = stats
-        hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
+        if gsums is None:
+            hip.gn_fused(x.v, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
+        else:
+            hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
         self.launches += 1
         return out
 
@@ -338,8 +348,12 @@ class Engine:
         if out is None:
             out = self.act(h.n, h.h, h.w, h.C)
         gsums, eps = stats
-        hip.spade_apply(h.v, gsums, eps, gamma, beta, gb.v if isinstance(gb, Act) else gb, skip.v, out.v, h.n, h.hw, self.GROUPS,
-                        step_idx, step_stride)
+        gbv = gb.v if isinstance(gb, Act) else gb
+        if gsums is None:
+            hip.gn_fused(h.v, eps, gamma, beta, out.v, h.n, h.hw, self.GROUPS, 0, gb=gbv, skip=skip.v, step_idx=step_idx,
+                         step_stride=step_stride)
+        else:
+            hip.spade_apply(h.v, gsums, eps, gamma, beta, gbv, skip.v, out.v, h.n, h.hw, self.GROUPS, step_idx, step_stride)
         self.launches += 1
         return out
 

@@ -52,7 +52,7 @@ EXPORTS = [
     "mgld_version", "mgld_last_error", "mgld_device_info",
     "mgld_graph_begin", "mgld_graph_end", "mgld_graph_launch", "mgld_graph_destroy",
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
-    "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_layernorm",
+    "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_gn_fused_applies", "mgld_gn_fused", "mgld_layernorm",
     "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
     "mgld_linear_small", "mgld_timestep_embedding",
     "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
@@ -261,6 +261,24 @@ def spade_apply(h, gsums, eps, gamma, beta, gb, skip, y, frames, rows, groups, s
         _chk(lib().mgld_spade_apply(_p(h), _ld(h), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip),
                                     _ld(skip), _p(y), _ld(y), frames, rows, h.shape[1], groups, _p(step_idx), C.c_int64(step_stride),
                                     stream_ptr()), "spade_apply")
+    return y
+
+
+def gn_fused_applies(rows, channels, groups):
+    """small frames (<= 256 rows, whole-group windows of <= 128 channels): statistics + apply run as one launch"""
+    return bool(lib().mgld_gn_fused_applies(int(rows), int(channels), int(groups)))
+
+
+def gn_fused(x, eps, gamma, beta, y, frames, rows, groups, silu=0, gb=None, skip=None, step_idx=None, step_stride=0):
+    """y = act(GN(x)) or, with gb / skip, the SPADE formula of spade_apply; one launch (statistics + apply)"""
+    _req_cuda(x, gamma, beta, y)
+    spade = gb is not None
+    if spade:
+        _req_cuda(gb, skip)
+    with timed("spade_apply" if spade else "gn_apply", {"bytes": (10.0 if spade else 4.0) * frames * rows * x.shape[1]}):
+        _chk(lib().mgld_gn_fused(_p(x), _ld(x), C.c_float(eps), _p(gamma), _p(beta), _p(gb) if spade else None, _ld(gb) if spade else 0,
+                                 _p(skip) if spade else None, _ld(skip) if spade else 0, _p(y), _ld(y), frames, rows, x.shape[1],
+                                 groups, int(silu), _p(step_idx), C.c_int64(step_stride), stream_ptr()), "gn_fused")
     return y
 
 

@@ -83,7 +83,8 @@ def dry(monkeypatch):
     monkeypatch.setattr(hip, "igemm", igemm)
     monkeypatch.setattr(hip, "attention", attention)
     monkeypatch.setattr(hip, "gn_chunks", lambda rows: 1 if rows <= 64 else (rows + 63) // 64)
-    for name in ["gn_stats", "gn_apply", "spade_apply", "layernorm", "temporal_attention", "softmax_rows", "linear_small",
+    monkeypatch.setattr(hip, "gn_fused_applies", lambda rows, c, g: rows <= 256 and (c // g) * (8 // __import__("math").gcd(c // g, 8)) <= 128)
+    for name in ["gn_stats", "gn_apply", "spade_apply", "gn_fused", "layernorm", "temporal_attention", "softmax_rows", "linear_small",
                  "timestep_embedding", "nchw_to_nhwc", "nhwc_to_nchw", "copy2d", "axpby"]:
         monkeypatch.setattr(hip, name, generic(name))
     monkeypatch.setattr(hip, "conv3p_applies", lambda *a: False)   # (a planner query into the library: keep the [N, K] weights)

@@ -458,6 +458,48 @@ def test_spade_apply(hip):
     assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
 
 
+@pytest.mark.parametrize("frames,C,h,w,silu", [(2, 1280, 16, 16, 1), (3, 1920, 8, 8, 1), (2, 2560, 16, 16, 1), (1, 320, 16, 16, 0),
+                                               (2, 960, 8, 8, 1), (2, 640, 16, 12, 2), (5, 64, 4, 4, 1), (1, 512, 16, 16, 0)])
+def test_groupnorm_single_launch(hip, frames, C, h, w, silu):
+    """mgld_gn_fused (frames of <= 256 rows: statistics + apply in one launch) against torch and against the two-launch path it
+    replaces (same per-channel fp32 / per-group fp64 arithmetic: agreement at the fp16 rounding level, strided input view)"""
+    rows = h * w
+    assert hip.gn_fused_applies(rows, C, 32)
+    assert not hip.gn_fused_applies(1024, C, 32)
+    x = h16(rnd(frames, C, h, w, seed=40) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=41), 0.1 * rnd(C, seed=42)
+    xt = torch.zeros(frames * rows, C + 24, dtype=torch.half, device=DEV)
+    xt[:, 8:8 + C] = _to_tok(x).to(DEV)
+    xv = xt[:, 8:8 + C]
+    y = torch.full((frames * rows, C), float("nan"), dtype=torch.half, device=DEV)
+    hip.gn_fused(xv, 1e-5, gamma.to(DEV), beta.to(DEV), y, frames, rows, 32, silu)
+    gsums = torch.empty(frames, hip.gn_chunks(rows), 32, 2, dtype=torch.float64, device=DEV)
+    hip.gn_stats(xv, frames, rows, 32, gsums)
+    y2 = torch.empty_like(y)
+    hip.gn_apply(xv, gsums, 1e-5, gamma.to(DEV), beta.to(DEV), y2, frames, rows, 32, silu)
+    ref = F.group_norm(x.float(), 32, gamma, beta, 1e-5)
+    ref = F.silu(ref) if silu == 1 else F.relu(ref) if silu == 2 else ref
+    assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
+    assert rel_l2(y.float(), y2.float()) < 3e-4
+
+
+def test_spade_single_launch(hip):
+    """SPADE form of mgld_gn_fused, with the per-step modulation table indexed on the device (step_idx)"""
+    frames, C, h, w, S = 2, 1280, 16, 16, 3
+    rows = h * w
+    hh, skip = h16(rnd(frames * rows, C, seed=43)), h16(rnd(frames * rows, C, seed=44))
+    table = h16(rnd(S, frames * rows, 2 * C, seed=45, scale=0.5)).to(DEV)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=46), 0.1 * rnd(C, seed=47)
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    y = torch.full((frames * rows, C), float("nan"), dtype=torch.half, device=DEV)
+    hip.gn_fused(hh.to(DEV), 1e-5, gamma.to(DEV), beta.to(DEV), y, frames, rows, 32, 0, gb=table[0], skip=skip.to(DEV), step_idx=step,
+                 step_stride=table.stride(0))
+    gb = table[2].cpu().float()
+    hn = F.group_norm(_from_tok(hh.float(), frames, h, w), 32, gamma, beta, 1e-5)
+    ref = _from_tok(skip.float(), frames, h, w) + hn * (1 + _from_tok(gb[:, :C], frames, h, w)) + _from_tok(gb[:, C:], frames, h, w)
+    assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
+
+
 @pytest.mark.parametrize("rows,C", [(130, 320), (64, 640), (37, 1280), (9, 64)])
 def test_layernorm(hip, rows, C):
     x = h16(rnd(rows, C, seed=38) * 2 + 0.5)
