@@ -59,7 +59,7 @@ def test_structcond_small_vs_golden(hip, small_nets):
     out = sc(g["lat"].cuda(), g["t"].cuda())
     assert set(out.keys()) == {"16", "8", "4", "2"}
     for k, v in out.items():
-        assert record(f"structcond_small_{k}", rel_l2(v, g[f"sc_{k}"])) < 5e-3
+        assert record(f"structcond_small_{k}", rel_l2(v, g[f"sc_{k}"])) < 2e-3
 
 
 def test_unet_small_vs_golden(hip, small_nets):
@@ -67,14 +67,14 @@ def test_unet_small_vs_golden(hip, small_nets):
     g = G("g_unet")
     sc = {k[3:]: v.cuda() for k, v in g.items() if k.startswith("sc_")}
     eps = unet(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].cuda(), struct_cond=sc)
-    assert record("unet_small", rel_l2(eps, g["eps"])) < 5e-3
+    assert record("unet_small", rel_l2(eps, g["eps"])) < 2.4e-3   # fp16-storage floor 1.8e-3 (tools/fp16_sim.py; DESIGN.md parity table)
     # per-frame (non-uniform) timesteps go through the M = n embedding path
     t2 = torch.tensor([541, 20, 999])
     usd = {k: v for k, v in unet.state_dict().items()}
     sc_cpu = {k[3:]: v for k, v in g.items() if k.startswith("sc_")}
     ref = onets.unet_forward(usd, UNET_SMALL, g["x"], t2, g["ctx"], sc_cpu)
     eps2 = unet(g["x"].cuda(), t2.cuda(), context=g["ctx"].cuda(), struct_cond=sc)
-    assert record("unet_small_mixed_t", rel_l2(eps2, ref)) < 5e-3
+    assert record("unet_small_mixed_t", rel_l2(eps2, ref)) < 2.4e-3
 
 
 def test_vae_small_vs_golden(hip):
@@ -83,19 +83,19 @@ def test_vae_small_vs_golden(hip):
     vq = synth.fill_module_(VideoAutoencoderKLResi(ddconfig=dict(VAE_DD_SMALL), lossconfig={"target": "torch.nn.Identity"},
                                                    embed_dim=4), "vae")
     post, fea = vq.encode(g["x"].cuda())
-    assert record("vae_small_mean", rel_l2(post.mean, g["mean"])) < 5e-3
-    assert record("vae_small_logvar", rel_l2(post.logvar, g["logvar"])) < 5e-3
+    assert record("vae_small_mean", rel_l2(post.mean, g["mean"])) < 2e-3
+    assert record("vae_small_logvar", rel_l2(post.logvar, g["logvar"])) < 2e-3
     from mgld_vsr_amd.engine import Engine
     f0 = vq.engine().to_nchw(fea[0])
     f1 = vq.engine().to_nchw(fea[1])
-    assert record("vae_small_fea0", rel_l2(f0, g["fea0"])) < 5e-3 and record("vae_small_fea1", rel_l2(f1, g["fea1"])) < 5e-3
+    assert record("vae_small_fea0", rel_l2(f0, g["fea0"])) < 1.6e-3 and record("vae_small_fea1", rel_l2(f1, g["fea1"])) < 1.8e-3
     dec = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])
-    assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 5e-3
+    assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 2.8e-3          # fp16-storage floor 2.15e-3 (tools/fp16_sim.py)
     vq.decoder.fusion_w = 0.5                                   # the reference script's default --dec_w
     dec05 = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])     # decoder alone: the reference's own features
-    assert record("vae_small_dec_w05", rel_l2(dec05, g["dec_w05"])) < 5e-3
+    assert record("vae_small_dec_w05", rel_l2(dec05, g["dec_w05"])) < 4e-3   # floor 3.2e-3: the fusion layers blend two fp16 feature sets
     dec05p = vq.decode(g["z"].cuda(), fea)                                     # chained with the product's encoder features
-    assert record("vae_small_dec_w05_chained", rel_l2(dec05p, g["dec_w05"])) < 5e-3
+    assert record("vae_small_dec_w05_chained", rel_l2(dec05p, g["dec_w05"])) < 4.6e-3
     from scripts.wavelet_color_fix import adaptive_instance_normalization, wavelet_reconstruction
     assert rel_l2(adaptive_instance_normalization(g["dec"], g["style"]), g["adain"]) < 1e-5
     assert rel_l2(wavelet_reconstruction(g["dec"], g["style"]), g["wavelet"]) < 1e-5
@@ -105,7 +105,7 @@ def test_vae_small_vs_golden(hip):
     dd.pop("num_frames")
     fs = synth.fill_module_(AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4), "first_stage")
     post = fs.encode(gf["x"].cuda())
-    assert record("first_stage_mean", rel_l2(post.mean, gf["mean"])) < 5e-3
+    assert record("first_stage_mean", rel_l2(post.mean, gf["mean"])) < 2e-3
 
 
 def _small_model():
@@ -145,9 +145,9 @@ def test_sample_small_vs_golden(hip, tag):
               time_replace=S, x_T=g[f"{tag}_xT"], noise=noise)
     fn = model.sample if tag == "plain" else (lambda **k: model.sample_canvas(tile_size=16, tile_overlap=8, batch_size_sample=1, **k))
     x0_ng = fn(**kw)
-    assert record(f"sample_{tag}_noguid", rel_l2(x0_ng, g[f"{tag}_x0_noguid"])) < 1e-2
+    assert record(f"sample_{tag}_noguid", rel_l2(x0_ng, g[f"{tag}_x0_noguid"])) < 1.6e-3
     x0 = fn(flows=flows, masks=masks, **kw)
-    assert record(f"sample_{tag}_guided", rel_l2(x0, g[f"{tag}_x0"])) < 2e-2
+    assert record(f"sample_{tag}_guided", rel_l2(x0, g[f"{tag}_x0"])) < 1.8e-3
     # hipGraph replay == eager launches, bit for bit
     x0_eager = fn(flows=flows, masks=masks, use_graph=False, **kw)
     assert torch.equal(x0_eager, x0)
@@ -178,14 +178,14 @@ def test_single_step_api_and_decode_first_stage_vs_golden(hip):
                                                                 t_replace=t_rep[:1], tile_size=16, tile_overlap=8, batch_size=1, tile_weights=tw)
             z = model.p_sample_canvas(x, g["ctx"], lat, ts, guidance_scale=-10.0, flows=flows, masks=masks, t_replace=t_rep[:1], tile_size=16,
                                       tile_overlap=8, batch_size=1, tile_weights=tw, noise=nz)
-        assert record(f"pstep_{tag}_x0", rel_l2(x0, g[f"{tag}_x0"])) < 2e-3
-        assert record(f"pstep_{tag}_mean", rel_l2(mean, g[f"{tag}_mean"])) < 2e-3
+        assert record(f"pstep_{tag}_x0", rel_l2(x0, g[f"{tag}_x0"])) < 1.7e-3
+        assert record(f"pstep_{tag}_mean", rel_l2(mean, g[f"{tag}_mean"])) < 1.6e-3
         assert abs(float(logvar.reshape(-1)[0]) - float(g[f"{tag}_logvar"].reshape(-1)[0])) < 1e-6
         assert abs(float(var.reshape(-1)[0]) - float(g[f"{tag}_var"].reshape(-1)[0])) < 1e-9
-        assert record(f"pstep_{tag}_z", rel_l2(z, g[f"{tag}_z"])) < 2e-3
+        assert record(f"pstep_{tag}_z", rel_l2(z, g[f"{tag}_z"])) < 1.6e-3
     dec = model.decode_first_stage(g["dec_z"].cuda())
     assert dec.shape == g["dec_out"].shape
-    assert record("first_stage_image_decode", rel_l2(dec, g["dec_out"])) < 2.5e-3
+    assert record("first_stage_image_decode", rel_l2(dec, g["dec_out"])) < 2e-3
 
 
 def test_sample_hoisting_windows_are_equivalent(hip, monkeypatch):
@@ -227,9 +227,9 @@ def test_unet_fullwidth_vs_oracle(hip):
         eps_ref = onets.unet_forward(unet.state_dict(), ucfg, x, t, ctx, sc_ref)
     sc_out = sc(lat.cuda(), t.cuda())
     for k in sc_ref:
-        assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < 5e-3
+        assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < 1.9e-3
     eps = unet(x.cuda(), t.cuda(), context=ctx.cuda(), struct_cond={k: v.cuda() for k, v in sc_ref.items()})
-    assert record("unet_full", rel_l2(eps, eps_ref)) < 5e-3
+    assert record("unet_full", rel_l2(eps, eps_ref)) < 2.4e-3
 
 
 def test_pipeline_small_end_to_end_vs_oracle(hip):
@@ -309,8 +309,8 @@ def test_pipeline_single_frame_vs_oracle(hip):
         _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
-    assert record("e2e_single_frame_latent", rel_l2(lat, x0)) < 3e-3
-    assert record("e2e_single_frame_frames", rel_l2(out, ref)) < 2e-3
+    assert record("e2e_single_frame_latent", rel_l2(lat, x0)) < 1.9e-3
+    assert record("e2e_single_frame_frames", rel_l2(out, ref)) < 1.7e-3
 
 
 def test_pipeline_config0_fullwidth_vs_reference(hip):
@@ -340,7 +340,7 @@ def test_pipeline_config0_fullwidth_vs_reference(hip):
     for k, v in got.items():
         record(k, v)
     assert got["c1_full_structcond_8"] < 2e-3 and got["c1_full_vae_fea0"] < 2e-3
-    assert got["c1_full_unet_eps"] < 2.5e-3 and got["c1_full_decoder"] < 2.5e-3
+    assert got["c1_full_unet_eps"] < 2.6e-3 and got["c1_full_decoder"] < 2.5e-3
     # the outputs.  The sampled latent meets the north_star tolerance (9.6e-4).  The colour-fixed frame of this config measures
     # 1.03e-3: it inherits the video decoder's single-evaluation error (2.0e-3 here), of which 1.6e-3 is the rounding of the
     # MFMA OPERANDS to fp16 alone (weights 1.1e-3 + activations 1.2e-3, tools/fp16_sim.py) — no storage
@@ -384,7 +384,7 @@ def test_pipeline_frame_sharded_matches_unsharded(hip):
             assert rp.pos == len(rec.trace)                               # identical communication sequence
             assert o.shape[0] == Tn // world
             worst = max(worst, rp.worst, rel_l2(o, out0[sh.f0:sh.f1]), rel_l2(l, lat0[sh.f0:sh.f1]))
-    assert record("frame_sharded_vs_unsharded", worst) < 3e-3            # tile configs differ with M: fp16-level only
+    assert record("frame_sharded_vs_unsharded", worst) < 1.3e-3            # tile configs differ with M: fp16-level only
 
 
 def test_sample_canvas_tile_sharded_matches_unsharded(hip):
@@ -421,8 +421,8 @@ def test_sample_canvas_tile_sharded_matches_unsharded(hip):
                 worst = max(worst, rp.worst, rel_l2(xr, x0))
     finally:
         eng.tile_shard = None
-    assert record("tile_sharded_vs_unsharded", worst) < 2e-3     # fewer tiles per pass -> other tile configs: fp16-level only
-    assert record("sample_canvas_guided_ref", rel_l2(x0, g["canvas_x0"])) < 2e-3
+    assert record("tile_sharded_vs_unsharded", worst) < 1e-3     # fewer tiles per pass -> other tile configs: fp16-level only
+    assert record("sample_canvas_guided_ref", rel_l2(x0, g["canvas_x0"])) < 1.8e-3
 
 
 def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
@@ -459,7 +459,7 @@ def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
         _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
-    assert record("e2e_full_latent", rel_l2(lat, x0)) < 2e-3
+    assert record("e2e_full_latent", rel_l2(lat, x0)) < 1.3e-3
     record("e2e_full_decoder_only", rel_l2(vq.decode(x0.cuda() / 0.18215, [f.cuda() for f in fea]), dec))
     assert record("e2e_full_frames", rel_l2(out, ref)) < 1e-3      # north_star: outputs within 1e-3 rel-L2 (measured 9.5e-4)
 
@@ -502,7 +502,7 @@ def test_raft_flow_vs_oracle(hip):
         rf, rb = oraft.compute_flow(net.state_dict(), lrs, iters=4)
     e = max(record("raft_flow_fwd", rel_l2(ff, rf)), record("raft_flow_bwd", rel_l2(fb, rb)))
     # fp16 activations through the recurrent update (tolerance stated here: flows feed sub-pixel warps of 64x64 latents)
-    assert e < 5e-3
+    assert e < 2.4e-3
     record("raft_flow_max_abs_px", float((ff.cpu() - rf).abs().max()))
 
 
@@ -527,10 +527,10 @@ def test_pipeline_estimate_flows_vs_oracle(hip):
         r0, r1 = oflow.resize_flow(rf[0], H // 8, H // 8), oflow.resize_flow(rb[0], H // 8, H // 8)
         rfo, rbo = oflow.forward_backward_consistency_check(r1, r0)
     assert f0.shape == (1, Tn - 1, 2, H // 8, H // 8) and fo.shape == (1, Tn - 1, 1, H // 8, H // 8)
-    assert max(record("flowprep_fwd", rel_l2(f0[0], r0)), record("flowprep_bwd", rel_l2(f1[0], r1))) < 5e-3
+    assert max(record("flowprep_fwd", rel_l2(f0[0], r0)), record("flowprep_bwd", rel_l2(f1[0], r1))) < 2.6e-3
     # the occlusion masks are thresholded (0/1): only pixels sitting on the threshold may flip
     flips = float((fo[0, :, 0].cpu() != rfo).float().mean()) + float((bo[0, :, 0].cpu() != rbo).float().mean())
-    assert record("flowprep_mask_flip_fraction", flips) < 2e-2
+    assert record("flowprep_mask_flip_fraction", flips) < 1e-3
 
 
 def test_text_tower_vs_oracle(hip):
@@ -548,6 +548,6 @@ def test_text_tower_vs_oracle(hip):
     out = emb([""])
     ref = otext.encode_with_transformer(emb.state_dict(), toks[:1], heads=2, layer_idx=1)
     assert out.shape == (1, 77, 128)
-    assert record("text_tower", rel_l2(out, ref)) < 3e-3
+    assert record("text_tower", rel_l2(out, ref)) < 1e-3
     with pytest.raises(NotImplementedError):
         emb(["a photo"])
