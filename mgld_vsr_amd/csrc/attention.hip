@@ -164,21 +164,15 @@ void flash_attn_kernel(const MgldAttn p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     const float mneg = -m_new * sc;
-    // (pairs: the scale FMA and the row-sum add run as v_pk_fma_f32 / v_pk_add_f32 — this loop is VALU-bound, two thirds of its
-    //  issue slots are the softmax, and only the exp2 has no packed form)
-    f32x2 rs2 = {0.f, 0.f};
-    const f32x2 sc2 = {sc, sc}, mneg2 = {mneg, mneg};
+    float rs = 0.f;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 t = f32x2{st[k2][r], st[k2][r + 1]} * sc2 + mneg2;
-        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-        st[k2][r] = e[0];
-        st[k2][r + 1] = e[1];
-        rs2 += e;
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[k2][r], sc, mneg));
+        st[k2][r] = e;
+        rs += e;
       }
-    float rs = rs2[0] + rs2[1];
     rs += __shfl_xor(rs, 32, 64);
     if (__any(m_new != m_run)) {  // rescale only when some row's max moved (rare after the first tiles)
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
