@@ -86,26 +86,44 @@ struct RowMap2D {       // a TY x TX pixel tile of one frame, raster order insid
 // ---- epilogue row pass ------------------------------------------------------------------------------------------------
 enum { EPI_GENERIC = 0, EPI_PLAIN_NONE = 1, EPI_PLAIN_SILU = 2, EPI_GEGLU = 3, EPI_SLAB = 4 };
 
-__device__ __forceinline__ f32x2 pk(float a, float b) { return f32x2{a, b}; }
-__device__ __forceinline__ f32x2 silu2(f32x2 x) {
-  const f32x2 t = x * pk(-1.4426950408889634f, -1.4426950408889634f);
-  const f32x2 d = pk(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])) + pk(1.f, 1.f);
+#ifndef MGLD_EPI_PK
+#define MGLD_EPI_PK 1     // 1: epilogue arithmetic on float pairs (v_pk_*_f32); 0: A/B build with the same code on scalars
+#endif
+#if MGLD_EPI_PK
+typedef f32x2 e2;
+__device__ __forceinline__ e2 pk(float a, float b) { return e2{a, b}; }
+#else
+struct e2 {
+  float x, y;
+  __device__ __forceinline__ float& operator[](int i) { return i ? y : x; }
+  __device__ __forceinline__ float operator[](int i) const { return i ? y : x; }
+};
+__device__ __forceinline__ e2 pk(float a, float b) { return e2{a, b}; }
+__device__ __forceinline__ e2 operator+(e2 a, e2 b) { return e2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ e2 operator-(e2 a, e2 b) { return e2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ e2 operator*(e2 a, e2 b) { return e2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ e2& operator+=(e2& a, e2 b) { a.x += b.x; a.y += b.y; return a; }
+__device__ __forceinline__ e2& operator*=(e2& a, e2 b) { a.x *= b.x; a.y *= b.y; return a; }
+#endif
+__device__ __forceinline__ e2 silu2(e2 x) {
+  const e2 t = x * pk(-1.4426950408889634f, -1.4426950408889634f);
+  const e2 d = pk(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])) + pk(1.f, 1.f);
   return x * pk(__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]));
 }
 // exact-GELU of a pair: erf(z) = sign(z) (1 - 2^(t q(t))), t = min(|z|, 4), q a degree-5 polynomial fitted to log2(erfc(t)) / t on [0, 4]
 // (weighted minimax, tools/fit_erf.py; |erf error| <= 2.9e-7 in fp32 Horner: fp32 round-off level, three orders below the fp16 rounding of
 // the stored product).  One transcendental (v_exp_f32) per element; the polynomial runs as v_pk_fma_f32 on the pair.
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
-  const f32x2 z = x * pk(0.70710678118654752440f, 0.70710678118654752440f);
-  const f32x2 t = pk(fminf(fabsf(z[0]), 4.f), fminf(fabsf(z[1]), 4.f));
-  f32x2 q = t * pk(1.4204740e-04f, 1.4204740e-04f) + pk(-3.6643003e-03f, -3.6643003e-03f);
+__device__ __forceinline__ e2 gelu2(e2 x) {
+  const e2 z = x * pk(0.70710678118654752440f, 0.70710678118654752440f);
+  const e2 t = pk(fminf(fabsf(z[0]), 4.f), fminf(fabsf(z[1]), 4.f));
+  e2 q = t * pk(1.4204740e-04f, 1.4204740e-04f) + pk(-3.6643003e-03f, -3.6643003e-03f);
   q = q * t + pk(3.0896224e-02f, 3.0896224e-02f);
   q = q * t + pk(-1.4969946e-01f, -1.4969946e-01f);
   q = q * t + pk(-9.1816545e-01f, -9.1816545e-01f);
   q = q * t + pk(-1.6279250e+00f, -1.6279250e+00f);
   q = q * t;
-  const f32x2 e = pk(1.f, 1.f) - pk(__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1]));
-  const f32x2 hx = x * pk(0.5f, 0.5f);
+  const e2 e = pk(1.f, 1.f) - pk(__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1]));
+  const e2 hx = x * pk(0.5f, 0.5f);
   return hx + hx * pk(copysignf(e[0], z[0]), copysignf(e[1], z[1]));
 }
 
@@ -133,13 +151,13 @@ __device__ __forceinline__ void epi_rows(const MgldIGemm& p, const RowMap rmap, 
         for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = v[j];
       }
     } else if constexpr (KIND == EPI_PLAIN_NONE || KIND == EPI_PLAIN_SILU || KIND == EPI_GEGLU) {
-      f32x2 v[4] = {pk(a0[0], a0[1]), pk(a0[2], a0[3]), pk(a1[0], a1[1]), pk(a1[2], a1[3])};
+      e2 v[4] = {pk(a0[0], a0[1]), pk(a0[2], a0[3]), pk(a1[0], a1[1]), pk(a1[2], a1[3])};
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += pk(bcol[2 * j], bcol[2 * j + 1]);
       if constexpr (KIND == EPI_GEGLU) {
         const f32x4 g0 = *(const f32x4*)(patch + row * LDW + 32 + pcv);
         const f32x4 g1 = *(const f32x4*)(patch + row * LDW + 32 + pcv + 4);
-        const f32x2 g[4] = {pk(g0[0], g0[1]), pk(g0[2], g0[3]), pk(g1[0], g1[1]), pk(g1[2], g1[3])};
+        const e2 g[4] = {pk(g0[0], g0[1]), pk(g0[2], g0[3]), pk(g1[0], g1[1]), pk(g1[2], g1[3])};
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= gelu2(g[j] + pk(bgate[2 * j], bgate[2 * j + 1]));
       } else {
@@ -161,7 +179,7 @@ __device__ __forceinline__ void epi_rows(const MgldIGemm& p, const RowMap rmap, 
       f16* cp = (f16*)outp + cbase + (int64_t)m * ldo + n;
       if (R) {
         const f16* rp = R + (int64_t)m * p.ldr + n;
-        const f32x2 beta2 = pk(p.beta, p.beta);
+        const e2 beta2 = pk(p.beta, p.beta);
         if (full && ((((uintptr_t)rp) & 15) == 0)) {
           const f16x8 rr = *(const f16x8*)rp;
 #pragma unroll
