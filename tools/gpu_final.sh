@@ -1,0 +1,11 @@
+#!/bin/bash
+# round-end validation: full GPU test suite, the bench line, rocprofv3 kernel stats and the PMC traffic table of the same build
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/final_tests.log
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/final_bench.log 2> gpurun_out/final_bench.err
+tail -1 gpurun_out/final_bench.log > gpurun_out/final_bench.json
+timeout 900 bash tools/prof_run.sh > gpurun_out/final_prof.log 2>&1
+timeout 1500 bash tools/pmc_traffic.sh > gpurun_out/final_pmc.log 2>&1
+tail -4 gpurun_out/final_tests.log; cut -c1-400 gpurun_out/final_bench.json; head -16 gpurun_out/kernel_stats.txt | cut -c1-160; tail -2 gpurun_out/final_pmc.log | cut -c1-600
