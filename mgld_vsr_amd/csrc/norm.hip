@@ -229,23 +229,30 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x
     }
   }
   __syncthreads();
-  for (int c = tid; c < Cw; c += 256) {   // fold the rpi row slots into slot 0 (column c is touched by this thread only)
-    float ss = 0.f, qq = 0.f;
-    for (int r = 0; r < rpi; ++r) { ss += sred[(r * Cw + c) * 2]; qq += sred[(r * Cw + c) * 2 + 1]; }
-    sred[c * 2] = ss; sred[c * 2 + 1] = qq;
-  }
-  __syncthreads();
-  for (int g = tid; g < Cw / cg; g += 256) {
+  // per group: all 256 threads sum the rpi x cg per-channel partials (fp64), wave shuffle + one LDS hop across the four waves
+  __shared__ double wred[4][2];
+  for (int g = 0; g < Cw / cg; ++g) {
     double sd = 0.0, qd = 0.0;
-    for (int i = 0; i < cg; ++i) { sd += (double)sred[(g * cg + i) * 2]; qd += (double)sred[(g * cg + i) * 2 + 1]; }
-    const double n = (double)rows * cg;
-    const double mean = sd / n;
-    double var = qd / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    st[g][0] = (float)mean;
-    st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int i = tid; i < rpi * cg; i += 256) {
+      const int r = i / cg, c = g * cg + (i - r * cg);
+      sd += (double)sred[(r * Cw + c) * 2];
+      qd += (double)sred[(r * Cw + c) * 2 + 1];
+    }
+    sd = wave_sum_d(sd);
+    qd = wave_sum_d(qd);
+    if ((tid & 63) == 0) { wred[tid >> 6][0] = sd; wred[tid >> 6][1] = qd; }
+    __syncthreads();
+    if (tid == 0) {
+      const double ss = wred[0][0] + wred[1][0] + wred[2][0] + wred[3][0], qq = wred[0][1] + wred[1][1] + wred[2][1] + wred[3][1];
+      const double n = (double)rows * cg;
+      const double mean = ss / n;
+      double var = qq / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      st[g][0] = (float)mean;
+      st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (!active) return;
   float sa[8], sb[8];
 #pragma unroll
@@ -378,6 +385,17 @@ static dim3 apply_grid(int frames, int rows, int C, int groups, int* Cb) {
   const int cap = 4096 / (frames > 0 ? frames : 1);
   if (chunks > cap) chunks = cap > 0 ? cap : 1;
   *Cb = channel_window(C, groups, (int64_t)chunks * frames, 512);
+  // a block passes over its rows rpi x 4 at a time (4 rows in flight per thread): make the chunk a whole number of passes —
+  // 32-row chunks with 24 rows per pass (C = 320) spent a second, three-quarters-idle pass and its memory round trip
+  const int NV = *Cb >> 3;
+  const int pass = (NV >= 256 ? 1 : 256 / NV) * 4;
+  if (pass <= 64 && chunks < cap) {
+    int k = (32 + pass / 2) / pass;
+    if (k < 1) k = 1;
+    int c2 = cdiv(rows, k * pass);
+    if (c2 > cap) c2 = cap;
+    if (c2 >= 1) chunks = c2;
+  }
   return dim3(chunks, frames, cdiv(C, *Cb));
 }
 
