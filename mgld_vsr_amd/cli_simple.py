@@ -109,6 +109,8 @@ def main(argv=None, w_latent=False):
     if opt.vqgan_ckpt:
         pipe.vq_model.init_from_ckpt(opt.vqgan_ckpt)
     os.makedirs(opt.outdir, exist_ok=True)
+    from .preproc import FrameWriter
+    writer = FrameWriter()
     gscale = -1.0 if w_latent else -10.0
     eng = pipe.engine()
     for seq_idx, seq in enumerate(sorted(os.listdir(opt.seqs_path))):
@@ -142,15 +144,14 @@ def main(argv=None, w_latent=False):
             if CAPTURE is not None:
                 CAPTURE.append({"flows": flows, "masks": masks, "x0": lat, "frames": x})
             from . import preproc
-            from PIL import Image
             arrs = preproc.to_png_payload(out, opt.input_size, opt.input_size)
             lat_np = lat.cpu().numpy() if w_latent else None
             for k, f in enumerate(seg_names):
                 base = os.path.splitext(os.path.basename(f))[0]
-                Image.fromarray(arrs[k]).save(os.path.join(opt.outdir, seq, base + ".png"))
+                writer.png(os.path.join(opt.outdir, seq, base + ".png"), arrs[k])       # encoded off this thread
                 if w_latent:
-                    with open(os.path.join(opt.latent_dir, seq, base + ".npy"), "wb") as fh:
-                        np.save(fh, lat_np[k])
+                    writer.npy(os.path.join(opt.latent_dir, seq, base + ".npy"), lat_np[k])
+    writer.close()
     return 0
 
 

@@ -127,6 +127,8 @@ def main(argv=None):
     if opt.vqgan_ckpt:
         pipe.vq_model.init_from_ckpt(opt.vqgan_ckpt)
     os.makedirs(opt.outdir, exist_ok=True)
+    from mgld_vsr_amd.preproc import FrameWriter
+    writer = FrameWriter()                          # PNG / .npy encoding overlaps the next segment's sampling
 
     seq_names = sorted(os.listdir(opt.seqs_path))
     for seq_idx, seq in enumerate(seq_names):
@@ -196,17 +198,16 @@ def main(argv=None):
                                          clamp=(0.0, 1.0))
                 ori_h, ori_w = min(ori_h, out.shape[-2]), min(ori_w, out.shape[-1])
             arrs = preproc.to_png_payload(out, ori_h, ori_w)                                  # crop + uint8 (:532-543)
-            from PIL import Image
             for k in range(arrs.shape[0]):
                 base = os.path.splitext(os.path.basename(paths[s0 + k]))[0]
-                Image.fromarray(arrs[k]).save(os.path.join(opt.outdir, seq, base + ".png"))       # '{}.png'.format(basename) (:541)
+                writer.png(os.path.join(opt.outdir, seq, base + ".png"), arrs[k])                 # '{}.png'.format(basename) (:541)
             if opt.latent_dir and len(latents) == 1:             # w_latent.py:389-397
                 os.makedirs(os.path.join(opt.latent_dir, seq), exist_ok=True)
                 lat = latents[0].cpu().numpy()
                 for k in range(lat.shape[0]):
                     base = os.path.splitext(os.path.basename(paths[s0 + k]))[0]
-                    with open(os.path.join(opt.latent_dir, seq, base + ".npy"), "wb") as fh:
-                        np.save(fh, lat[k])
+                    writer.npy(os.path.join(opt.latent_dir, seq, base + ".npy"), lat[k])
+    writer.close()
 
 if __name__ == "__main__":
     main()

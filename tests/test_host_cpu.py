@@ -453,3 +453,24 @@ def test_checkpoint_loads_before_respacing(tmp_path):
     ctx = torch.randn(1, 77, 64)
     pipe3.load_checkpoint({"state_dict": sd2}, context=ctx, verbose=False)
     assert torch.equal(pipe3.model.cond_stage_model([""]), ctx)
+
+
+def test_frame_writer_writes_everything_and_reraises(tmp_path):
+    """preproc.FrameWriter: PNG / .npy output on a thread pool; close() waits for every file and surfaces the first failure"""
+    from PIL import Image
+    from mgld_vsr_amd.preproc import FrameWriter
+    rng = np.random.default_rng(0)
+    imgs = [(rng.random((24, 40, 3)) * 255).astype(np.uint8) for _ in range(6)]
+    with FrameWriter(workers=3) as w:
+        for k, im in enumerate(imgs):
+            w.png(str(tmp_path / f"{k:02d}.png"), im)
+            w.npy(str(tmp_path / f"{k:02d}.npy"), im[:2, :2].astype(np.float32))
+    for k, im in enumerate(imgs):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / f"{k:02d}.png")), im)
+        assert np.array_equal(np.load(tmp_path / f"{k:02d}.npy"), im[:2, :2].astype(np.float32))
+    w = FrameWriter(workers=1)
+    w.png(str(tmp_path / "missing_dir" / "x.png"), imgs[0])
+    w.png(str(tmp_path / "ok.png"), imgs[1])
+    with pytest.raises(FileNotFoundError):
+        w.close()
+    assert (tmp_path / "ok.png").exists()
