@@ -358,7 +358,9 @@ def main():
                    "frames_per_segment": args.frames,
                    "parallelism": (f"tile-sharded x{world}" if args.tile_shard and shard is not None else f"frame-sharded x{world}")
                    if shard is not None else f"segment-parallel x{world}", "finite": ok,
-                   "reduced_width": bool(args.small)},
+                   "reduced_width": bool(args.small),
+                   # how a sampling step is launched: one hipGraph, or (sharded modes) graph pieces around the collectives
+                   "graphs_per_step": int(getattr(pipe.model, "last_graph_pieces", 0))},
         "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
                                                           GFLOP_DEC_PER_FRAME) / 1e3 / (dt / args.steps), 1),
     }

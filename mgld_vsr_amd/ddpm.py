@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .engine import Act, Engine
+from .engine import Act, Engine, GraphPieces
 from .util import default, instantiate_from_config
 from .vae import DiagonalGaussianDistribution
 
@@ -449,7 +449,9 @@ class LatentDiffusionVSRTextWT(nn.Module):
             if tsh is not None:
                 if len(mine) < nl:
                     et[len(mine) * T:].zero_()
-                et = tsh.gather(et)                              # every tile's eps on every rank (one exchange per step)
+                etl = et
+                et = eng.arena.alloc((tsh.world * nl * T, c, ts, ts), torch.float32)
+                eng.collective(lambda: tsh.gather(etl, out=et))   # every tile's eps on every rank (one exchange per step)
             acc, cnt = st["acc"], st["cnt"]
             acc.zero_()
             cnt.zero_()
@@ -467,7 +469,8 @@ class LatentDiffusionVSRTextWT(nn.Module):
             else:
                 # frame-sharded clip: the guidance chain couples neighbouring frames -> all-gather the (64 KiB/frame)
                 # latents, evaluate the tiny gradient on the whole clip on every rank, keep this rank's frames
-                zf = sh.all_gather(st["z"])
+                zf = st["z_full"]
+                eng.collective(lambda: sh.all_gather(st["z"], out=zf))
                 hip.guidance(zf, st["ff"], st["fb"], st["fo"], st["bo"], st["coef"], st["step_idx"], st["gscale"],
                              st["x_full"], st["work"])
                 x.copy_(sh.local(st["x_full"]))
@@ -509,10 +512,13 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 "ctx": self.model.diffusion_model.context_cache(eng, ctx), "guided": flows is not None,
                 "gscale": float(guidance_scale), "tiles": None,
             }
+            pieces_mode = False
             sh = eng.shard
             if sh is not None:
                 assert tile is None and T_total == sh.F, "frame sharding: one clip per segment, local frames only"
-                use_graph = use_graph and sh.world == 1   # collectives sit between the launches of a step
+                # collectives sit between the launches of a step: the step replays as graph PIECES around them (engine.GraphPieces)
+                pieces_mode = use_graph and sh.world > 1 and os.environ.get("MGLD_SHARD_GRAPH", "1") != "0"
+                use_graph = use_graph and sh.world == 1
             if flows is not None:
                 T_clip = T_total if sh is None else sh.T
                 assert T_clip == self.num_frames, "guidance expects one clip of num_frames frames"
@@ -521,6 +527,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 st["work"] = torch.empty(hip.guidance_work_bytes(T_clip, c, h, w), dtype=torch.uint8, device=dev)
                 if sh is not None:
                     st["x_full"] = torch.empty((T_clip, c, h, w), device=dev)
+                    st["z_full"] = torch.empty((T_clip, c, h, w), device=dev)
             # persistent (non-arena) conditioning buffers
             if tile is None:
                 la = torch.empty(T_total * h * w, 8, dtype=torch.float16, device=dev)
@@ -534,6 +541,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 if tsh is not None:
                     if tsh.n_tiles != len(tiles):
                         raise ValueError(f"tile shard built for {tsh.n_tiles} tiles, this canvas has {len(tiles)}")
+                    pieces_mode = use_graph and tsh.world > 1 and os.environ.get("MGLD_SHARD_GRAPH", "1") != "0"
                     use_graph = use_graph and tsh.world == 1     # the tile exchange sits between the launches of a step
                 own = tiles if tsh is None else tiles[tsh.k0:tsh.k1]
                 n_own = max(1, len(own))
@@ -552,6 +560,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 st["hoist_window"] = Wn = min(self._hoist_window(eng, lat_in, S), int(os.environ.get("MGLD_HOIST_WINDOW", S)))
             intermediates = [x.clone()]
             graph = None
+            eng.pieces = None
             for k, i in enumerate(reversed(range(S))):
                 if self.precompute_structcond and k % Wn == 0:  # a new hoisting window: schedule indices i .. i-Wn+1
                     self._precompute_structcond(eng, st, lat_in, i, max(0, i - Wn + 1))
@@ -559,7 +568,23 @@ class LatentDiffusionVSRTextWT(nn.Module):
                         self._precompute_spade(eng, st)
                 if k == 1 and hoist_spade:
                     self._precompute_spade(eng, st)             # after the eager first step (it records the block scales)
-                if k == 0 or not use_graph:
+                if pieces_mode and k > 0:
+                    if eng.pieces is None:                      # record the step as graph pieces around its collectives
+                        eng.arena.frozen = True
+                        eng.pieces = GraphPieces()
+                        eng.pieces.begin()
+                        try:
+                            self._step_body(eng, st)
+                            eng.pieces.finish()
+                        except BaseException:
+                            eng.pieces.abort()
+                            eng.pieces = None
+                            raise
+                        finally:
+                            eng.arena.frozen = False
+                    else:
+                        eng.pieces.replay()
+                elif k == 0 or not use_graph:
                     self._step_body(eng, st)
                 else:
                     if graph is None:
@@ -575,6 +600,8 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 if return_intermediates and (i % log_every_t == 0 or i == S - 1):
                     intermediates.append(x.clone())
             self.last_launches_per_step = eng.launches
+            self.last_graph_pieces = eng.pieces.n_graphs if eng.pieces is not None else (1 if graph is not None else 0)
+            eng.pieces = None
             out = x
         cur.wait_stream(self._stream)
         if return_intermediates:

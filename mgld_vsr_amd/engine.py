@@ -166,6 +166,55 @@ class Arena:
         return sum(c.numel() for c in self.chunks)
 
 
+class GraphPieces:
+    """A sharded step as hipGraph PIECES with the collectives between them (frame / tile sharding: a collective cannot sit
+    inside a captured graph, and ~550 eager launches per step make a step host-bound once a rank holds one frame).  Recording
+    pass = the first step after the eager one: every `Engine.collective(fn)` ends the running capture, launches that piece (so
+    the exchange sees real data), runs `fn`, and starts the next capture; later steps replay the list [graph, fn, graph, ...].
+    Legal for the same reason the single graph is: the arena hands out identical pointers for identical call sequences, and the
+    exchanges write into caller-owned buffers of fixed address."""
+
+    def __init__(self):
+        self.items, self.cur = [], None
+
+    def begin(self):
+        self.cur = hip.Graph()
+        self.cur.begin()
+
+    def _close(self):
+        g, self.cur = self.cur, None
+        g.end()
+        g.launch()
+        self.items.append(g)
+
+    def collective(self, fn):
+        self._close()
+        fn()
+        self.items.append(fn)
+        self.begin()
+
+    def finish(self):
+        self._close()
+
+    def abort(self):
+        if self.cur is not None:
+            try:
+                self.cur.end()
+            finally:
+                self.cur = None
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, hip.Graph):
+                it.launch()
+            else:
+                it()
+
+    @property
+    def n_graphs(self):
+        return sum(1 for it in self.items if isinstance(it, hip.Graph))
+
+
 class Engine:
     """Owns the arena, the packed-weight cache and the op helpers every network forward is written in."""
 
@@ -183,12 +232,20 @@ class Engine:
         self.launches = 0
         self.shard = None   # parallel.FrameShard when the frames of one segment are split over ranks
         self.tile_shard = None   # parallel.TileShard when the latent tiles of aggregation sampling are split over ranks
+        self.pieces = None       # GraphPieces while a sharded step is recorded / replayed as hipGraph pieces
         # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
         self._splitk_ws = hip.ensure_workspace(workspace_bytes) if self.device.type == "cuda" else None
 
     # ---- memory ----
     def reset(self):
         self.arena.reset()
+
+    def collective(self, fn):
+        """run an inter-rank exchange: directly, or as a break between two graph pieces while a sharded step is being recorded"""
+        if self.pieces is not None and self.pieces.cur is not None:
+            self.pieces.collective(fn)
+        else:
+            fn()
 
     def empty(self, rows, C, dtype=torch.float16):
         return self.arena.alloc((rows, C), dtype)
@@ -312,7 +369,7 @@ class Engine:
         ext = self.arena.alloc(((F + 2) * hw, x.C), torch.float16)
         mid = ext[hw:(F + 1) * hw]
         hip.copy2d(x.v, mid)
-        sh.halo(x.v, hw, ext[:hw], ext[(F + 1) * hw:])
+        self.collective(lambda: sh.halo(x.v, hw, ext[:hw], ext[(F + 1) * hw:]))
         hip.igemm(mid, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
                   tconv=(x.C, F + 2, hw), t_off=1)
         self.launches += 2

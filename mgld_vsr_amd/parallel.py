@@ -95,10 +95,13 @@ def gather_frames(local_frames, segment_ids, n_segments, device=None):
 class DistComm:
     """torch.distributed transport ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
 
-    def all_gather(self, t, shard):
+    def all_gather(self, t, shard, out=None):
+        """`out`: a caller-owned buffer of the gathered shape (fixed address: what the graph pieces of a sharded step need)"""
         import torch.distributed as dist
         t = t.contiguous()
-        out = torch.empty((shard.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if out is None:
+            out = torch.empty((shard.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        assert out.is_contiguous() and out.shape[0] == shard.world * t.shape[0]
         try:
             dist.all_gather_into_tensor(out, t)
         except (RuntimeError, NotImplementedError):
@@ -127,9 +130,9 @@ class DistComm:
                 req.wait()
 
 
-    def gather_tiles(self, t, shard):
+    def gather_tiles(self, t, shard, out=None):
         """[per*rows, ...] (this rank's tiles, zero-padded to `per` tiles) -> [world*per*rows, ...] in rank order"""
-        return self.all_gather(t, shard)
+        return self.all_gather(t, shard, out=out)
 
 
 class RecordingComm:
@@ -139,18 +142,24 @@ class RecordingComm:
     def __init__(self):
         self.trace = []
 
-    def all_gather(self, t, shard):
+    def all_gather(self, t, shard, out=None):
         self.trace.append(("gather", t.detach().clone()))
-        return t
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
 
     def exchange(self, x, rows_per_frame, recv_left, recv_right, shard):
         self.trace.append(("halo", x.detach().clone()))
         recv_left.zero_()
         recv_right.zero_()
 
-    def gather_tiles(self, t, shard):
+    def gather_tiles(self, t, shard, out=None):
         self.trace.append(("tiles", t.detach().clone()))
-        return t
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
 
 
 class ReplayComm:
@@ -171,8 +180,12 @@ class ReplayComm:
         self.worst = max(self.worst, float((local.float() - mine.float()).norm()) / den)
         return full
 
-    def all_gather(self, t, shard):
-        return self._next("gather", t, shard, None).clone()
+    def all_gather(self, t, shard, out=None):
+        full = self._next("gather", t, shard, None)
+        if out is None:
+            return full.clone()
+        out.copy_(full)
+        return out
 
     def exchange(self, x, rows_per_frame, recv_left, recv_right, shard):
         full = self._next("halo", x, shard, rows_per_frame)
@@ -188,7 +201,7 @@ class ReplayComm:
             recv_right.zero_()
 
 
-    def gather_tiles(self, t, shard):
+    def gather_tiles(self, t, shard, out=None):
         k, full = self.trace[self.pos]
         self.pos += 1
         assert k == "tiles", f"communication sequence diverged: expected {k}, got tiles"
@@ -197,7 +210,10 @@ class ReplayComm:
         mine = full[shard.k0 * rows:shard.k0 * rows + valid]
         den = float(mine.float().norm()) + 1e-30
         self.worst = max(self.worst, float((t[:valid].float() - mine.float()).norm()) / den)
-        out = torch.zeros((shard.world * shard.per * rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if out is None:
+            out = torch.zeros((shard.world * shard.per * rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        else:
+            out.zero_()
         out[:full.shape[0]] = full
         return out
 
@@ -220,8 +236,8 @@ class TileShard:
         """position of global tile k in the gathered buffer (in tiles)"""
         return (k // self.per) * self.per + (k % self.per)
 
-    def gather(self, t):
-        return self.comm.gather_tiles(t, self)
+    def gather(self, t, out=None):
+        return self.comm.gather_tiles(t, self, out=out)
 
 
 class FrameShard:
@@ -239,9 +255,9 @@ class FrameShard:
         """this rank's frames of a full-clip tensor"""
         return t.narrow(dim, self.f0, self.F)
 
-    def all_gather(self, t):
-        """[F*k, ...] per rank -> [T*k, ...] in rank (= frame) order"""
-        return self.comm.all_gather(t, self)
+    def all_gather(self, t, out=None):
+        """[F*k, ...] per rank -> [T*k, ...] in rank (= frame) order (into `out` when given)"""
+        return self.comm.all_gather(t, self, out=out)
 
     def halo(self, x, rows_per_frame, recv_left, recv_right):
         self.comm.exchange(x, rows_per_frame, recv_left, recv_right, self)

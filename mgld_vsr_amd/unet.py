@@ -376,7 +376,8 @@ class TemporalAttention(nn.Module):
             # the 8x8 level), run the (tiny) kernel on the whole clip, keep this rank's rows
             if x.n != sh.F:
                 raise RuntimeError("sharded temporal attention expects one clip per segment")
-            full = sh.all_gather(qkv)
+            full = eng.arena.alloc((sh.T * x.hw, 3 * C), torch.float16)      # fixed address: the exchange of every replayed step lands here
+            eng.collective(lambda: sh.all_gather(qkv, out=full))
             of = eng.empty(sh.T * x.hw, C)
             hip.temporal_attention(full[:, 0:C], full[:, C:2 * C], full[:, 2 * C:3 * C], of, sh.T, x.hw, H, d, d ** -0.5)
             eng.launches += 1

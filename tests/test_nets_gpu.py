@@ -385,6 +385,17 @@ def test_pipeline_frame_sharded_matches_unsharded(hip):
             assert o.shape[0] == Tn // world
             worst = max(worst, rp.worst, rel_l2(o, out0[sh.f0:sh.f1]), rel_l2(l, lat0[sh.f0:sh.f1]))
     assert record("frame_sharded_vs_unsharded", worst) < 1.3e-3            # tile configs differ with M: fp16-level only
+    # the same virtual ranks with the step replayed as hipGraph PIECES around its collectives (engine.GraphPieces: 2 halo
+    # exchanges + the temporal-attention gather + the guidance gather = 5 pieces per step): bit-identical to eager launches
+    for world, r in ((2, 1), (4, 2)):
+        sh = parallel.FrameShard(Tn, r, world, parallel.ReplayComm(rec.trace))
+        o_e, l_e = pipe.run_segment(x, shard=sh, gather=False, **kw)
+        rp = parallel.ReplayComm(rec.trace)
+        sh = parallel.FrameShard(Tn, r, world, rp)
+        o_g, l_g = pipe.run_segment(x, shard=sh, gather=False, **dict(kw, use_graph=True))
+        assert rp.pos == len(rec.trace)
+        assert pipe.model.last_graph_pieces == 5, pipe.model.last_graph_pieces
+        assert torch.equal(l_g, l_e) and torch.equal(o_g, o_e)
 
 
 def test_sample_canvas_tile_sharded_matches_unsharded(hip):
@@ -419,6 +430,15 @@ def test_sample_canvas_tile_sharded_matches_unsharded(hip):
                 xr = model.sample_canvas(**kw)
                 assert rp.pos == len(rec.trace)
                 worst = max(worst, rp.worst, rel_l2(xr, x0))
+        # graph pieces around the one tile exchange of a step (2 pieces): bit-identical to the eager sharded run
+        rp = parallel.ReplayComm(rec.trace)
+        eng.tile_shard = parallel.TileShard(n_tiles, 1, 2, rp)
+        xe = model.sample_canvas(**kw)
+        rp = parallel.ReplayComm(rec.trace)
+        eng.tile_shard = parallel.TileShard(n_tiles, 1, 2, rp)
+        xg = model.sample_canvas(**dict(kw, use_graph=True))
+        assert rp.pos == len(rec.trace) and model.last_graph_pieces == 2
+        assert torch.equal(xg, xe)
     finally:
         eng.tile_shard = None
     assert record("tile_sharded_vs_unsharded", worst) < 1e-3     # fewer tiles per pass -> other tile configs: fp16-level only
