@@ -93,8 +93,9 @@ def _shard_worker(rank, world, port, ret):
     y = sh.all_gather(yl.reshape(sh.F * hw, C)).reshape(T, hw, C)
     ok_conv = torch.allclose(y, _tconv_full(x, w), atol=1e-5)
     # all-gather keeps rank (= frame) order
-    ids = sh.all_gather(torch.arange(sh.f0, sh.f1, dtype=torch.float32).reshape(sh.F, 1))
-    ok_order = ids.flatten().tolist() == list(range(T))
+    buf = torch.full((T, 1), -1.0)     # caller-owned destination (what the graph pieces of a sharded step use): filled in place
+    ids = sh.all_gather(torch.arange(sh.f0, sh.f1, dtype=torch.float32).reshape(sh.F, 1), out=buf)
+    ok_order = ids is buf and ids.flatten().tolist() == list(range(T))
     ret[rank] = (bool(ok_conv), bool(ok_order), float(ext[:hw].abs().sum()), float(ext[(sh.F + 1) * hw:].abs().sum()))
     import torch.distributed as dist
     dist.barrier()
@@ -156,7 +157,9 @@ def _tile_worker(rank, world, port, ret):
     loc = torch.zeros(sh.per * T, c, ts, ts)
     for j, k in enumerate(range(sh.k0, sh.k1)):
         loc[j * T:(j + 1) * T] = float(k + 1)
-    full = sh.gather(loc)
+    buf = torch.full((world * sh.per * T, c, ts, ts), -1.0)
+    full = sh.gather(loc, out=buf)
+    assert full is buf
     got = [float(full[sh.slot(k) * T, 0, 0, 0]) for k in range(n_tiles)]
     ret[rank] = (got, sh.k0, sh.k1, tuple(full.shape))
     import torch.distributed as dist
