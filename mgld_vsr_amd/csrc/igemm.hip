@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
 // instead of 2 per 1 and half the weight bytes per FLOP of the 128-pixel tiles.  Weights: the tiled layout of tap_inner = 2 only.
 template <int TY, int TX, int BN, int WM, int WN, bool UP2, int PF = 1>
 __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kernel(const MgldIGemm p, float* __restrict__ ws, int hchunk,
-                                                                                  int tiles_x, int tiles_y) {
+                                                                                  int tiles_x, int tiles_y, int order) {
   constexpr int BM = TY * TX;
   constexpr int WAVES_N = BN / WN;
   constexpr int NW = (BM / WM) * WAVES_N;
@@ -924,12 +924,24 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  // Workgroups go round-robin to the 8 XCDs in linear-id order (gridDim.x % 8 == 0: the same XCD pattern in every K-split plane).
+  // order 0: the N/BN blocks sharing a PATCH run back to back on one XCD (see conv3p) — the activations leave the Infinity Cache
+  // once (64x64 level: A >> W).  order 1: every XCD takes a contiguous eighth of the (weight tile major, pixel tile minor) list,
+  // i.e. all pixel tiles of ~N/BN/8 weight tiles: the blocks sharing a WEIGHT tile share it through that XCD's L2 instead of
+  // every XCD streaming the whole matrix (16x16 / 8x8 levels: W = 30-60 MB against 1-5 MB of activations; PMC showed 3-3.8x the
+  // algorithmic bytes there).
   int tile_m = blockIdx.x, tile_n = blockIdx.y;
-  if ((gridDim.x & 7) == 0) {   // the N/BN blocks sharing a patch run back to back on one XCD (see conv3p)
+  if ((gridDim.x & 7) == 0) {
     const int lin = blockIdx.x + gridDim.x * blockIdx.y;
     const int xcd = lin & 7, j = lin >> 3;
-    tile_m = xcd + 8 * (j / (int)gridDim.y);
-    tile_n = j % (int)gridDim.y;
+    if (order == 1) {
+      const int q = xcd * ((int)(gridDim.x * gridDim.y) >> 3) + j;
+      tile_n = q / (int)gridDim.x;
+      tile_m = q - tile_n * (int)gridDim.x;
+    } else {
+      tile_m = xcd + 8 * (j / (int)gridDim.y);
+      tile_n = j % (int)gridDim.y;
+    }
   }
   const int tpf = tiles_x * tiles_y;
   const int frame = tile_m / tpf;
@@ -1402,8 +1414,13 @@ int launch_conv3q(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
   const int tiles_x = cdiv(p->Wout, TX), tiles_y = cdiv(p->Hout, TY);
   dim3 grid(frames * tiles_x * tiles_y, cdiv(p->N, BN), splits > 1 ? splits : 1);
   constexpr int THREADS = 64 * (TY * TX / WM) * (BN / WN);
+  // tile order: share the weight tiles per XCD where the weights outweigh the activations (env MGLD_CONV3Q_ORDER = 0 / 1 forces)
+  static int forder = -2;
+  if (forder == -2) { const char* e = getenv("MGLD_CONV3Q_ORDER"); forder = e ? atoi(e) : -1; }
+  const double wbytes = 2.0 * p->N * p->K, abytes = 2.0 * p->M * p->Cin / (UP2 ? 4 : 1);
+  const int order = forder >= 0 ? forder : (wbytes > 2.0 * abytes ? 1 : 0);
   hipLaunchKernelGGL((conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF>), grid, dim3(THREADS), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk,
-                     tiles_x, tiles_y);
+                     tiles_x, tiles_y, order);
   if (splits > 1) {
     const int64_t total = (int64_t)p->M * ((p->N + 3) >> 2);
     int blocks = (int)((total + 255) / 256);

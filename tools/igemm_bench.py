@@ -27,6 +27,8 @@ CONV = [
     ("conv32 256->256", 1, 8192, 256, 2304, 256, 32, 32, 0, 0, 300),
     ("conv16 1280->1280", 1, 2048, 1280, 11520, 1280, 16, 16, 0, 0, 300),
     ("conv16 2560->1280", 1, 2048, 1280, 23040, 2560, 16, 16, 0, 0, 100),
+    ("conv8 1280->1280", 1, 512, 1280, 11520, 1280, 8, 8, 0, 0, 550),
+    ("conv8 2560->1280", 1, 512, 1280, 23040, 2560, 8, 8, 0, 0, 150),
     ("up 32->64 640", 1, 32768, 640, 5760, 640, 32, 32, 0, 1, 50),
     ("up 16->32 1280", 1, 8192, 1280, 11520, 1280, 16, 16, 0, 1, 50),
 ]
