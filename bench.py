@@ -33,8 +33,8 @@ GFLOP_DEC_PER_FRAME = 4139.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddpm-steps", type=int, default=50)

@@ -50,6 +50,7 @@ class FrameWriter:
         from concurrent.futures import ThreadPoolExecutor
         self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
         self._pending = []
+        self._by_path = {}      # a path written twice (the repeat-last padding of a short final segment): the later write wins
 
     @staticmethod
     def _png(path, arr):
@@ -62,11 +63,22 @@ class FrameWriter:
         with open(path, "wb") as fh:
             np.save(fh, arr)
 
+    def _submit(self, fn, path, arr):
+        prev = self._by_path.get(path)
+        if prev is not None:
+            try:
+                prev.result()       # never two writers on one file; the earlier error (if any) resurfaces in close()
+            except Exception:
+                pass
+        f = self._pool.submit(fn, path, arr)
+        self._by_path[path] = f
+        self._pending.append(f)
+
     def png(self, path, arr):
-        self._pending.append(self._pool.submit(self._png, path, arr))
+        self._submit(self._png, path, arr)
 
     def npy(self, path, arr):
-        self._pending.append(self._pool.submit(self._npy, path, arr))
+        self._submit(self._npy, path, arr)
 
     def close(self):
         err = None

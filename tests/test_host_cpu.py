@@ -468,6 +468,10 @@ def test_frame_writer_writes_everything_and_reraises(tmp_path):
     for k, im in enumerate(imgs):
         assert np.array_equal(np.asarray(Image.open(tmp_path / f"{k:02d}.png")), im)
         assert np.array_equal(np.load(tmp_path / f"{k:02d}.npy"), im[:2, :2].astype(np.float32))
+    with FrameWriter(workers=4) as w:          # the same path twice (repeat-last padding of a short segment): the later write wins
+        for im in imgs:
+            w.png(str(tmp_path / "dup.png"), im)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "dup.png")), imgs[-1])
     w = FrameWriter(workers=1)
     w.png(str(tmp_path / "missing_dir" / "x.png"), imgs[0])
     w.png(str(tmp_path / "ok.png"), imgs[1])

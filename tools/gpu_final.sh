@@ -4,8 +4,10 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/final_tests.log
+( time timeout 900 python bench.py > gpurun_out/final_bench_default.log 2> gpurun_out/final_bench_default.err ) 2> gpurun_out/final_bench_default.time
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/final_bench.log 2> gpurun_out/final_bench.err
 tail -1 gpurun_out/final_bench.log > gpurun_out/final_bench.json
 timeout 900 bash tools/prof_run.sh > gpurun_out/final_prof.log 2>&1
 timeout 1500 bash tools/pmc_traffic.sh > gpurun_out/final_pmc.log 2>&1
-tail -4 gpurun_out/final_tests.log; cut -c1-400 gpurun_out/final_bench.json; head -16 gpurun_out/kernel_stats.txt | cut -c1-160; tail -2 gpurun_out/final_pmc.log | cut -c1-600
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+tail -4 gpurun_out/final_tests.log; cat gpurun_out/final_bench_default.time | tail -3; cut -c1-300 gpurun_out/final_bench.json; head -12 gpurun_out/kernel_stats.txt | cut -c1-150; tail -2 gpurun_out/final_pmc.log | cut -c1-400
