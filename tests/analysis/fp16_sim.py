@@ -4,7 +4,7 @@ the fp32 golden outputs.  R(x) = x.half().float().  Modes: which tensors are rou
    in   - activations entering a contraction (conv / linear / conv1d / conv3d / attention matmuls): what the MFMA sees in any case
    w    - weights of the contractions
    out  - outputs of contractions and of the normalisations as they are stored (fp16 tensors between kernels)
-Scratch tool for DESIGN.md section 5."""
+Analysis script behind the floor table of DESIGN.md section 5 (test infrastructure: it drives the oracle; not collected by pytest)."""
 import json
 import os
 import sys
@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL  # noqa: E402

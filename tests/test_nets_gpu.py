@@ -67,7 +67,7 @@ def test_unet_small_vs_golden(hip, small_nets):
     g = G("g_unet")
     sc = {k[3:]: v.cuda() for k, v in g.items() if k.startswith("sc_")}
     eps = unet(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].cuda(), struct_cond=sc)
-    assert record("unet_small", rel_l2(eps, g["eps"])) < 2.4e-3   # fp16-storage floor 1.8e-3 (tools/fp16_sim.py; DESIGN.md parity table)
+    assert record("unet_small", rel_l2(eps, g["eps"])) < 2.4e-3   # fp16-storage floor 1.8e-3 (tests/analysis/fp16_sim.py; DESIGN.md parity table)
     # per-frame (non-uniform) timesteps go through the M = n embedding path
     t2 = torch.tensor([541, 20, 999])
     usd = {k: v for k, v in unet.state_dict().items()}
@@ -90,7 +90,7 @@ def test_vae_small_vs_golden(hip):
     f1 = vq.engine().to_nchw(fea[1])
     assert record("vae_small_fea0", rel_l2(f0, g["fea0"])) < 1.6e-3 and record("vae_small_fea1", rel_l2(f1, g["fea1"])) < 1.8e-3
     dec = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])
-    assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 2.8e-3          # fp16-storage floor 2.15e-3 (tools/fp16_sim.py)
+    assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 2.8e-3          # fp16-storage floor 2.15e-3 (tests/analysis/fp16_sim.py)
     vq.decoder.fusion_w = 0.5                                   # the reference script's default --dec_w
     dec05 = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])     # decoder alone: the reference's own features
     assert record("vae_small_dec_w05", rel_l2(dec05, g["dec_w05"])) < 4e-3   # floor 3.2e-3: the fusion layers blend two fp16 feature sets
@@ -343,7 +343,7 @@ def test_pipeline_config0_fullwidth_vs_reference(hip):
     assert got["c1_full_unet_eps"] < 2.6e-3 and got["c1_full_decoder"] < 2.5e-3
     # the outputs.  The sampled latent meets the north_star tolerance (9.6e-4).  The colour-fixed frame of this config measures
     # 1.03e-3: it inherits the video decoder's single-evaluation error (2.0e-3 here), of which 1.6e-3 is the rounding of the
-    # MFMA OPERANDS to fp16 alone (weights 1.1e-3 + activations 1.2e-3, tools/fp16_sim.py) — no storage
+    # MFMA OPERANDS to fp16 alone (weights 1.1e-3 + activations 1.2e-3, tests/analysis/fp16_sim.py) — no storage
     # format between the kernels can remove it, only a second MFMA pass per convolution would.  Bound: 1.1e-3.
     assert got["c1_full_latent"] < 1e-3 and got["c1_full_frames"] < 1.1e-3, got
     assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
