@@ -23,6 +23,7 @@
 //     23040) are split along K over grid.z into fp32 partials and finished by a small reduce+epilogue kernel.
 #include "common.h"
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -255,13 +256,14 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
   // per output row, residual rows read the same way.  (Wave-local: no block barrier except the one releasing the stages.)
   __syncthreads();
   if constexpr (ABL & 512) return;  // ablation build (timing only): no epilogue
-  static_assert(WN == 64 || WN == 32, "wave tile width");
+  // wave tiles wider than 64 columns (the full-N LINEAR tiles, WN = 160) go through the patch in column chunks of CW
+  constexpr int CW = WN <= 64 ? WN : (WN % 64 == 0 ? 64 : 32), NC = WN / CW, NIC = CW / 32;
+  static_assert(WN % 32 == 0 && NC * CW == WN, "wave tile width");
   const bool geglu = (WN == 64) && (!splitk) && (p.act == MGLD_ACT_GEGLU);   // value/gate pairing needs 64-column wave tiles
-  constexpr int LDW = WN + 4;                       // patch row stride (floats): 16-B aligned, conflict-free b128
+  constexpr int LDW = CW + 4;                       // patch row stride (floats): 16-B aligned, conflict-free b128
   float* patch = (float*)smem + wave * (32 * LDW);
   const int Nout = splitk ? N : (geglu ? N / 2 : N);
-  const int wcols = geglu ? WN / 2 : WN;            // output columns this wave produces
-  const int ncol0 = geglu ? (bn0 + wn * WN) / 2 : bn0 + wn * WN;
+  const int wcols = geglu ? CW / 2 : CW;            // output columns this wave produces per chunk
   const int64_t cbase = splitk ? (int64_t)kz * M * N : (int64_t)bz * p.strideC;
   const int ldo = splitk ? N : p.ldc;
   const bool of32 = splitk || p.out_f32;
@@ -272,6 +274,14 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
   const int lpr = wcols >> 3;                       // lanes per output row (8 columns each)
   const int rpi = 64 / lpr;                         // rows per wave pass
   const int prow = lane / lpr, pcv = (lane - prow * lpr) * 8;
+  int kind = EPI_GENERIC;
+  if (splitk) kind = EPI_SLAB;
+  else if (geglu) kind = (alpha == 1.f && !of32) ? EPI_GEGLU : EPI_GENERIC;
+  else if (!of32 && !p.bias_m && alpha == 1.f && (act == MGLD_ACT_NONE || act == MGLD_ACT_SILU)) kind = act == MGLD_ACT_SILU ? EPI_PLAIN_SILU : EPI_PLAIN_NONE;
+  // (column chunks unrolled by hand through compile-time indices: a runtime `c` would index acc[] dynamically = scratch memory)
+  auto do_chunk = [&](auto CI) {
+  constexpr int c = decltype(CI)::value;
+  const int ncol0 = geglu ? (bn0 + wn * WN) / 2 : bn0 + wn * WN + c * CW;
   const int n = ncol0 + pcv;                        // this lane's 8 output columns [n, n+8)
   const bool full = (n + 8 <= Nout);
   // per-lane column constants (same for every row): bias of the 8 columns (value and gate halves for GEGLU)
@@ -286,19 +296,16 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
       if (geglu && nb + 32 + j < N) bgate[j] = p.bias[nb + 32 + j];
     }
   }
-  int kind = EPI_GENERIC;
-  if (splitk) kind = EPI_SLAB;
-  else if (geglu) kind = (alpha == 1.f && !of32) ? EPI_GEGLU : EPI_GENERIC;
-  else if (!of32 && !p.bias_m && alpha == 1.f && (act == MGLD_ACT_NONE || act == MGLD_ACT_SILU)) kind = act == MGLD_ACT_SILU ? EPI_PLAIN_SILU : EPI_PLAIN_NONE;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     // ---- phase 1: raw accumulators -> patch[row = l31][col] ----
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int nic = 0; nic < NIC; ++nic)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
-        *(f32x4*)(patch + l31 * LDW + ni * 32 + rg * 8 + lhi * 4) =
-            f32x4{acc[ni][mi][rg * 4], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+        *(f32x4*)(patch + l31 * LDW + nic * 32 + rg * 8 + lhi * 4) =
+            f32x4{acc[c * NIC + nic][mi][rg * 4], acc[c * NIC + nic][mi][rg * 4 + 1], acc[c * NIC + nic][mi][rg * 4 + 2],
+                  acc[c * NIC + nic][mi][rg * 4 + 3]};
     // ---- phase 2: patch rows -> epilogue math -> global, 8 columns (16 B of fp16 / 32 B of fp32) per lane ----
     // The variant (plain fp16 epilogue with a compile-time activation / GEGLU / raw split-K slab / everything else) is picked by
     // ONE block-uniform switch per 32-row slice; inside, the arithmetic is straight-line packed fp32 (v_pk_add/mul/fma_f32).
@@ -312,6 +319,13 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
       default: epi_rows<EPI_GENERIC>(p, rmap, patch, LDW, wm * WM + mi * 32, rpi, prow, pcv, n, Nout, full, bcol, bgate, R, outp, cbase, ldo, of32, act, alpha, geglu); break;
     }
   }
+  };
+  static_assert(NC <= 5, "column chunks");
+  do_chunk(std::integral_constant<int, 0>{});
+  if constexpr (NC > 1) do_chunk(std::integral_constant<int, 1>{});
+  if constexpr (NC > 2) do_chunk(std::integral_constant<int, 2>{});
+  if constexpr (NC > 3) do_chunk(std::integral_constant<int, 3>{});
+  if constexpr (NC > 4) do_chunk(std::integral_constant<int, 4>{});
 }
 
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST>
@@ -1244,6 +1258,17 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
     if (force < 0) { const char* e = getenv("MGLD_IGEMM_FORCE"); force = e ? atoi(e) : 0; }
     if (force && p->act != MGLD_ACT_GEGLU && N > 64) { *cfg = force; return; }
   }
+  // full-N tiles (128 x 320, eight waves of 32 x 160) for the 320-channel projections of the 64x64 level: the activation rows enter LDS
+  // ONCE instead of once per 64-column tile, and M / 128 = 256 blocks is exactly one per CU.  Measured (profiles/r02_linear_ring_depth.txt):
+  // isolated launches 18.5 vs 19.4 us (K = 320) and 40.6 vs 50.5 us (K = 1280), but the whole segment does not move (801 vs 797 ms:
+  // in the pipeline the producer leaves the rows in L2 / Infinity Cache and one block per CU exposes its prologue and epilogue), so
+  // the planner does not pick them: p->tune = 10 or env MGLD_IGEMM_FULLN=1 selects them, p->tune = 11 forbids them (tests).
+  {
+    static int fulln = -1;
+    if (fulln < 0) { const char* e = getenv("MGLD_IGEMM_FULLN"); fulln = e ? atoi(e) : 0; }
+    const bool can = p->mode == MGLD_MODE_LINEAR && N == 320 && (K % BK) == 0 && batch == 1 && p->act != MGLD_ACT_GEGLU;
+    if (can && (p->tune == 10 || (fulln && p->tune != 11 && M >= 16384 && (M % 128) == 0))) { *cfg = 128320; return; }
+  }
   if (p->act == MGLD_ACT_GEGLU) { *cfg = (t128 >= 256 || M <= 64) ? 128128 : 64128; return; }
   if (N <= 32) { *cfg = 128032; return; }
   if (N <= 64) { *cfg = 128064; return; }
@@ -1479,6 +1504,7 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
   int bm = cfg / 1000, bn = cfg % 1000, wm, wn;
   switch (cfg) {
     case 128128: wm = 64; wn = (p->act == MGLD_ACT_GEGLU) ? 64 : 32; break;
+    case 128320: wm = 32; wn = 160; break;
     case 64128: wm = 32; wn = 64; break;
     case 128032: wm = 32; wn = 32; break;
     case 128064: wm = 64; wn = 32; break;
@@ -1533,6 +1559,9 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
     case 128128:
       if (p->act == MGLD_ACT_GEGLU) return launch_cfg<128, 128, 64, 64>(p, s, splits, kchunk);
       return launch_cfg<128, 128, 64, 32>(p, s, splits, kchunk);
+    case 128320:
+      launch_fast<MGLD_MODE_LINEAR, true, 128, 320, 32, 160, 2>(p, s, 1, kchunk);
+      return mgld_check_launch("igemm");
     case 64128: return launch_cfg<64, 128, 32, 64>(p, s, 1, kchunk);
     case 128032: return launch_cfg<128, 32, 32, 32>(p, s, 1, kchunk);
     case 128064: return launch_cfg<128, 64, 64, 32>(p, s, 1, kchunk);

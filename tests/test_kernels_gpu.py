@@ -70,6 +70,25 @@ def test_igemm_linear_ring_depth(hip, depth, M, N, K, act):
     assert torch.equal(out, base)
 
 
+@pytest.mark.parametrize("M,K,act,resid", [(32768, 320, 0, True), (16384, 1280, 3, False), (1000, 640, 0, True), (128, 960, 0, False)])
+def test_igemm_linear_full_n_tile(hip, M, K, act, resid):
+    """128 x 320 tiles (eight waves of 32 x 160, the whole N = 320 in one tile: tune = 10) against the 128 x 64 tiles (tune = 11):
+    same products per output element and the same k order -> identical bits; bias, SiLU, residual and ragged M included"""
+    N = 320
+    a, w, b = h16(rnd(M, K, seed=51)), h16(rnd(N, K, seed=52, scale=K ** -0.5)), rnd(N, seed=53)
+    r = h16(rnd(M, N, seed=54)) if resid else None
+    pre = a.float() @ w.float().t() + b
+    ref = (F.silu(pre) if act == hip.ACT_SILU else pre) + (r.float() if resid else 0)
+    outs = []
+    for tune in (10, 11):
+        out = torch.full((M, N), float("nan"), dtype=torch.half, device=DEV)
+        hip.igemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV), act=act, resid=None if r is None else r.to(DEV), tune=tune)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert rel_l2(outs[0].cpu().float(), ref) < 1e-3
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 1280, 11520), (2048, 640, 5760), (300, 200, 2048), (64, 1280, 23040),
                                    (2048, 1280, 5120), (1000, 384, 4096)])
 def test_igemm_splitk(hip, M, N, K):
