@@ -44,6 +44,9 @@ def main():
             sk = torch.randn(frames * rows, C, device=dev).half()
             t_p = timeit(lambda: hip.spade_apply(x, gs, 1e-5, g, b, gb, sk, y, frames, rows, 32), e0, e1)
             line += f"   spade {t_p:8.2f} us {5 * mb / t_p * 1e-3:6.2f} TB/s"
+        if hip.gn_fused_applies(rows, C, 32):
+            t_f = timeit(lambda: hip.gn_fused(x, 1e-5, g, b, y, frames, rows, 32, 1), e0, e1)
+            line += f"   fused {t_f:8.2f} us {2 * mb / t_f * 1e-3:6.2f} TB/s"
         print(line)
 
 
