@@ -480,7 +480,9 @@ def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
     assert record("e2e_full_latent", rel_l2(lat, x0)) < 1.3e-3
-    record("e2e_full_decoder_only", rel_l2(vq.decode(x0.cuda() / 0.18215, [f.cuda() for f in fea]), dec))
+    # the full-width video decoder alone, fed the ORACLE's latents and encoder features (measured 1.67e-3: the fp16-operand floor of
+    # a single network evaluation; the frames below meet the 1e-3 bar because AdaIN renormalises per plane)
+    assert record("e2e_full_decoder_only", rel_l2(vq.decode(x0.cuda() / 0.18215, [f.cuda() for f in fea]), dec)) < 2.2e-3
     assert record("e2e_full_frames", rel_l2(out, ref)) < 1e-3      # north_star: outputs within 1e-3 rel-L2 (measured 9.5e-4)
 
 
