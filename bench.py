@@ -48,6 +48,12 @@ def parse():
     ap.add_argument("--tile-shard", action="store_true",
                     help="N>1 with --tile: split the latent tiles of ONE segment's aggregation sampling over the ranks (one all-gather "
                          "of the tiles' eps per step; BASELINE configs[3]) instead of one segment per rank")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="segments kept in flight on ONE GPU (one host thread + stream + pipeline instance each).  1 = the reference's "
+                         "one-segment-at-a-time loop.  With 2-3 in flight one segment's kernels fill the tile-quantisation tails and the "
+                         "latency-bound stretches of the others: same result per segment (tested bit for bit), higher frames/s, "
+                         "proportionally longer per-segment latency.  0 (default) = 3 up to 8 x 512^2 frames per segment, 2 up to twice "
+                         "that, else 1 (arena memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
@@ -335,14 +341,64 @@ def main():
             kw["flows"], kw["masks"] = pipe.estimate_flows(frames)
         return pipe.run_segment(frames, **kw)
 
-    for _ in range(args.warmup):
-        step()
-    parallel.barrier()                       # barrier + torch.cuda.synchronize() on both sides of the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    parallel.barrier()
-    dt = parallel.max_over_ranks(time.perf_counter() - t0)
+    if args.inflight > 0:
+        inflight = args.inflight
+    else:
+        px = args.frames * args.size * args.size
+        inflight = 3 if px <= 8 * 512 * 512 else (2 if px <= 16 * 512 * 512 else 1)
+    if shard is not None:
+        inflight = 1                          # the sharded modes spread ONE segment over the ranks
+    inflight = max(1, min(inflight, args.steps))
+    if inflight > 1:
+        # K segments as `inflight` concurrent streams of K / inflight segments: every worker thread owns a pipeline instance (its own
+        # engine, arena, hipGraph), a stream and a split-K scratch (the library keeps that per host thread); weights are the same
+        # synthetic ones in every instance, every segment's result is what the one-at-a-time loop produces
+        import threading
+        from mgld_vsr_amd import hip as _hip
+        pipes = [pipe] + [build_pipeline(args) for _ in range(inflight - 1)]
+        ins = [(frames, noise, flows, masks)] + [make_inputs(pipes[i], args, rank * inflight + i) for i in range(1, inflight)]
+        streams = [torch.cuda.Stream() for _ in range(inflight)]
+        outs, errs = [None] * inflight, []
+
+        def worker(i, n):
+            try:
+                torch.cuda.set_device(local)
+                with torch.cuda.stream(streams[i]):
+                    _hip.ensure_workspace()
+                    f_, n_, fl_, mk_ = ins[i]
+                    for _ in range(n):
+                        outs[i] = pipes[i].run_segment(f_, flows=fl_, masks=mk_, noise=n_, tile=TILE, use_graph=GRAPH)
+                streams[i].synchronize()
+            except BaseException as e:   # noqa: BLE001  (re-raised on the main thread)
+                errs.append(e)
+
+        def run_all(counts):
+            th = [threading.Thread(target=worker, args=(i, c)) for i, c in enumerate(counts) if c > 0]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+
+        for i in range(inflight):                 # warm-up one instance at a time (fills caches, sets kernel attributes)
+            run_all([args.warmup if j == i else 0 for j in range(inflight)])
+        counts = [args.steps // inflight + (1 if i < args.steps % inflight else 0) for i in range(inflight)]
+        parallel.barrier()
+        t0 = time.perf_counter()
+        run_all(counts)
+        parallel.barrier()
+        dt = parallel.max_over_ranks(time.perf_counter() - t0)
+        out = torch.cat([o.float().reshape(-1)[:1024] for o in outs if o is not None])
+    else:
+        for _ in range(args.warmup):
+            step()
+        parallel.barrier()                       # barrier + torch.cuda.synchronize() on both sides of the timed region
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        parallel.barrier()
+        dt = parallel.max_over_ranks(time.perf_counter() - t0)
     ok = bool(torch.isfinite(out).all())
     ms_per_step = 1e3 * dt / args.steps
     segs = 1 if shard is not None else world
@@ -357,10 +413,13 @@ def main():
                                + ("one segment, frames sharded over the GPUs" if shard is not None else "one segment per GPU"),
                    "frames_per_segment": args.frames,
                    "parallelism": (f"tile-sharded x{world}" if args.tile_shard and shard is not None else f"frame-sharded x{world}")
-                   if shard is not None else f"segment-parallel x{world}", "finite": ok,
+                   if shard is not None else f"segment-parallel x{world}" + (f", {inflight} segments in flight per GPU" if inflight > 1 else ""),
+                   "finite": ok,
                    "reduced_width": bool(args.small),
                    # how a sampling step is launched: one hipGraph, or (sharded modes) graph pieces around the collectives
-                   "graphs_per_step": int(getattr(pipe.model, "last_graph_pieces", 0))},
+                   "graphs_per_step": int(getattr(pipe.model, "last_graph_pieces", 0)),
+                   "segments_in_flight": inflight,
+                   "segment_latency_ms": round(ms_per_step * inflight, 1)},
         "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
                                                           GFLOP_DEC_PER_FRAME) / 1e3 / (dt / args.steps), 1),
     }

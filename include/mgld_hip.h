@@ -121,7 +121,8 @@ int mgld_igemm_config(const MgldIGemm* p);
 int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen);
 /* fp32 scratch for split-K partial sums (few output tiles, deep K: the 16x16 / 8x8 UNet levels).  Caller-owned device
  * memory, must stay valid while launches that may use it are in flight / captured; single-stream use.  Without it the
- * launcher falls back to smaller tiles. */
+ * launcher falls back to smaller tiles.  The registration is per calling host thread (one thread drives one stream): threads that
+ * launch concurrently on different streams register different buffers. */
 int mgld_set_workspace(void* ptr, int64_t bytes);
 
 /* ---- K3: GroupNorm (32 groups) on NHWC fp16, fp32 statistics -----------------------------------------------

@@ -1150,8 +1150,10 @@ int num_cus() {
   return v;
 }
 
-float* g_ws = nullptr;     // split-K workspace (set by mgld_set_workspace; single-stream use)
-size_t g_ws_bytes = 0;
+// split-K workspace (mgld_set_workspace).  Per HOST THREAD: a thread drives one stream, so two threads that keep two segments in flight
+// on one GPU (bench.py --inflight 2) each register their own scratch and their concurrent launches never share slabs.
+thread_local float* g_ws = nullptr;
+thread_local size_t g_ws_bytes = 0;
 
 // XCD-aware tile order of igemm_kernel (see the kernel): 0 = dispatch order, 1 = A-sharing blocks on one XCD, 2 = W-sharing blocks
 // on one XCD.  env MGLD_IGEMM_ORDER = 0 / 1 / 2 forces (A/B runs); default: by which operand is re-fetched more.

@@ -5,6 +5,7 @@ and dtype bookkeeping.  Every compute call goes through the C ABI; if the librar
 this module's `lib()` fails loudly — there is no eager/CPU fallback on the product path.
 """
 import ctypes as C
+import threading
 import os
 
 import torch
@@ -118,6 +119,8 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
           M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0):
     """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h)."""
     _req_cuda(a, w, out)
+    if not getattr(_TLS, "touched", False):
+        ensure_workspace()          # a thread other than the one that built the Engine: give it its own split-K scratch
     p = MgldIGemm()
     p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
@@ -210,21 +213,22 @@ def igemm_kernel_name(p):
     return buf.value.decode(), splits
 
 
+_TLS = threading.local()     # the library keeps the split-K scratch per host thread; so does this mirror
+
+
 def set_workspace(t):
-    """register a device uint8/float tensor as the split-K scratch (the caller keeps it alive); None unregisters"""
+    """register a device uint8/float tensor as the calling thread's split-K scratch (the caller keeps it alive); None unregisters"""
     _chk(lib().mgld_set_workspace(_p(t), C.c_int64(t.numel() * t.element_size() if t is not None else 0)), "set_workspace")
-
-
-_WORKSPACE = None
+    _TLS.touched = True
 
 
 def ensure_workspace(nbytes=256 << 20):
-    """process-lifetime split-K scratch (one per process: the library holds a single pointer)"""
-    global _WORKSPACE
-    if _WORKSPACE is None or _WORKSPACE.numel() < nbytes:
-        _WORKSPACE = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    set_workspace(_WORKSPACE)
-    return _WORKSPACE
+    """thread-lifetime split-K scratch: one per host thread (a thread drives one stream; concurrent streams must not share slabs)"""
+    ws = getattr(_TLS, "ws", None)
+    if ws is None or ws.numel() < nbytes:
+        ws = _TLS.ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    set_workspace(ws)
+    return ws
 
 
 def igemm_flops(p):

@@ -179,22 +179,26 @@ def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
 
 
 @pytest.mark.gpu
-def test_bench_json_line_contract():
+@pytest.mark.parametrize("steps", [1, 4])
+def test_bench_json_line_contract(steps):
     """bench.py prints exactly ONE JSON line with the driver's keys, the roofline object of the dominant kernel and (when
-    asked) the CPU baseline; run here on the reduced-width nets (a plumbing check — `config.reduced_width` says so)."""
+    asked) the CPU baseline; run here on the reduced-width nets (a plumbing check — `config.reduced_width` says so).  steps = 1 is
+    the one-segment-at-a-time loop, steps = 4 the default scheduling: up to three segments in flight on the GPU (threads + streams)."""
     import json
     env = dict(os.environ, PYTHONPATH=ROOT)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--frames", "2", "--size", "128", "--ddpm-steps", "3",
-           "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+           "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
+    assert d["config"]["segments_in_flight"] == min(3, steps)
+    assert abs(d["config"]["segment_latency_ms"] - d["ms_per_step"] * min(3, steps)) < 0.2
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["dtype"] == "f16" and d["data"] == "synthetic" and d["value"] > 0
     assert d["config"]["finite"] is True and d["config"]["reduced_width"] is True and "workload" in d["config"]
     rf = d["roofline"]

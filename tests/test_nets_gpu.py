@@ -573,3 +573,45 @@ def test_text_tower_vs_oracle(hip):
     assert record("text_tower", rel_l2(out, ref)) < 1e-3
     with pytest.raises(NotImplementedError):
         emb(["a photo"])
+
+
+def test_two_segments_in_flight_match_sequential(hip):
+    """bench.py --inflight 2: two pipeline instances driven by two host threads on two streams of ONE GPU (each thread with its own
+    split-K scratch: the library keeps it per host thread) must each produce exactly what they produce alone — concurrent launches
+    share no scratch, no arena, no graph."""
+    import threading
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    Tn, S, H, h = 2, 3, 128, 16
+    cfgs = model_configs(Tn, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                         struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                         vae_overrides=dict(ch=32, resolution=H), context_dim=64)
+    pipes = [VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=cfgs) for _ in range(2)]
+    ins = []
+    for i in range(2):
+        x = synth.synth_tensor(f"inflight/x{i}", (Tn, 3, H, H), 0.5).clamp(-1, 1)
+        noise = {"posterior": synth.synth_tensor(f"inflight/np{i}", (Tn, 4, h, h)), "x_T": synth.synth_tensor(f"inflight/n0{i}", (Tn, 4, h, h)),
+                 "steps": torch.stack([synth.synth_tensor(f"inflight/n{i}_{k}", (Tn, 4, h, h)) for k in range(S)])}
+        ins.append((x, noise))
+    alone = [pipes[i].run_segment(ins[i][0], noise=ins[i][1]).clone() for i in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs, errs = [None, None], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                hip.ensure_workspace()
+                for _ in range(3):
+                    outs[i] = pipes[i].run_segment(ins[i][0], noise=ins[i][1])
+            streams[i].synchronize()
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(outs[i], alone[i])
+    hip.set_workspace(hip._test_ws)
