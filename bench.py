@@ -346,50 +346,26 @@ def main():
     else:
         px = args.frames * args.size * args.size
         inflight = 3 if px <= 8 * 512 * 512 else (2 if px <= 16 * 512 * 512 else 1)
-    if shard is not None:
-        inflight = 1                          # the sharded modes spread ONE segment over the ranks
+    if shard is not None or (args.raft and args.guidance):
+        inflight = 1                          # the sharded modes spread ONE segment over the ranks; --raft estimates flows inside step()
     inflight = max(1, min(inflight, args.steps))
     if inflight > 1:
         # K segments as `inflight` concurrent streams of K / inflight segments: every worker thread owns a pipeline instance (its own
         # engine, arena, hipGraph), a stream and a split-K scratch (the library keeps that per host thread); weights are the same
         # synthetic ones in every instance, every segment's result is what the one-at-a-time loop produces
-        import threading
-        from mgld_vsr_amd import hip as _hip
-        pipes = [pipe] + [build_pipeline(args) for _ in range(inflight - 1)]
-        ins = [(frames, noise, flows, masks)] + [make_inputs(pipes[i], args, rank * inflight + i) for i in range(1, inflight)]
-        streams = [torch.cuda.Stream() for _ in range(inflight)]
-        outs, errs = [None] * inflight, []
-
-        def worker(i, n):
-            try:
-                torch.cuda.set_device(local)
-                with torch.cuda.stream(streams[i]):
-                    _hip.ensure_workspace()
-                    f_, n_, fl_, mk_ = ins[i]
-                    for _ in range(n):
-                        outs[i] = pipes[i].run_segment(f_, flows=fl_, masks=mk_, noise=n_, tile=TILE, use_graph=GRAPH)
-                streams[i].synchronize()
-            except BaseException as e:   # noqa: BLE001  (re-raised on the main thread)
-                errs.append(e)
-
-        def run_all(counts):
-            th = [threading.Thread(target=worker, args=(i, c)) for i, c in enumerate(counts) if c > 0]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            if errs:
-                raise errs[0]
-
-        for i in range(inflight):                 # warm-up one instance at a time (fills caches, sets kernel attributes)
-            run_all([args.warmup if j == i else 0 for j in range(inflight)])
-        counts = [args.steps // inflight + (1 if i < args.steps % inflight else 0) for i in range(inflight)]
+        from mgld_vsr_amd.pipeline import SegmentPool
+        pool = SegmentPool(lambda: build_pipeline(args), inflight, first=pipe)
+        ins = [(frames, noise, flows, masks)] + [make_inputs(pool.pipes[i], args, rank * inflight + i) for i in range(1, inflight)]
+        jobs = [((ins[j % inflight][0],), dict(flows=ins[j % inflight][2], masks=ins[j % inflight][3], noise=ins[j % inflight][1],
+                                               tile=TILE, use_graph=GRAPH)) for j in range(args.steps)]
+        for i in range(inflight):                 # warm-up one instance at a time, on ITS inputs
+            pool._drive([[(w, *jobs[i]) for w in range(args.warmup)] if j == i else [] for j in range(inflight)])
         parallel.barrier()
         t0 = time.perf_counter()
-        run_all(counts)
+        outs = pool.run(jobs)
         parallel.barrier()
         dt = parallel.max_over_ranks(time.perf_counter() - t0)
-        out = torch.cat([o.float().reshape(-1)[:1024] for o in outs if o is not None])
+        out = torch.cat([o.float().reshape(-1)[:1024] for o in outs[-inflight:]])
     else:
         for _ in range(args.warmup):
             step()

@@ -579,7 +579,6 @@ def test_two_segments_in_flight_match_sequential(hip):
     """bench.py --inflight 2: two pipeline instances driven by two host threads on two streams of ONE GPU (each thread with its own
     split-K scratch: the library keeps it per host thread) must each produce exactly what they produce alone — concurrent launches
     share no scratch, no arena, no graph."""
-    import threading
     from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
     Tn, S, H, h = 2, 3, 128, 16
     cfgs = model_configs(Tn, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
@@ -593,25 +592,12 @@ def test_two_segments_in_flight_match_sequential(hip):
                  "steps": torch.stack([synth.synth_tensor(f"inflight/n{i}_{k}", (Tn, 4, h, h)) for k in range(S)])}
         ins.append((x, noise))
     alone = [pipes[i].run_segment(ins[i][0], noise=ins[i][1]).clone() for i in range(2)]
-    streams = [torch.cuda.Stream() for _ in range(2)]
-    outs, errs = [None, None], []
-
-    def worker(i):
-        try:
-            with torch.cuda.stream(streams[i]):
-                hip.ensure_workspace()
-                for _ in range(3):
-                    outs[i] = pipes[i].run_segment(ins[i][0], noise=ins[i][1])
-            streams[i].synchronize()
-        except BaseException as e:  # noqa: BLE001
-            errs.append(e)
-
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert not errs, errs
+    from mgld_vsr_amd.pipeline import SegmentPool
+    it = iter(pipes)
+    pool = SegmentPool(lambda: next(it), 2)
+    outs = pool.run([((ins[j % 2][0],), dict(noise=ins[j % 2][1])) for j in range(6)])     # three segments per instance, concurrently
+    for j in range(6):
+        assert torch.equal(outs[j], alone[j % 2])
     for i in range(2):
         assert torch.equal(outs[i], alone[i])
     hip.set_workspace(hip._test_ws)
