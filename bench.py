@@ -359,7 +359,7 @@ def main():
         jobs = [((ins[j % inflight][0],), dict(flows=ins[j % inflight][2], masks=ins[j % inflight][3], noise=ins[j % inflight][1],
                                                tile=TILE, use_graph=GRAPH)) for j in range(args.steps)]
         for i in range(inflight):                 # warm-up one instance at a time, on ITS inputs
-            pool._drive([[(w, *jobs[i]) for w in range(args.warmup)] if j == i else [] for j in range(inflight)])
+            pool.run_on(i, [jobs[i]] * args.warmup)
         parallel.barrier()
         t0 = time.perf_counter()
         outs = pool.run(jobs)

@@ -64,6 +64,10 @@ def parse(argv, w_latent):
     p.add_argument("--input_size", type=int, default=512)
     p.add_argument("--dec_w", type=float, default=0.5)
     p.add_argument("--colorfix_type", type=str, default="nofix")
+    p.add_argument("--inflight", type=int, default=1,
+                   help="(extension) segments kept in flight on the GPU (pipeline.SegmentPool: one model instance + host thread + stream "
+                        "each; 2-3 give ~+20 %% frames/s).  The noise of every segment is drawn on the main thread in segment order, "
+                        "so the output does not depend on this option")
     opt = p.parse_args(argv)
     if opt.C != 4 or opt.f != 8:
         p.error("--C / --f: the SD-2.1 latent space of this path is 4 channels at 1/8 resolution")
@@ -102,17 +106,68 @@ def main(argv=None, w_latent=False):
         v["params"].pop("ckpt_path", None)
         v["params"]["lossconfig"] = {"target": "torch.nn.Identity"}
         cfgs = (cfgs[0], v)
-    pipe = VSRPipeline(num_frames=opt.n_frames, ddpm_steps=opt.ddpm_steps, dec_w=opt.dec_w, colorfix_type=opt.colorfix_type,
-                       synthetic_weights=opt.ckpt is None, configs=cfgs)
-    if opt.ckpt:
-        pipe.load_checkpoint(opt.ckpt)
-    if opt.vqgan_ckpt:
-        pipe.vq_model.init_from_ckpt(opt.vqgan_ckpt)
+    def make_pipe():
+        pp = VSRPipeline(num_frames=opt.n_frames, ddpm_steps=opt.ddpm_steps, dec_w=opt.dec_w, colorfix_type=opt.colorfix_type,
+                         synthetic_weights=opt.ckpt is None, configs=cfgs)
+        if opt.ckpt:
+            pp.load_checkpoint(opt.ckpt)
+        if opt.vqgan_ckpt:
+            pp.vq_model.init_from_ckpt(opt.vqgan_ckpt)
+        return pp
+
+    pipe = make_pipe()
     os.makedirs(opt.outdir, exist_ok=True)
+    from . import preproc
     from .preproc import FrameWriter
     writer = FrameWriter()
     gscale = -1.0 if w_latent else -10.0
-    eng = pipe.engine()
+    h8 = opt.input_size // 8
+
+    def segment_job(pp, item):
+        """one segment on pipeline instance `pp` (the calling thread's current stream): decode -> resize/crop -> flows -> sample -> payload"""
+        seq, seg_names, nz = item
+        dev = pp.engine().device
+        frames = []
+        for f in seg_names:
+            img = load_img(os.path.join(opt.seqs_path, seq, f)).to(dev)
+            frames.append(torch.clamp(hip.resize_center_crop(img, opt.input_size), -1.0, 1.0))
+        x = torch.cat(frames, 0)                                                       # [T,3,S,S] in [-1,1]
+        x01 = torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0)
+        f0, f1 = pp.model.compute_flow(x01[None])                                      # full-resolution flows (:342-344)
+        f0, f1 = resize_flow(f0[0], "ratio", (0.125, 0.125)), resize_flow(f1[0], "ratio", (0.125, 0.125))
+        fwd, bwd = (f1, f0) if w_latent else (f0, f1)                                  # (:354) vs w_latent (:360)
+        fo, bo = forward_backward_consistency_check(fwd, bwd)
+        flows, masks = (f0[None], f1[None]), (fo[None, :, None], bo[None, :, None])
+        out, lat = pp.run_segment(x, flows=flows, masks=masks, guidance_scale=gscale, noise=nz, return_latents=True, init_from_vq=True)
+        cap = {"flows": flows, "masks": masks, "x0": lat, "frames": x} if CAPTURE is not None else None
+        arrs = preproc.to_png_payload(out, opt.input_size, opt.input_size)
+        return arrs, (lat.cpu().numpy() if w_latent else None), cap
+
+    def emit(item, res):
+        seq, seg_names, _ = item
+        arrs, lat_np, cap = res
+        if cap is not None:
+            CAPTURE.append(cap)
+        for k, f in enumerate(seg_names):
+            base = os.path.splitext(os.path.basename(f))[0]
+            writer.png(os.path.join(opt.outdir, seq, base + ".png"), arrs[k])           # encoded off this thread
+            if w_latent:
+                writer.npy(os.path.join(opt.latent_dir, seq, base + ".npy"), lat_np[k])
+
+    pool = None
+    if opt.inflight > 1:
+        from .pipeline import SegmentPool
+        pool = SegmentPool(make_pipe, opt.inflight, first=pipe)
+    pending = []
+
+    def flush():
+        if not pending:
+            return
+        results = pool.map(segment_job, pending) if pool is not None else [segment_job(pipe, it) for it in pending]
+        for it, res in zip(pending, results):
+            emit(it, res)
+        pending.clear()
+
     for seq_idx, seq in enumerate(sorted(os.listdir(opt.seqs_path))):
         if seq_idx % opt.n_gpus != opt.select_idx:                     # process-level sharding (:302-303)
             continue
@@ -126,31 +181,13 @@ def main(argv=None, w_latent=False):
             os.makedirs(os.path.join(opt.latent_dir, seq), exist_ok=True)
         for n in range(n_seg):
             seg_names = names[n * opt.n_frames:(n + 1) * opt.n_frames]
-            frames = []
-            for f in seg_names:
-                img = load_img(os.path.join(opt.seqs_path, seq, f)).to(eng.device)
-                frames.append(torch.clamp(hip.resize_center_crop(img, opt.input_size), -1.0, 1.0))
-            x = torch.cat(frames, 0)                                                       # [T,3,S,S] in [-1,1]
-            x01 = torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0)
-            f0, f1 = pipe.model.compute_flow(x01[None])                                    # full-resolution flows (:342-344)
-            h8 = opt.input_size // 8
-            f0, f1 = resize_flow(f0[0], "ratio", (0.125, 0.125)), resize_flow(f1[0], "ratio", (0.125, 0.125))
-            fwd, bwd = (f1, f0) if w_latent else (f0, f1)                                  # (:354) vs w_latent (:360)
-            fo, bo = forward_backward_consistency_check(fwd, bwd)
-            flows, masks = (f0[None], f1[None]), (fo[None, :, None], bo[None, :, None])
-            nz = NOISE_HOOK(x.shape[0], h8, h8, opt.ddpm_steps) if NOISE_HOOK is not None else None
-            out, lat = pipe.run_segment(x, flows=flows, masks=masks, guidance_scale=gscale, noise=nz, return_latents=True,
-                                        init_from_vq=True)
-            if CAPTURE is not None:
-                CAPTURE.append({"flows": flows, "masks": masks, "x0": lat, "frames": x})
-            from . import preproc
-            arrs = preproc.to_png_payload(out, opt.input_size, opt.input_size)
-            lat_np = lat.cpu().numpy() if w_latent else None
-            for k, f in enumerate(seg_names):
-                base = os.path.splitext(os.path.basename(f))[0]
-                writer.png(os.path.join(opt.outdir, seq, base + ".png"), arrs[k])       # encoded off this thread
-                if w_latent:
-                    writer.npy(os.path.join(opt.latent_dir, seq, base + ".npy"), lat_np[k])
+            # the segment's noise, drawn HERE in segment order (the draws run_segment would make itself, same generators): what a
+            # segment gets does not depend on how many are in flight
+            nz = NOISE_HOOK(len(seg_names), h8, h8, opt.ddpm_steps) if NOISE_HOOK is not None else pipe.draw_noise(len(seg_names), h8, h8)
+            pending.append((seq, seg_names, nz))
+            if len(pending) >= max(1, opt.inflight) * (4 if pool is not None else 1):
+                flush()
+    flush()
     writer.close()
     return 0
 

@@ -174,6 +174,16 @@ class VSRPipeline:
             eng.shard = None
             eng.tile_shard = None
 
+    def draw_noise(self, T, h, w):
+        """the three draws run_segment makes when no noise is injected — posterior sample (host generator, as
+        DiagonalGaussianDistribution.sample does), x_T (device generator, `randn_like(init_latent)`), the per-step noise (device) — in
+        that order and from the same generators, as a dict for `run_segment(noise=...)`.  A harness that keeps several segments in
+        flight (SegmentPool) draws them HERE, on its own thread, segment by segment: the results then match the one-at-a-time loop."""
+        dev = self.engine().device
+        shape = (int(T), 4, int(h), int(w))
+        post = torch.randn(shape)
+        return {"posterior": post, "x_T": torch.randn(shape, device=dev), "steps": torch.randn((self.ddpm_steps,) + shape, device=dev)}
+
     def _run_segment(self, eng, frames, flows, masks, guidance_scale, noise, tile, use_graph, return_latents, shard, gather,
                      clamp01=True, init_from_vq=False, tile_shard=None):
         m, vq = self.model, self.vq_model
@@ -279,17 +289,20 @@ class SegmentPool:
         return len(self.pipes)
 
     def _drive(self, plan):
-        """plan[i] = list of (slot, args, kwargs) for worker i; returns {slot: result}"""
+        """plan[i] = list of (slot, call) for worker i, call(pipeline instance) -> result; returns {slot: result}"""
         from . import hip
         out, errs = {}, []
+        ready = torch.cuda.Event()
+        ready.record()                     # whatever the caller enqueued for the jobs (inputs, pre-drawn noise) on ITS stream ...
 
         def worker(i):
             try:
                 torch.cuda.set_device(self.device)
+                self.streams[i].wait_event(ready)                # ... is complete before a worker stream touches it
                 with torch.cuda.stream(self.streams[i]):
                     hip.ensure_workspace()                       # this thread's split-K scratch
-                    for slot, a, kw in plan[i]:
-                        out[slot] = self.pipes[i].run_segment(*a, **kw)
+                    for slot, call in plan[i]:
+                        out[slot] = call(self.pipes[i])
                 self.streams[i].synchronize()
             except BaseException as e:   # noqa: BLE001  (re-raised on the calling thread)
                 errs.append(e)
@@ -303,14 +316,22 @@ class SegmentPool:
             raise errs[0]
         return out
 
-    def warmup(self, job, n=1):
-        """run `job` n times on every instance, one instance at a time (fills weight caches, sets kernel attributes)"""
+    @staticmethod
+    def _seg(job):
         a, kw = job
-        for i in range(len(self.pipes)):
-            self._drive([[(j, a, kw) for j in range(n)] if w == i else [] for w in range(len(self.pipes))])
+        return lambda pipe: pipe.run_segment(*a, **kw)
+
+    def run_on(self, i, jobs):
+        """jobs (args, kwargs of run_segment) on instance i only, in order (warm-up: fills that instance's caches)"""
+        res = self._drive([[(j, self._seg(job)) for j, job in enumerate(jobs)] if w == i else [] for w in range(len(self.pipes))])
+        return [res[j] for j in range(len(jobs))]
+
+    def map(self, fn, items):
+        """results[j] = fn(pipeline instance, items[j]); item j on instance j % k, every instance on its own thread + stream"""
+        k = len(self.pipes)
+        res = self._drive([[(j, (lambda pipe, it=it: fn(pipe, it))) for j, it in enumerate(items) if j % k == i] for i in range(k)])
+        return [res[j] for j in range(len(items))]
 
     def run(self, jobs):
-        """jobs[j] -> results[j]; job j runs on instance j % k (static round-robin: equal segments need no work queue)"""
-        k = len(self.pipes)
-        res = self._drive([[(j, a, kw) for j, (a, kw) in enumerate(jobs) if j % k == i] for i in range(k)])
-        return [res[j] for j in range(len(jobs))]
+        """jobs[j] = (args, kwargs) of run_segment -> results[j]; static round-robin (equal segments need no work queue)"""
+        return self.map(lambda pipe, job: pipe.run_segment(*job[0], **job[1]), jobs)

@@ -205,3 +205,43 @@ def test_bench_json_line_contract(steps):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_fixed_size_cli_output_does_not_depend_on_segments_in_flight(tmp_path):
+    """`--inflight 2` (pipeline.SegmentPool: two model instances, threads, streams) writes the same PNGs and latents as the
+    one-segment-at-a-time loop: every segment's noise is drawn on the main thread in segment order (VSRPipeline.draw_noise: the
+    draws run_segment makes itself, same generators), so the seed alone fixes the output.  Two sequences x two segments."""
+    import yaml
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL
+    from mgld_vsr_amd import cli_simple
+    from mgld_vsr_amd.pipeline import model_configs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g_harness_old.npz"))
+    for s_ in range(2):
+        seq = tmp_path / "in" / f"seq{s_}"
+        seq.mkdir(parents=True)
+        for k in range(6):
+            Image.fromarray(np.roll(g["lr_u8"][k], 7 * s_, axis=1)).save(seq / f"{k:04d}.png")
+    dcfg, vcfg = model_configs(T, unet_overrides={k: v for k, v in UNET_SMALL.items() if k != "num_frames"},
+                               struct_overrides={k: v for k, v in STRUCT_SMALL.items() if k != "num_frames"},
+                               vae_overrides=dict(ch=VAE_DD_SMALL["ch"], resolution=128), context_dim=UNET_SMALL["context_dim"])
+    for name, cfg in (("diffusion.yaml", dcfg), ("vae.yaml", vcfg)):
+        with open(tmp_path / name, "w") as fh:
+            yaml.safe_dump({"model": cfg}, fh)
+    outs = {}
+    for k in (1, 2):
+        argv = ["--seqs-path", str(tmp_path / "in"), "--outdir", str(tmp_path / f"out{k}"), "--latent-dir", str(tmp_path / f"lat{k}"),
+                "--ddpm_steps", "3", "--n_frames", str(T), "--config", str(tmp_path / "diffusion.yaml"), "--vqgan_config",
+                str(tmp_path / "vae.yaml"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type", "adain", "--input_size", "128",
+                "--inflight", str(k)]
+        cli_simple.main(argv, w_latent=True)
+        outs[k] = {(s_, f): np.asarray(Image.open(tmp_path / f"out{k}" / s_ / f)) for s_ in ("seq0", "seq1")
+                   for f in sorted(os.listdir(tmp_path / f"out{k}" / s_))}
+        outs[k].update({(s_, f): np.load(tmp_path / f"lat{k}" / s_ / f) for s_ in ("seq0", "seq1") for f in sorted(os.listdir(tmp_path / f"lat{k}" / s_))})
+    assert len(outs[1]) == 24 and outs[1].keys() == outs[2].keys()
+    for key in outs[1]:
+        assert np.array_equal(outs[1][key], outs[2][key]), key
+    a, b = outs[1][("seq0", "0000.png")].astype(np.int32), outs[1][("seq1", "0000.png")].astype(np.int32)
+    assert np.abs(a - b).mean() > 1.0            # (the two sequences are different inputs)
