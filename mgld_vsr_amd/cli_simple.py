@@ -157,7 +157,10 @@ def main(argv=None, w_latent=False):
     pool = None
     if opt.inflight > 1:
         from .pipeline import SegmentPool
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state()
         pool = SegmentPool(make_pipe, opt.inflight, first=pipe)
+        torch.set_rng_state(rng_cpu)          # building the extra instances draws from the global generators (module initialisers):
+        torch.cuda.set_rng_state(rng_dev)     # put them back, so that the segments' noise does not depend on --inflight
     pending = []
 
     def flush():
