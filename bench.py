@@ -312,6 +312,8 @@ def main():
             dist.destroy_process_group()
         return
     rank, world, local = dist_setup(args.gpus, args.backend)
+    if world > 1:      # N ranks build their (synthetic) weights at the same time: share the host cores instead of oversubscribing them
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local)
