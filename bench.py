@@ -388,7 +388,8 @@ def main():
         "config": {"workload": f"{args.frames}-frame {args.size}x{args.size} sequence (latent {args.size // 8}x{args.size // 8}x4), "
                                f"{args.ddpm_steps} DDPM steps, random-init SD-2.1 UNet + struct-cond encoder + KL-VAE encode x2 "
                                f"+ temporal video decoder + AdaIN, flow-guided warp {'on' if args.guidance else 'off'}{', aggregation sampling 64/32' if args.tile else ''}; "
-                               + ("one segment, frames sharded over the GPUs" if shard is not None else "one segment per GPU"),
+                               + ("one segment, frames sharded over the GPUs" if shard is not None else
+                                  ("one segment per GPU at a time" if inflight == 1 else f"independent segments, {inflight} in flight per GPU")),
                    "frames_per_segment": args.frames,
                    "parallelism": (f"tile-sharded x{world}" if args.tile_shard and shard is not None else f"frame-sharded x{world}")
                    if shard is not None else f"segment-parallel x{world}" + (f", {inflight} segments in flight per GPU" if inflight > 1 else ""),
