@@ -145,15 +145,19 @@ def _pmc_traffic(kernel):
     the file is only used when it was taken for THIS kernel name on THIS kernel source (sha256 of csrc/igemm.hip), else null."""
     import hashlib
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
-            pm = json.load(fh)
         with open(os.path.join(ROOT, "mgld_vsr_amd", "csrc", "igemm.hip"), "rb") as fh:
             sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                pm = json.load(fh)
+        except (OSError, ValueError):
+            continue
         ent = pm.get("kernels", {}).get(kernel)
         if ent and pm.get("igemm_hip_sha16") == sha:
             return round(ent["hbm_bytes_per_launch"])
-    except Exception:
-        pass
     return None
 
 
@@ -198,6 +202,13 @@ def roofline(pipe, args, frames, noise, flows, masks):
             g = shapes.setdefault(key, {"count": 0, "ms": 0.0, "flops": hip.igemm_flops(p)})
             g["count"] += 1
             g["ms"] += ms
+            if p.mode == 2 and p.M >= 65536:
+                # temporal Conv3d (3,1,1) of the video decoder at its 128^2..512^2 levels: K = 3*C with C = 128..512 is 128-256 FLOP/B,
+                # i.e. HBM-bound: graded on algorithmic bytes (each frame row read once, written once) over time
+                h = hbm.setdefault("tconv_vae", {"bytes": 0.0, "ms": 0.0, "launches": 0})
+                h["bytes"] += igemm_algo_bytes(p)
+                h["ms"] += ms
+                h["launches"] += 1
         elif kind == "attention":
             name = f"flash_attn_kernel<{info['d']}>"
             k = kern.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "splitk_launches": 0})
@@ -283,6 +294,8 @@ def cpu_baseline(args):
         t_dec = time.time() - t0
     per_frame = (args.ddpm_steps * t_step + 2 * t_enc + t_dec) / Tc
     return {"value": round(1.0 / per_frame, 5), "unit": "HR frames/s", "cores": cores, "kind": "port",
+            "note": "the CPU RESTATEMENT (oracle/, torch fp32 kernels) of the reference's algorithm, not the reference's own Python (which does "
+                    "not travel to the GPU box; SURVEY.md quotes 0.0041 frames/s for it on other host cores)",
             "sample": f"oracle fp32 on a {Tc}-frame {args.size}x{args.size} clip: 1 DDPM step (struct-cond+UNet) {t_step:.2f}s, "
                       f"1 VAE encode {t_enc:.2f}s, 1 VAE video-decode {t_dec:.2f}s; extrapolated to "
                       f"{args.ddpm_steps} steps + 2 encodes + 1 decode"}
@@ -366,8 +379,29 @@ def main():
         t0 = time.perf_counter()
         outs = pool.run(jobs)
         parallel.barrier()
-        dt = parallel.max_over_ranks(time.perf_counter() - t0)
+        dt_local = time.perf_counter() - t0
+        dt = parallel.max_over_ranks(dt_local)
         out = torch.cat([o.float().reshape(-1)[:1024] for o in outs[-inflight:]])
+        # MEASURED per-segment latency under this scheduling: a hipEvent pair around every segment on its worker's stream
+        lat = sorted(pool.last_latency_ms.values())
+        latency = {"median_ms": round(lat[len(lat) // 2], 1), "max_ms": round(lat[-1], 1), "min_ms": round(lat[0], 1),
+                   "how": "hipEvent pair around each segment on its own stream, all timed segments"}
+        # the OTHER scheduling, outside the contract's timed region: the same K segments one at a time on this rank's first
+        # instance (the reference's loop); reported next to `value`, never instead of it
+        parallel.barrier()
+        t1 = time.perf_counter()
+        e_lat = []
+        for j in range(args.steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            pipe.run_segment(frames, **kw)
+            b.record()
+            e_lat.append((a, b))
+        parallel.barrier()
+        dt1 = parallel.max_over_ranks(time.perf_counter() - t1)
+        l1 = sorted(a.elapsed_time(b) for a, b in e_lat)
+        one_at_a_time = {"value": round((1 if shard is not None else world) * args.frames * args.steps / dt1, 4), "ms_per_step": round(1e3 * dt1 / args.steps, 2),
+                         "segment_latency_ms": round(l1[len(l1) // 2], 1), "steps": args.steps}
     else:
         for _ in range(args.warmup):
             step()
@@ -376,8 +410,12 @@ def main():
         for _ in range(args.steps):
             out = step()
         parallel.barrier()
-        dt = parallel.max_over_ranks(time.perf_counter() - t0)
+        dt_local = time.perf_counter() - t0
+        dt = parallel.max_over_ranks(dt_local)
+        latency = {"median_ms": round(1e3 * dt / args.steps, 1), "how": "one segment at a time: wall time of the timed region / segments"}
+        one_at_a_time = None
     ok = bool(torch.isfinite(out).all())
+    per_rank_ms = parallel.gather_floats(1e3 * dt_local / args.steps) if world > 1 else [round(1e3 * dt_local / args.steps, 2)]
     ms_per_step = 1e3 * dt / args.steps
     segs = 1 if shard is not None else world
     fps = segs * args.frames * args.steps / dt
@@ -398,13 +436,19 @@ def main():
                    # how a sampling step is launched: one hipGraph, or (sharded modes) graph pieces around the collectives
                    "graphs_per_step": int(getattr(pipe.model, "last_graph_pieces", 0)),
                    "segments_in_flight": inflight,
-                   "segment_latency_ms": round(ms_per_step * inflight, 1)},
+                   "segment_latency_ms": latency["median_ms"], "segment_latency": latency,
+                   "world_size_seen": world, "backend": args.backend if world > 1 else None, "per_rank_ms_per_step": per_rank_ms},
         "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME + 2 * GFLOP_ENC_PER_FRAME +
                                                           GFLOP_DEC_PER_FRAME) / 1e3 / (dt / args.steps), 1),
     }
     # whole-segment algorithmic FLOP rate against the dense fp16 MFMA peak of the GPUs in use (the path is compute-bound:
     # ~55 TFLOP per HR frame against ~0.15 TB of algorithmic HBM traffic)
     res["sustained_frac_of_mfma_peak"] = round(res["sustained_tflops"] / (PEAK_FP16_TFLOPS * world), 4)
+    if one_at_a_time is not None:     # both schedulings in one line: `value` = the default (segments in flight), this = the reference's loop
+        res["value_one_at_a_time"] = one_at_a_time["value"]
+        res["one_at_a_time"] = one_at_a_time
+    else:
+        res["value_one_at_a_time"] = res["value"]
     if rank == 0:
         if not args.no_roofline:
             res["roofline"] = roofline(pipe, args, frames, noise, flows, masks)

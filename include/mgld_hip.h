@@ -109,6 +109,14 @@ typedef struct MgldIGemm {
                              (RAFT's 7x7, 1x5, 5x1 and strided 1x1 convolutions, raft_arch.py:216,383-389,430).         */
   int32_t tune;           /* 0 = the launcher picks the kernel variant.  > 0 (tuning runs / variant tests): force variant
                              tune - 1 of the 2-D-tile patch conv where it applies (ids: csrc/igemm.hip "conv3q launch plan"). */
+  float w2_scale;         /* see W2 */
+  const void* W2;         /* NULL, or the fp16 ROUNDING RESIDUAL of the weights in the layout / strides of W:
+                             W2 = fp16((W_fp32 - fp32(W)) / w2_scale), w2_scale a power of two (2^-11 keeps the residual in fp16's normal
+                             range).  The kernel then computes acc = w2_scale * (A W2^T) + A W^T in ONE launch (the K loop runs twice over
+                             the same A: residual pass first, accumulators scaled once, main pass): the product sees weights exact to
+                             ~2^-21 instead of 2^-11, at twice the MFMA work and no extra activation traffic beyond L2.  For the layers
+                             whose fp16 weight rounding dominates the output error.  Not with split-fp32 outputs of the
+                             raster patch kernel (conv3p).                                                                                  */
 } MgldIGemm;
 
 int mgld_igemm(const MgldIGemm* p, void* stream);
@@ -240,7 +248,8 @@ int mgld_fb_consistency(const float* fwd_flow, const float* bwd_flow, float alph
 int mgld_resize_flow(const float* flow, float* out, int n, int h, int w, int oh, int ow, void* stream);
 
 /* ---- H1/H2: colour fix (wavelet_color_fix.py:44-119) --------------------------------------------------- */
-/* out = (x-mean_x)/sqrt(var_x+eps)*sqrt(var_s+eps)+mean_s per (n,c) plane; unbiased variance; fp32 NCHW */
+/* out = (x-mean_x)/sqrt(var_x+eps)*sqrt(var_s+eps)+mean_s per (n,c) plane; unbiased variance; fp32 NCHW.
+ * work: >= 512 * planes floats, 8-byte aligned (fp64 partial sums of up to 64 chunks per plane and tensor) */
 int mgld_adain(const float* content, const float* style, float* out, int planes, int64_t hw, float eps,
                float* work, void* stream);
 /* 5-level a-trous wavelet: out = high(content) + low(style); work >= 4*planes*h*w floats */

@@ -23,41 +23,54 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _digest():
+def _file_digest(paths):
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
-                                                         os.path.join(HERE, "..", "include", "mgld_hip.h")]
-    for f in files:
+    for f in paths:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
 
+def _common():
+    return [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mgld_hip.h")]
+
+
+def _digest():
+    return _file_digest([os.path.join(CSRC, s) for s in SOURCES] + _common())
+
+
 def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into libmgld_hip.so. Returns the library path."""
+    """Compile every HIP source for gfx950 into libmgld_hip.so (objects whose source, headers and flags are unchanged are kept).
+    Returns the library path."""
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as fh:
-            if fh.read().strip() == dig:
+            if fh.read().strip().split("\n")[0] == dig:
                 return LIB
     hipcc = _hipcc()
     objs = []
     procs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        odig = _file_digest([os.path.join(CSRC, s)] + _common())
+        ostamp = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            continue
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print("[mgld build]", " ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for s, p in procs:
+        procs.append((s, ostamp, odig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, ostamp, odig, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
             raise RuntimeError(f"hipcc failed on {s}")
         elif verbose and out.strip():
             print(out.decode(errors="replace"))
+        with open(ostamp, "w") as fh:
+            fh.write(odig)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print("[mgld build]", " ".join(cmd), flush=True)

@@ -113,6 +113,12 @@ def main(argv=None, w_latent=False):
             pp.load_checkpoint(opt.ckpt)
         if opt.vqgan_ckpt:
             pp.vq_model.init_from_ckpt(opt.vqgan_ckpt)
+        elif opt.ckpt:
+            # a real diffusion checkpoint with NO video-VAE checkpoint: the VAE's parameters are still the zeros _finish_init left
+            # (synthetic_weights is off) — frames would be garbage without any error.  Refuse, as load_checkpoint refuses a
+            # synthetic text context next to real weights.
+            raise SystemExit("[mgld] --ckpt was given but no --vqgan_ckpt exists: the video VAE would run with uninitialised weights; "
+                             "pass --vqgan_ckpt (or drop --ckpt to run everything on the built-in synthetic weights)")
         return pp
 
     pipe = make_pipe()
@@ -196,4 +202,5 @@ def main(argv=None, w_latent=False):
 
 
 if __name__ == "__main__":
-    sys.exit(main(w_latent="--w-latent" in sys.argv))
+    # `python -m mgld_vsr_amd.cli_simple [--w-latent] ...`: the flag selects the _w_latent script's behaviour and is not an argparse option
+    sys.exit(main([a for a in sys.argv[1:] if a != "--w-latent"], w_latent="--w-latent" in sys.argv[1:]))

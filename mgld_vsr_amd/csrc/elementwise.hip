@@ -427,32 +427,71 @@ __global__ void resize_flow_kernel(const float* __restrict__ flow, float* __rest
   }
 }
 
-// ---- AdaIN (wavelet_color_fix.py:44-71): per-plane mean / unbiased var via fp64 two-level reduction ----------------
-// work: [2 tensors][planes][2] doubles
-__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ x, int64_t hw, double* __restrict__ st) {
+// ---- AdaIN (wavelet_color_fix.py:44-71): per-plane mean / unbiased var, fp64 sums ----------------------------------------
+// HBM-bound (12 B per element: content and style read once, output written once), so the planes are cut into chunks that fill the
+// chip: launch 1 = one block per (chunk, plane, tensor) -> fp64 partial (sum, sum of squares); launch 2 = the apply blocks finish the
+// reduction over a plane's <= 64 chunks in their prologue (no finalize launch) and stream content -> out with 16-byte accesses.
+// (Round 2 ran ONE block per plane: 24 blocks on 256 CUs, 0.013 of the HBM peak.)
+// work: [2 tensors][planes][AD_MAXCH chunks][2] doubles
+constexpr int AD_MAXCH = 64;
+constexpr int64_t AD_CHUNK = 16384;     // elements per chunk (64 KiB): 512^2 planes -> 16 chunks, 24 planes x 2 tensors -> 768 blocks
+inline int adain_chunks(int64_t hw) {
+  int64_t c = (hw + AD_CHUNK - 1) / AD_CHUNK;
+  return (int)(c < 1 ? 1 : (c > AD_MAXCH ? AD_MAXCH : c));
+}
+__global__ __launch_bounds__(256) void plane_partial_kernel(const float* __restrict__ content, const float* __restrict__ style, int64_t hw,
+                                                            int chunks, int planes, double* __restrict__ part) {
   __shared__ double rs[4], rq[4];
-  const int plane = blockIdx.x;
-  const float* p = x + (int64_t)plane * hw;
+  const int chunk = blockIdx.x, plane = blockIdx.y, tz = blockIdx.z;
+  const float* p = (tz ? style : content) + (int64_t)plane * hw;
+  const int64_t per = (((hw + chunks - 1) / chunks) + 3) & ~(int64_t)3;
+  const int64_t i0 = (int64_t)chunk * per, i1 = min(hw, i0 + per);
   double s = 0.0, q = 0.0;
-  for (int64_t i = threadIdx.x; i < hw; i += 256) { const double v = p[i]; s += v; q += v * v; }
+  if ((hw & 3) == 0 && ((((uintptr_t)p) & 15) == 0)) {        // planes start 16-byte aligned: 16-byte loads (i0 % 4 == 0, i1 % 4 == 0)
+    for (int64_t i = i0 + (int64_t)threadIdx.x * 4; i < i1; i += 1024) {
+      const f32x4 v = *(const f32x4*)(p + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const double d = v[k]; s += d; q += d * d; }
+    }
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) { const double v = p[i]; s += v; q += v * v; }
+  }
   s = wave_sum_d(s); q = wave_sum_d(q);
   if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    s = rs[0] + rs[1] + rs[2] + rs[3]; q = rq[0] + rq[1] + rq[2] + rq[3];
-    const double mean = s / (double)hw;
-    const double var = (q - s * mean) / (double)(hw - 1);  // unbiased (Tensor.var default)
-    st[plane * 2] = mean; st[plane * 2 + 1] = var;
+    double* o = part + (((int64_t)tz * planes + plane) * AD_MAXCH + chunk) * 2;
+    o[0] = rs[0] + rs[1] + rs[2] + rs[3];
+    o[1] = rq[0] + rq[1] + rq[2] + rq[3];
   }
 }
-__global__ void adain_apply_kernel(const float* __restrict__ content, const double* __restrict__ cst,
-                                   const double* __restrict__ sst, float* __restrict__ out, int planes, int64_t hw, float eps) {
-  const int64_t total = (int64_t)planes * hw;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int pl = (int)(idx / hw);
-    const float cm = (float)cst[pl * 2], cs = sqrtf((float)cst[pl * 2 + 1] + eps);
-    const float sm = (float)sst[pl * 2], ss = sqrtf((float)sst[pl * 2 + 1] + eps);
-    out[idx] = (content[idx] - cm) / cs * ss + sm;
+__global__ __launch_bounds__(256) void adain_apply_kernel(const float* __restrict__ content, const double* __restrict__ part,
+                                                          float* __restrict__ out, int planes, int64_t hw, int chunks, float eps) {
+  __shared__ float st[4];   // content mean, content std, style mean, style std
+  const int pl = blockIdx.y;
+  if (threadIdx.x < 64) {   // one wave finishes both reductions (chunks <= 64)
+    const int t = threadIdx.x;
+    const double* pc = part + ((int64_t)pl * AD_MAXCH + t) * 2;
+    const double* ps = part + (((int64_t)planes + pl) * AD_MAXCH + t) * 2;
+    double cs_ = t < chunks ? pc[0] : 0.0, cq = t < chunks ? pc[1] : 0.0, ss_ = t < chunks ? ps[0] : 0.0, sq = t < chunks ? ps[1] : 0.0;
+    cs_ = wave_sum_d(cs_); cq = wave_sum_d(cq); ss_ = wave_sum_d(ss_); sq = wave_sum_d(sq);
+    if (t == 0) {
+      const double cm = cs_ / (double)hw, cv = (cq - cs_ * cm) / (double)(hw - 1);   // unbiased (Tensor.var default)
+      const double sm = ss_ / (double)hw, sv = (sq - ss_ * sm) / (double)(hw - 1);
+      st[0] = (float)cm; st[1] = sqrtf((float)cv + eps); st[2] = (float)sm; st[3] = sqrtf((float)sv + eps);
+    }
+  }
+  __syncthreads();
+  const float cm = st[0], cs = st[1], sm = st[2], ss = st[3];
+  const float* c = content + (int64_t)pl * hw;
+  float* o = out + (int64_t)pl * hw;
+  if ((hw & 3) == 0 && (((((uintptr_t)c) | ((uintptr_t)o)) & 15) == 0)) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < hw; i += (int64_t)gridDim.x * 1024) {
+      const f32x4 v = *(const f32x4*)(c + i);
+      *(f32x4*)(o + i) = f32x4{(v[0] - cm) / cs * ss + sm, (v[1] - cm) / cs * ss + sm, (v[2] - cm) / cs * ss + sm, (v[3] - cm) / cs * ss + sm};
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) o[i] = (c[i] - cm) / cs * ss + sm;
   }
 }
 
@@ -681,12 +720,13 @@ extern "C" int mgld_adain(const float* content, const float* style, float* out, 
                           void* stream) {
   MGLD_REQUIRE(content && style && out && work && planes > 0 && hw > 1, "adain: bad args");
   MGLD_REQUIRE(((uintptr_t)work & 7) == 0, "adain: work alignment");
-  double* cst = (double*)work;
-  double* sst = cst + (int64_t)planes * 2;
-  hipLaunchKernelGGL(plane_stats_kernel, dim3(planes), dim3(256), 0, S_(stream), content, hw, cst);
-  hipLaunchKernelGGL(plane_stats_kernel, dim3(planes), dim3(256), 0, S_(stream), style, hw, sst);
-  hipLaunchKernelGGL(adain_apply_kernel, dim3(egrid((int64_t)planes * hw)), dim3(256), 0, S_(stream), content, cst, sst, out,
-                     planes, hw, eps);
+  MGLD_REQUIRE(planes <= 65535, "adain: too many planes");
+  double* part = (double*)work;
+  const int chunks = adain_chunks(hw);
+  hipLaunchKernelGGL(plane_partial_kernel, dim3(chunks, planes, 2), dim3(256), 0, S_(stream), content, style, hw, chunks, planes, part);
+  int bpp = (int)((hw + 4095) / 4096);           // apply blocks per plane: ~4 float4 per thread
+  if (bpp > 256) bpp = 256;
+  hipLaunchKernelGGL(adain_apply_kernel, dim3(bpp, planes), dim3(256), 0, S_(stream), content, part, out, planes, hw, chunks, eps);
   return mgld_check_launch("adain");
 }
 

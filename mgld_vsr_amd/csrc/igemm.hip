@@ -381,6 +381,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   const int clog = cphys ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
   const char* zero = (const char*)g_zero_page;
   const int nk = (k_end - k_begin + BK - 1) / BK;
+  // W2 (MgldIGemm): the K range is walked TWICE over the same A — first against the scaled fp16 residual of the weights (same layout,
+  // `wdelta` bytes away from W), then, after ONE multiplication of the accumulators by w2_scale, against W itself.
+  const bool two = (p.W2 != nullptr);
+  const int nkt = two ? 2 * nk : nk;
+  const int64_t wdelta = two ? (const char*)p.W2 - (const char*)p.W : 0;
+  const f16* __restrict__ Wc = two ? (const f16*)((const char*)W + wdelta) : W;     // GENERAL path: matrix of the stage being issued
 
   // ======== FAST path state: K % 64 == 0, and for the gather modes Cin % 64 == 0 and no upsample fold. ========
   // Every 64-deep stage then lies inside ONE tap, so the tap / channel offset is wave-uniform (SGPR) and a lane's
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
     for (int j = 0; j < JB; ++j) {
       const int n = bn0 + (j * NW + wave) * 8 + (lane >> 3);
       const bool valid = n < N;
-      fw_ptr[j] = valid ? (const char*)(W + (int64_t)n * p.ldw + k_begin + clog * 8) : zero;
+      fw_ptr[j] = valid ? (const char*)(W + (int64_t)n * p.ldw + k_begin + clog * 8) + wdelta : zero;
       fw_step[j] = valid ? BK * 2 : 0;
     }
   } else {
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
       }
 #pragma unroll
       for (int j = 0; j < JB; ++j) {
-        const f16* src = (b_valid[j] & kval) ? (W + b_base[j] + kl) : (const f16*)zero;
+        const f16* src = (b_valid[j] & kval) ? (Wc + b_base[j] + kl) : (const f16*)zero;
         glds16(src, sbase + BM * ROWB + j * (NW * 1024));
       }
       kl += BK;
@@ -630,6 +636,32 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
       }
     }
   };
+  // after the stage that ends the residual pass has been issued: rewind A, switch to W (caller scope: plain scalars / pointers)
+  int issued = 0;
+#define MGLD_AFTER_ISSUE()                                                            \
+  if (two && ++issued == nk) {                                                        \
+    if constexpr (FAST) {                                                             \
+      if constexpr (MODE == MGLD_MODE_LINEAR) {                                       \
+        _Pragma("unroll") for (int j = 0; j < JA; ++j) fa_ptr[j] -= (int64_t)nk * fa_step[j]; \
+      } else {                                                                        \
+        u_tap = __builtin_amdgcn_readfirstlane(s_tap);                                \
+        u_c0 = __builtin_amdgcn_readfirstlane(s_c0);                                  \
+      }                                                                               \
+      _Pragma("unroll") for (int j = 0; j < JB; ++j) fw_ptr[j] -= (int64_t)nk * fw_step[j] + (fw_step[j] ? wdelta : 0); \
+    } else {                                                                          \
+      kl = k_begin + clog * 8;                                                        \
+      tap = kl / Cin;                                                                 \
+      c = kl - tap * Cin;                                                             \
+      Wc = W;                                                                         \
+    }                                                                                 \
+  }
+#define MGLD_SCALE_ACC()                                                              \
+  {                                                                                   \
+    const float sc2_ = p.w2_scale;                                                    \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                 \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[ni][mi][r] *= sc2_;        \
+  }
   if constexpr (NST == 0) {
     // ---- register-staged tiles (LINEAR fast path only): global_load_dwordx4 -> VGPRs -> ds_write_b128 into the same swizzled
     // LDS image the DMA path builds.  The LDS-DMA instruction costs a wave 60-185 issue cycles per KiB (MI355X_MICROARCH.md), which
@@ -664,14 +696,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   } else {
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) {
+    if (s < nkt) {
       issue_stage(s, u_tap, u_c0);
       MGLD_ADVANCE_TAP();
+      MGLD_AFTER_ISSUE();
     }
   int cur = 0;  // buffer of stage kt
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nkt; ++kt) {
     {
-      const int ahead = min(NST - 2, nk - 1 - kt);                      // newer stages that may stay outstanding
+      const int ahead = min(NST - 2, nkt - 1 - kt);                     // newer stages that may stay outstanding
       if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (JA + JB)) : "memory");
       else if (NST >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JB) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -686,16 +719,20 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
       const int nxt = kt + NST - 1;
       int nb = cur + NST - 1;
       if (nb >= NST) nb -= NST;
-      if (nxt < nk) {
+      if (nxt < nkt) {
         issue_stage(nb, u_tap, u_c0);
         MGLD_ADVANCE_TAP();
+        MGLD_AFTER_ISSUE();
       }
     }
     const char* sb = smem + cur * STAGE;
     cur = (cur + 1 == NST) ? 0 : cur + 1;
+    if (two && kt == nk) MGLD_SCALE_ACC()        // residual pass done: acc = w2_scale * (A W2^T); A W^T accumulates on top
     compute_stage(sb);
   }
   }
+#undef MGLD_AFTER_ISSUE
+#undef MGLD_SCALE_ACC
 
   tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, RowMapLinear{bm0, M}, bn0, wm, wn, wave, lane, acc, smem);
 }
@@ -1002,13 +1039,17 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
     fw_ok[k] = (g64 * 64 < ((N + 63) & ~63)) && (b < NPB);
     fw_ptr[k] = (const char*)(W + (((int64_t)g64 * nh * 3 * 4 + (rb & 3)) * 3 + dxi) * 512 + lane * 8);
   }
-  auto issue_b = [&](const int buf, const int h, const int dyi) {
-    const int64_t soff = (int64_t)(h * 3 + dyi) * (12 * 512);
+  // W2 (MgldIGemm): the slices are walked TWICE — first against the scaled fp16 residual of the weights (same tiled layout, `wdelta` bytes
+  // away), then, after ONE multiplication of the accumulators by w2_scale, against the weights themselves.  `lo` selects the matrix.
+  const bool two = (p.W2 != nullptr);
+  const int64_t wdelta = two ? (const char*)p.W2 - (const char*)p.W : 0;
+  auto issue_b = [&](const int buf, const int h, const int dyi, const bool lo) {
+    const int64_t soff = (int64_t)(h * 3 + dyi) * (12 * 512) * 2 + (lo ? wdelta : 0);
 #pragma unroll
     for (int k = 0; k < BSLOTS; ++k) {
       const int b = k * NW + wave;
       if (b < NPB) {
-        const char* src = fw_ok[k] ? fw_ptr[k] + soff * 2 : zero;
+        const char* src = fw_ok[k] ? fw_ptr[k] + soff : zero;
         glds16(src, smem + B_BASE + buf * B_BYTES + b * 1024);
       }
     }
@@ -1049,16 +1090,35 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
+  const int ns = h1 - h0;                     // channel slices of this block (of this K split)
+  const int nv = two ? 2 * ns : ns;           // slice visits: residual pass, then main pass
   if (h0 < h1) {
     MGLD_Q_ISSUE_A(0, 0)
     MGLD_Q_ISSUE_A(1, 0)
     MGLD_Q_ISSUE_A(2, 0)
-    issue_b(0, h0, 0);
+    issue_b(0, h0, 0, two);
   }
   int cur = 0;
-  for (int h = h0; h < h1; ++h) {
-    const int pa = (h - h0) & 1;
-    const bool more = (h + 1 < h1);
+  int h = h0;
+  for (int v = 0; v < nv; ++v) {
+    const int pa = v & 1;
+    const bool more = (v + 1 < nv);
+    const bool wrap = two && (v + 1 == ns);   // the next visit starts the main pass: its patch is slice h0 again
+    const int hn = wrap ? h0 : h + 1;
+    const bool lo = two && (v < ns), lo_next = two && (v + 1 < ns);
+    if (two && v == ns) {                     // residual pass done: acc = w2_scale * (A W2^T), then A W^T accumulates on top
+      const float sc2 = p.w2_scale;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ni][mi][r] *= sc2;
+    }
+    if (wrap) {
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) fa_ptr[s] -= (int64_t)ns * fa_step[s];
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1068,8 +1128,8 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
         if (s == 1) { MGLD_Q_ISSUE_A(1, pa ^ 1) }
         if (s == 2) { MGLD_Q_ISSUE_A(2, pa ^ 1) }
       }
-      if (s < 2) issue_b(cur ^ 1, h, s + 1);
-      else if (more) issue_b(cur ^ 1, h + 1, 0);
+      if (s < 2) issue_b(cur ^ 1, h, s + 1, lo);
+      else if (more) issue_b(cur ^ 1, hn, 0, lo_next);
       const int abase = pa * A_BYTES;
       const int bb = B_BASE + cur * B_BYTES;
       // fragments of step u + PF are fetched from LDS while the MFMAs of step u run (PF + 1 register sets, static indices);
@@ -1095,6 +1155,7 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
       }
       cur ^= 1;
     }
+    h = hn;
   }
 #undef MGLD_Q_ISSUE_A
   tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, 0, RowMap2D<TX>{frame * p.Hout * p.Wout, y0, x0, p.Hout, p.Wout}, bn0, wm, wn, wave,
@@ -1227,7 +1288,7 @@ int launch_cfg(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   if (p->mode == MGLD_MODE_LINEAR && fast_ok(p) && splits <= 1) {
     static int rs = -1;   // env MGLD_IGEMM_RS = 1: register-staged tiles on the LINEAR fast path (p->tune = 9 selects them per launch)
     if (rs < 0) { const char* e = getenv("MGLD_IGEMM_RS"); rs = e ? atoi(e) : 0; }
-    if ((rs && p->tune == 0) || p->tune == 9) {
+    if (((rs && p->tune == 0) || p->tune == 9) && !p->W2) {
       launch_fast<MGLD_MODE_LINEAR, true, BM, BN, WM, WN, 0>(p, s, splits, kchunk);
       if (splits > 1) {}
       return mgld_check_launch("igemm");
@@ -1546,13 +1607,19 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
     MGLD_REQUIRE(p->mode != MGLD_MODE_LINEAR && (p->Cin % BK) == 0 && !(p->mode == MGLD_MODE_CONV3X3 && p->up2) &&
                      !(p->mode == MGLD_MODE_CONV3X3 && p->kh > 0 && !(p->kh == 3 && p->kw == 3)),
                  "igemm: tap_inner needs a gather mode with Cin % 64 == 0 and no upsample fold");
+  if (p->W2) {
+    MGLD_REQUIRE((((uintptr_t)p->W2) & 15) == 0 && p->w2_scale > 0.f, "igemm: W2 must be 16-byte aligned with a positive w2_scale");
+    MGLD_REQUIRE(p->tune != 9, "igemm: the register-staged LINEAR variant does not take W2");
+  }
   if (p->rowvec) MGLD_REQUIRE(p->rows_per_frame > 0, "igemm: rows_per_frame");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return dispatch_conv3q(p, s, cfg, splits, kchunk);
-  if (conv3p_plan(p, &cfg, &splits, &kchunk))
+  if (conv3p_plan(p, &cfg, &splits, &kchunk)) {
+    MGLD_REQUIRE(!p->W2, "igemm: the raster patch kernel (MGLD_CONV3Q=0) does not take W2");
     return cfg == 64 ? launch_conv3p<64, 32, 32>(p, s, splits, kchunk) : launch_conv3p<128, 64, 32>(p, s, splits, kchunk);
+  }
   choose(p, &cfg, &splits, &kchunk);
   switch (cfg) {
     // 128x128: eight waves of 64x32 (two blocks = 16 waves per CU) measured ~3 % faster end to end than four of 64x64:

@@ -157,7 +157,8 @@ class LatentDiffusionVSRTextWT(nn.Module):
         yield None  # use_ema=False in the shipped config (mgldvsr_512_realbasicvsr_deg.yaml:21)
 
     def init_from_ckpt(self, path, ignore_keys=(), only_model=False):
-        sd = torch.load(path, map_location="cpu")
+        from .util import load_trusted_checkpoint
+        sd = load_trusted_checkpoint(path)
         if "state_dict" in sd:
             sd = sd["state_dict"]
         for k in list(sd.keys()):

@@ -98,6 +98,31 @@ def pack_geglu(w, b):
     return wp, bp
 
 
+def split_residual(w32, scale=None):
+    """fp32 packed weights -> (hi, lo): hi = fp16(w), lo = fp16((w - hi) / scale) with scale = 2^-11, i.e. the rounding residual of
+    the weights lifted into fp16's normal range (MgldIGemm.W2: the kernel computes scale * (A lo^T) + A hi^T)."""
+    scale = hip.W2_SCALE if scale is None else scale
+    hi = w32.to(torch.float16)
+    lo = ((w32 - hi.to(torch.float32)) / scale).to(torch.float16)
+    return hi, lo
+
+
+# where the second MFMA pass on the weight residual is switched on (env MGLD_W2 = comma-separated scope names, "all", or "0"):
+#   vae_dec   every contraction of the video decoder (VideoDecoder_Mix incl. fusion layers, temporal convs, post_quant_conv)
+#   vae_enc   the video VAE's encoder (its features feed the decoder's fusion layers)
+#   first     the first-stage (image) encoder that produces the init latent / struct-cond input
+#   unet_io   the UNet's input_blocks.0 and out convolutions
+#   unet      every contraction of the UNet and the struct-cond encoder
+W2_DEFAULT = "vae_dec"
+
+
+def w2_scopes():
+    v = os.environ.get("MGLD_W2", W2_DEFAULT).strip()
+    if v in ("", "0", "none", "off"):
+        return frozenset()
+    return frozenset(t.strip() for t in v.split(",") if t.strip())
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # activations + arena
 # ------------------------------------------------------------------------------------------------------------------
@@ -233,6 +258,8 @@ class Engine:
         self.shard = None   # parallel.FrameShard when the frames of one segment are split over ranks
         self.tile_shard = None   # parallel.TileShard when the latent tiles of aggregation sampling are split over ranks
         self.pieces = None       # GraphPieces while a sharded step is recorded / replayed as hipGraph pieces
+        self.w2_scopes = w2_scopes()   # precision scopes that run the second MFMA pass on the weight residual (split_residual)
+        self._scope = []               # stack of active scope names (Engine.scope)
         # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
         self._splitk_ws = hip.ensure_workspace(workspace_bytes) if self.device.type == "cuda" else None
 
@@ -270,6 +297,41 @@ class Engine:
         self._wcache[key] = dev
         return dev
 
+    # ---- precision scopes ----
+    class _Scope:
+        def __init__(self, eng, name):
+            self.eng, self.name = eng, name
+
+        def __enter__(self):
+            self.eng._scope.append(self.name)
+
+        def __exit__(self, *exc):
+            self.eng._scope.pop()
+            return False
+
+    def scope(self, name):
+        """`with eng.scope("vae_dec"):` — contractions launched inside use split weights when MGLD_W2 names the scope"""
+        return Engine._Scope(self, name)
+
+    @property
+    def w2_on(self):
+        s = self.w2_scopes
+        return bool(s) and ("all" in s or any(n in s for n in self._scope))
+
+    def weight2(self, tag, params, fn):
+        """like weight(), for a contraction that may run the residual pass: -> (hi, lo-or-None) fp16 device tensors; fn must return
+        ONE fp32 matrix.  lo is built (once) only while a scope that MGLD_W2 names is active."""
+        hi = self.weight(tag, params, fn)
+        if not self.w2_on:
+            return hi, None
+        key = (tag + "#w2",) + tuple((id(p), p._version) for p in params if p is not None)
+        lo = self._wcache.get(key)
+        if lo is None:
+            with torch.no_grad():
+                w32 = fn(*[None if p is None else p.detach().float().cpu() for p in params])
+            lo = self._wcache[key] = split_residual(w32)[1].to(self.device).contiguous()
+        return hi, lo
+
     def const(self, key, fn):
         """device constant built once per engine (e.g. identity affine vectors): fn() -> tensor or tuple of tensors"""
         hit = self._wcache.get(("const", key))
@@ -282,7 +344,7 @@ class Engine:
 
     # ---- ops ----
     def conv3x3(self, x, wp, bias, cout, out=None, stride=1, pad=(1, 1), up2=False, hw_out=None, rowvec=None,
-                rows_per_frame=0, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16):
+                rows_per_frame=0, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, w2=None):
         hin, win = x.h, x.w
         if hw_out is None:
             hv, wv = (2 * hin, 2 * win) if up2 else (hin, win)
@@ -297,8 +359,10 @@ class Engine:
         if stride == 1 and tuple(pad) == (1, 1) and (ho, wo) == ((2 * hin, 2 * win) if up2 else (hin, win)):
             wt = self._conv3p_tiled(wp, x.n, cin, cout, hin, win, tap_inner, up2)
             if wt is not None:
-                wp, tap_inner, kw = wt, 2, dict(N=cout, K=9 * cin)
-        hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec,
+                w2t = None if w2 is None else self._conv3p_tiled(w2, x.n, cin, cout, hin, win, tap_inner, up2)
+                if w2 is None or w2t is not None:
+                    wp, w2, tap_inner, kw = wt, w2t, 2, dict(N=cout, K=9 * cin)
+        hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec, w2=w2,
                   rows_per_frame=rows_per_frame or ho * wo, resid=None if resid is None else resid.v, act=act, alpha=alpha,
                   beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0), tap_inner=tap_inner, **kw)
         self.launches += 1
@@ -337,7 +401,8 @@ class Engine:
         self.launches += 1
         return out
 
-    def linear(self, x, w, bias, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, n_out=None):
+    def linear(self, x, w, bias, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, n_out=None,
+               w2=None):
         """x: Act or 2-D view; w [N, K] fp16 packed."""
         xv = x.v if isinstance(x, Act) else x
         N = n_out if n_out is not None else (w.shape[0] // 2 if act == hip.ACT_GEGLU else w.shape[0])
@@ -346,18 +411,18 @@ class Engine:
             out = Act(ov, x.n, x.h, x.w) if isinstance(x, Act) else ov
         ov = out.v if isinstance(out, Act) else out
         rv = resid.v if isinstance(resid, Act) else resid
-        hip.igemm(xv, w, ov, bias=bias, resid=rv, act=act, alpha=alpha, beta=beta, M=xv.shape[0], N=w.shape[0], K=w.shape[1])
+        hip.igemm(xv, w, ov, bias=bias, resid=rv, act=act, alpha=alpha, beta=beta, M=xv.shape[0], N=w.shape[0], K=w.shape[1], w2=w2)
         self.launches += 1
         return out
 
-    def tconv3(self, x, wp, bias, T, alpha_blend, out=None):
+    def tconv3(self, x, wp, bias, T, alpha_blend, out=None, w2=None):
         """SpatialTemporalConv: out = a*(conv3d_t(x)+b) + (1-a)*x."""
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C)
         sh = self.shard
         if sh is None:
             hip.igemm(x.v, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
-                      tconv=(x.C, T, x.hw))
+                      tconv=(x.C, T, x.hw), w2=w2)
             self.launches += 1
             return out
         # frame-sharded clip (parallel.FrameShard): this rank holds F consecutive frames.  The conv runs on a halo-extended
@@ -371,7 +436,7 @@ class Engine:
         hip.copy2d(x.v, mid)
         self.collective(lambda: sh.halo(x.v, hw, ext[:hw], ext[(F + 1) * hw:]))
         hip.igemm(mid, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
-                  tconv=(x.C, F + 2, hw), t_off=1)
+                  tconv=(x.C, F + 2, hw), t_off=1, w2=w2)
         self.launches += 2
         return out
 

@@ -63,7 +63,7 @@ def forward_backward_consistency_check(fwd_flow, bwd_flow, alpha=0.01, beta=0.5)
 def adaptive_instance_normalization(content_feat, style_feat):
     c, s = _dev(content_feat), _dev(style_feat)
     assert c.dim() == 4 and c.shape[:2] == s.shape[:2]
-    work = torch.empty(4 * c.shape[0] * c.shape[1] * 2 + 8, dtype=torch.float32, device=c.device)
+    work = torch.empty(512 * c.shape[0] * c.shape[1] + 8, dtype=torch.float32, device=c.device)   # mgld_adain: 512 floats per plane
     if s.shape != c.shape:
         raise NotImplementedError("AdaIN expects content and style of the same shape (as the VSR scripts pass)")
     return hip.adain(c, s, torch.empty_like(c), work)

@@ -33,6 +33,7 @@ class MgldIGemm(C.Structure):
         ("batch", C.c_int32), ("tap_inner", C.c_int32),
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
         ("t_off", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("tune", C.c_int32),
+        ("w2_scale", C.c_float), ("W2", C.c_void_p),
     ]
 
 
@@ -114,10 +115,15 @@ def _ld(t):
     return t.stride(0)
 
 
+W2_SCALE = 2.0 ** -11     # scale of the weight-residual matrices (MgldIGemm.W2): fp16(residual / W2_SCALE) stays in fp16's normal range
+
+
 def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None,
           act=ACT_NONE, alpha=1.0, beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0,
-          M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0):
-    """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h)."""
+          M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0, w2=None, w2_scale=W2_SCALE):
+    """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h).
+    w2: the scaled fp16 rounding residual of the weights (same layout as w; engine.split_residual): the product then uses weights
+    exact to ~2^-21 at twice the MFMA work."""
     _req_cuda(a, w, out)
     if not getattr(_TLS, "touched", False):
         ensure_workspace()          # a thread other than the one that built the Engine: give it its own split-K scratch
@@ -142,6 +148,9 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
     p.tap_inner = tap_inner
     p.t_off = t_off
     p.tune = tune
+    if w2 is not None:
+        assert w2.is_cuda and w2.dtype == w.dtype and w2.shape == w.shape and w2.stride() == w.stride(), "w2 must mirror w"
+        p.W2, p.w2_scale = w2.data_ptr(), float(w2_scale)
     if ksize is not None:
         p.kh, p.kw = ksize
     p.strideA, p.strideW, p.strideC, p.strideR = strideA, strideW, strideC, strideR

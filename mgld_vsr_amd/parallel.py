@@ -62,6 +62,18 @@ def max_over_ranks(value, device=None):
     return float(t[0])
 
 
+def gather_floats(value, device=None):
+    """all-gather one python float per rank -> list indexed by rank (bench.py reports every rank's ms per step, not only the max)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [round(float(value), 2)]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [round(float(o[0]), 2) for o in out]
+
+
 def gather_frames(local_frames, segment_ids, n_segments, device=None):
     """Collect per-rank outputs on rank 0: `local_frames` = list of [T,3,H,W] tensors for `segment_ids`.
     Returns the ordered list on rank 0, None elsewhere.  (Not on the timed path: the reference lets every process write

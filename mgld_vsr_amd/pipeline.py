@@ -11,7 +11,7 @@ import torch
 from . import synth
 from .ddpm import space_timesteps
 from .flowops import adaptive_instance_normalization, wavelet_reconstruction
-from .util import instantiate_from_config
+from .util import instantiate_from_config, load_trusted_checkpoint
 
 
 def model_configs(num_frames=5, unet_overrides=None, struct_overrides=None, vae_overrides=None, context_dim=1024):
@@ -100,7 +100,7 @@ class VSRPipeline:
         (`context` [1,77,1024]) — a real checkpoint is never paired with the synthetic context silently.
         Returns (missing_keys, unexpected_keys) of the diffusion model."""
         m = self.model
-        sd = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, str) else ckpt
+        sd = load_trusted_checkpoint(ckpt) if isinstance(ckpt, str) else ckpt
         sd = sd["state_dict"] if "state_dict" in sd else sd
         cs = m.cond_stage_model
         tk = "cond_stage_model.model."
@@ -174,6 +174,16 @@ class VSRPipeline:
             eng.shard = None
             eng.tile_shard = None
 
+    def _rank_shared_generator(self):
+        """host generator of the noise a SHARDED segment draws itself (no `noise=`): seeded once from the process seed — which every
+        rank sets alike — and then ADVANCED from segment to segment, as the reference's global generator is (fresh noise per segment,
+        oldcanvas_tile.py:432-436); re-seeded only when the process seed itself changes.  Every rank makes the same calls in the
+        same order, so all ranks see the same draws."""
+        seed = int(torch.initial_seed()) & 0x7FFFFFFF
+        if getattr(self, "_shared_gen_seed", None) != seed:
+            self._shared_gen, self._shared_gen_seed = torch.Generator().manual_seed(seed), seed
+        return self._shared_gen
+
     def draw_noise(self, T, h, w):
         """the three draws run_segment makes when no noise is injected — posterior sample (host generator, as
         DiagonalGaussianDistribution.sample does), x_T (device generator, `randn_like(init_latent)`), the per-step noise (device) — in
@@ -196,7 +206,7 @@ class VSRPipeline:
                 from .parallel import FrameShard
                 fs = FrameShard(frames.shape[0], tile_shard.rank, tile_shard.world)
             lat_shape = (frames.shape[0], 4, frames.shape[2] // 8, frames.shape[3] // 8)
-            g = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)       # the same draws on every rank
+            g = self._rank_shared_generator()                                              # the same draws on every rank
             for k, shp in (("posterior", lat_shape), ("x_T", lat_shape), ("steps", (self.ddpm_steps,) + lat_shape)):
                 if noise.get(k) is None:
                     noise[k] = torch.randn(shp, generator=g)
@@ -208,7 +218,7 @@ class VSRPipeline:
             # noise the caller did not inject is drawn for the WHOLE clip from a generator every rank seeds alike, then
             # sliced: the result does not depend on how many ranks share the segment
             lat_shape = (shard.T, 4, frames.shape[2] // 8, frames.shape[3] // 8)
-            g = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
+            g = self._rank_shared_generator()
             for k, shp in (("posterior", lat_shape), ("x_T", lat_shape), ("steps", (self.ddpm_steps,) + lat_shape)):
                 if noise.get(k) is None:
                     noise[k] = torch.randn(shp, generator=g)
@@ -279,39 +289,82 @@ class SegmentPool:
     should inject their noise (`noise=`) so that results do not depend on which worker drew from the global generator first."""
 
     def __init__(self, make_pipeline, k, first=None):
+        import queue
         import threading
-        self._threading = threading
         self.pipes = ([first] if first is not None else []) + [make_pipeline() for _ in range(k - (1 if first is not None else 0))]
         self.streams = [torch.cuda.Stream() for _ in self.pipes]
         self.device = torch.cuda.current_device()
+        # PERSISTENT workers: one host thread per instance for the pool's lifetime.  The kernel library keeps the split-K scratch per
+        # host thread, so a worker registers its 256 MB workspace ONCE (threads started per call re-allocated it inside the timed
+        # region, and a graph cached across calls would have replayed against freed scratch).
+        self._queues = [queue.Queue() for _ in self.pipes]
+        self._threads = [threading.Thread(target=self._worker, args=(i,), daemon=True, name=f"mgld-segment-{i}") for i in range(len(self.pipes))]
+        self._sem = threading.Semaphore(0)
+        self.last_latency_ms = {}     # slot -> GPU-side latency of that job in the last _drive call (hipEvent pair on the worker's stream)
+        for t in self._threads:
+            t.start()
 
     def __len__(self):
         return len(self.pipes)
 
-    def _drive(self, plan):
-        """plan[i] = list of (slot, call) for worker i, call(pipeline instance) -> result; returns {slot: result}"""
+    def _worker(self, i):
         from . import hip
-        out, errs = {}, []
-        ready = torch.cuda.Event()
-        ready.record()                     # whatever the caller enqueued for the jobs (inputs, pre-drawn noise) on ITS stream ...
-
-        def worker(i):
+        torch.cuda.set_device(self.device)
+        ws_ready = False
+        while True:
+            item = self._queues[i].get()
+            if item is None:
+                return
+            plan, ready, out, lat, errs = item
             try:
-                torch.cuda.set_device(self.device)
-                self.streams[i].wait_event(ready)                # ... is complete before a worker stream touches it
+                self.streams[i].wait_event(ready)                # whatever the caller enqueued on ITS stream is complete first
+                evs = []
                 with torch.cuda.stream(self.streams[i]):
-                    hip.ensure_workspace()                       # this thread's split-K scratch
-                    for slot, call in plan[i]:
+                    if not ws_ready:
+                        hip.ensure_workspace()                   # this thread's split-K scratch, for the thread's lifetime
+                        ws_ready = True
+                    for slot, call in plan:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
                         out[slot] = call(self.pipes[i])
+                        e1.record()
+                        evs.append((slot, e0, e1))
                 self.streams[i].synchronize()
+                for slot, e0, e1 in evs:
+                    lat[slot] = e0.elapsed_time(e1)
             except BaseException as e:   # noqa: BLE001  (re-raised on the calling thread)
                 errs.append(e)
+            finally:
+                self._sem.release()
 
-        th = [self._threading.Thread(target=worker, args=(i,)) for i in range(len(self.pipes)) if plan[i]]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    def close(self):
+        for q in self._queues:
+            q.put(None)
+        for t in self._threads:
+            t.join(timeout=5)
+        self._threads = []
+
+    def __del__(self):
+        try:
+            for q in self._queues:
+                q.put(None)
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def _drive(self, plan):
+        """plan[i] = list of (slot, call) for worker i, call(pipeline instance) -> result; returns {slot: result}.  The GPU-side latency
+        of every job (first launch .. last kernel, measured with a hipEvent pair on the worker's stream) lands in last_latency_ms."""
+        out, lat, errs = {}, {}, []
+        ready = torch.cuda.Event()
+        ready.record()                     # whatever the caller enqueued for the jobs (inputs, pre-drawn noise) on ITS stream ...
+        n = 0
+        for i, pl in enumerate(plan):
+            if pl:
+                self._queues[i].put((pl, ready, out, lat, errs))
+                n += 1
+        for _ in range(n):
+            self._sem.acquire()
+        self.last_latency_ms = lat
         if errs:
             raise errs[0]
         return out

@@ -163,7 +163,8 @@ class RAFT_SR(nn.Module):
         self.update_block = BasicUpdateBlock(self.corr_levels, self.corr_radius, hidden_dim=128)
         self._engine = None
         if load_path:
-            sd = torch.load(load_path, map_location="cpu")
+            from .util import load_trusted_checkpoint
+            sd = load_trusted_checkpoint(load_path)
             self.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()})
 
     def set_engine(self, eng):

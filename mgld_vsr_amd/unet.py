@@ -349,9 +349,9 @@ class SpatialTemporalConv(nn.Module):
         self.temporal_alpha = nn.Parameter(torch.zeros(1))
 
     def run(self, eng, x, out=None):
-        w = eng.weight("t3", (self.temporal_conv.weight,), pack_tconv3)
+        w, w2 = eng.weight2("t3", (self.temporal_conv.weight,), pack_tconv3)
         return eng.tconv3(x, w, eng.f32("b", self.temporal_conv.bias), self.num_frames, float(self.temporal_alpha.detach()),
-                          out=out)
+                          out=out, w2=w2)
 
 
 class TemporalAttention(nn.Module):
@@ -608,9 +608,10 @@ class InflatedUNetModelDualcondV2(nn.Module, _TimeEmbedMixin):
                     h = layer.run(eng, h, ctx_cache, out=o)
                 elif isinstance(layer, (Downsample, Upsample, SpatialTemporalConv, TemporalAttention)):
                     h = layer.run(eng, h, out=o)
-                elif isinstance(layer, nn.Conv2d):
-                    h = eng.conv3x3(h, eng.weight("c3", (layer.weight,), lambda w: pack_conv3x3(w, h.C)), eng.f32("b", layer.bias),
-                                    layer.out_channels, out=o)
+                elif isinstance(layer, nn.Conv2d):                     # input_blocks.0: the 4 -> 320 convolution on the noisy latent
+                    with eng.scope("unet_io"):
+                        wi, wi2 = eng.weight2("c3", (layer.weight,), lambda w: pack_conv3x3(w, h.C))
+                        h = eng.conv3x3(h, wi, eng.f32("b", layer.bias), layer.out_channels, out=o, w2=wi2)
                 else:
                     raise RuntimeError(f"unexpected layer {type(layer)}")
             return h
@@ -627,7 +628,9 @@ class InflatedUNetModelDualcondV2(nn.Module, _TimeEmbedMixin):
         t = eng.groupnorm(h, eng.f32("g", gn.weight), eng.f32("b", gn.bias), gn.eps, True)
         if out_eps is None:
             out_eps = Act(eng.arena.alloc((x.rows, self.out_channels), torch.float32), x.n, x.h, x.w)
-        eng.conv3x3(t, eng.weight("c3", (conv.weight,), pack_conv3x3), eng.f32("b", conv.bias), self.out_channels, out=out_eps)
+        with eng.scope("unet_io"):                                              # out: the 320 -> 4 convolution that produces eps
+            wo, wo2 = eng.weight2("c3", (conv.weight,), pack_conv3x3)
+            eng.conv3x3(t, wo, eng.f32("b", conv.bias), self.out_channels, out=out_eps, w2=wo2)
         return out_eps
 
     # ---- reference-compatible entry ----

@@ -30,3 +30,46 @@ def exists(x):
 
 def default(val, d):
     return val if val is not None else (d() if callable(d) else d)
+
+
+def load_trusted_checkpoint(path, map_location="cpu"):
+    """torch.load for the reference's checkpoint files (scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py:91-108 calls
+    `torch.load(ckpt, map_location="cpu")` with the pre-2.6 default, i.e. the full unpickler).  stablevsr_025.ckpt / vqgan_cfw_00011.ckpt
+    are Lightning checkpoints: next to `state_dict` they pickle callback / hyper-parameter objects, which torch >= 2.6's default
+    `weights_only=True` refuses ("Unsupported global").  Order: the safe loader first (plain state dicts need nothing else); when it
+    refuses, the full unpickler on this local, user-supplied file — with classes of modules that are not importable here
+    (pytorch_lightning is not a dependency of this path) replaced by inert placeholders, since only the tensors are read."""
+    import pickle
+
+    import torch
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError:
+        pass
+
+    class _Placeholder:
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, state):
+            self.__dict__["_state"] = state
+
+        def __call__(self, *a, **k):
+            return _Placeholder()
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return type(name, (_Placeholder,), {"__module__": module})
+
+    class _PickleModule:
+        __name__ = "mgld_vsr_amd.util.tolerant_pickle"
+        Unpickler = _Unpickler
+        load = staticmethod(lambda f, **kw: _Unpickler(f, **kw).load())
+        loads = staticmethod(pickle.loads)
+        dump, dumps, Pickler = staticmethod(pickle.dump), staticmethod(pickle.dumps), pickle.Pickler
+        PickleError, UnpicklingError, PicklingError = pickle.PickleError, pickle.UnpicklingError, pickle.PicklingError
+
+    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_PickleModule)

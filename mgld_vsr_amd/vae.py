@@ -24,14 +24,14 @@ def Normalize(in_channels, num_groups=32):
 
 def _conv3(eng, conv, x, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, **kw):
     up2 = bool(kw.get("up2", False))
-    w = eng.weight("c3up" if up2 else "c3", (conv.weight,), lambda t: pack_conv3x3(t, x.C, tap_inner=False if up2 else None))
+    w, w2 = eng.weight2("c3up" if up2 else "c3", (conv.weight,), lambda t: pack_conv3x3(t, x.C, tap_inner=False if up2 else None))
     return eng.conv3x3(x, w, eng.f32("b", conv.bias), conv.out_channels, out=out, resid=resid, act=act, alpha=alpha, beta=beta,
-                       **kw)
+                       w2=w2, **kw)
 
 
 def _conv1(eng, conv, x, out=None, resid=None, alpha=1.0, beta=1.0):
-    w = eng.weight("c1", (conv.weight,), lambda t: pack_conv1x1(t, x.C))
-    return eng.linear(x, w, eng.f32("b", conv.bias), out=out, resid=resid, alpha=alpha, beta=beta)
+    w, w2 = eng.weight2("c1", (conv.weight,), lambda t: pack_conv1x1(t, x.C))
+    return eng.linear(x, w, eng.f32("b", conv.bias), out=out, resid=resid, alpha=alpha, beta=beta, w2=w2)
 
 
 def _gn(eng, norm, x, silu):
@@ -372,6 +372,8 @@ class DiagonalGaussianDistribution(object):
 
 
 class _AutoencoderBase(nn.Module):
+    ENC_SCOPE, DEC_SCOPE = "first", "first_dec"      # precision scopes (engine.w2_scopes) of the first-stage (image) autoencoder
+
     def engine(self):
         if self._engine is None:
             self._engine = Engine()
@@ -390,15 +392,17 @@ class _AutoencoderBase(nn.Module):
     def _moments(self, eng, x, fea_out=None):
         """x: NCHW fp32 device tensor -> (moments NCHW fp32 [n, 2*embed, h/8, w/8], [fea Acts])."""
         xa = eng.from_nchw(x)
-        h, fea = self.encoder.run(eng, xa, fea_out=fea_out)
-        m = Act(eng.arena.alloc((h.rows, 2 * self.embed_dim), torch.float32), h.n, h.h, h.w)
-        wq = eng.weight("c1", (self.quant_conv.weight,), lambda t: pack_conv1x1(t, h.C))
-        eng.linear(h, wq, eng.f32("b", self.quant_conv.bias), out=m)
+        with eng.scope(self.ENC_SCOPE):
+            h, fea = self.encoder.run(eng, xa, fea_out=fea_out)
+            m = Act(eng.arena.alloc((h.rows, 2 * self.embed_dim), torch.float32), h.n, h.h, h.w)
+            wq, wq2 = eng.weight2("c1", (self.quant_conv.weight,), lambda t: pack_conv1x1(t, h.C))
+            eng.linear(h, wq, eng.f32("b", self.quant_conv.bias), out=m, w2=wq2)
         return eng.to_nchw(m, 2 * self.embed_dim), fea
 
     def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
         """autoencoder.py:1652-1672: accepts full-model checkpoints by stripping the `first_stage_model.` prefix."""
-        sd = torch.load(path, map_location="cpu")
+        from .util import load_trusted_checkpoint
+        sd = load_trusted_checkpoint(path)
         if "state_dict" in sd:
             sd = sd["state_dict"]
         for k in list(sd.keys()):
@@ -434,11 +438,13 @@ class AutoencoderKL(_AutoencoderBase):
         eng = self.engine()
         eng.reset()
         za = eng.from_nchw(z.to(eng.device, torch.float32))
-        wq = eng.weight("c1", (self.post_quant_conv.weight,), lambda t: pack_conv1x1(t, za.C))
         zq = eng.act(za.n, za.h, za.w, 8)
         zq.v.zero_()
-        eng.linear(za, wq, eng.f32("b", self.post_quant_conv.bias), out=zq.cols(0, self.post_quant_conv.out_channels))
-        return eng.to_nchw(self.decoder.run(eng, zq), self.decoder.out_ch)
+        with eng.scope(self.DEC_SCOPE):
+            wq, wq2 = eng.weight2("c1", (self.post_quant_conv.weight,), lambda t: pack_conv1x1(t, za.C))
+            eng.linear(za, wq, eng.f32("b", self.post_quant_conv.bias), out=zq.cols(0, self.post_quant_conv.out_channels), w2=wq2)
+            out = self.decoder.run(eng, zq)
+        return eng.to_nchw(out, self.decoder.out_ch)
 
     @torch.no_grad()
     def encode(self, x, return_encfea=False):
@@ -452,6 +458,7 @@ class AutoencoderKL(_AutoencoderBase):
 
 class VideoAutoencoderKLResi(_AutoencoderBase):
     """ldm/models/autoencoder.py:1564-1690: encode(x) -> (posterior, enc_fea); decode(z, enc_fea) -> frames."""
+    ENC_SCOPE, DEC_SCOPE = "vae_enc", "vae_dec"
 
     def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=[], image_key="image",
                  colorize_nlabels=None, monitor=None, fusion_w=1.0, freeze_dec=True, synthesis_data=False, use_usm=False,
@@ -490,12 +497,13 @@ class VideoAutoencoderKLResi(_AutoencoderBase):
         z = z.to(eng.device, torch.float32)
         fea = [f if isinstance(f, Act) else eng.from_nchw(f.to(eng.device, torch.float32)) for f in enc_fea]
         za = eng.from_nchw(z)
-        wq = eng.weight("c1", (self.post_quant_conv.weight,), lambda t: pack_conv1x1(t, za.C))
         # post_quant_conv output padded to 8 channels (zero weight rows) so conv_in sees Cin % 8 == 0
         zq = eng.act(za.n, za.h, za.w, 8)
         zq.v.zero_()
-        eng.linear(za, wq, eng.f32("b", self.post_quant_conv.bias), out=zq.cols(0, self.post_quant_conv.out_channels))
-        out = self.decoder.run(eng, zq, fea)
+        with eng.scope(self.DEC_SCOPE):
+            wq, wq2 = eng.weight2("c1", (self.post_quant_conv.weight,), lambda t: pack_conv1x1(t, za.C))
+            eng.linear(za, wq, eng.f32("b", self.post_quant_conv.bias), out=zq.cols(0, self.post_quant_conv.out_channels), w2=wq2)
+            out = self.decoder.run(eng, zq, fea)
         return eng.to_nchw(out, self.decoder.out_ch)
 
     def forward(self, input, latent, sample_posterior=True):

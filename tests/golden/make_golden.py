@@ -354,6 +354,63 @@ def gen_fullwidth():
          **{f"sc_{k}_norm": nrm(v) for k, v in scd.items()}, sc_8=scd["8"])
 
 
+def gen_workload(name="c2", S=4):
+    """BASELINE configs[1]-[4] at FULL width through the reference's own classes (tests/golden/cases.py lists the workloads): the
+    per-segment body of the script (oldcanvas_tile.py:429-471) — first-stage encode -> q_sample_respace -> model.sample /
+    sample_canvas -> video-VAE encode / decode (dec_w = 1 and the script's default 0.5) -> AdaIN -> clamp.  Latents are stored in
+    full, pixel tensors as strided slices + norms.  CPU minutes on 8 threads: c2 S=4 ~6, c2g S=4 ~6, c4 S=4 ~25, c2 S=50 ~40; not
+    part of the default run (`make_golden.py workload:c2:4`)."""
+    from cases import case_inputs
+    from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
+    ae = ref_import.ref("ldm.models.autoencoder")
+    cf = ref_import.ref("scripts.wavelet_color_fix")
+    uf = ref_import.ref("scripts.util_flow")
+    S = int(S)
+    c = case_inputs(name, S)
+    Tn, H, h, x, noise, st = c["T"], c["H"], c["h"], c["x"], c["noise"], c["stride"]
+    ucfg, scfg, dd = dict(UNET_FULL, num_frames=Tn), dict(STRUCT_FULL, num_frames=Tn), dict(VAE_DD_FULL, num_frames=Tn)
+    model, ddpm = build_ref_model(ucfg, scfg, dd, Tn)
+    vq = ae.VideoAutoencoderKLResi(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4, fusion_w=1.0,
+                                   freeze_dec=True, version=1).eval()
+    synth.fill_module_(vq, "vae")
+    sac, somac = respace(model, S)
+    post = model.first_stage_model.encode(x)
+    init = model.scale_factor * (post.mean + post.std * noise["posterior"])
+    ctx = model.cond_stage_model([""])
+    xT = model.q_sample_respace(x_start=init, t=torch.full((Tn,), 999).long(), sqrt_alphas_cumprod=sac,
+                                sqrt_one_minus_alphas_cumprod=somac, noise=noise["x_T"])
+    flows = masks = None
+    extra = {}
+    if c["ff"] is not None:
+        focc, bocc = uf.forward_backward_consistency_check(c["fb"], c["ff"])
+        flows, masks = (c["ff"][None], c["fb"][None]), (focc[None, :, None], bocc[None, :, None])
+        extra.update(focc=focc, bocc=bocc)
+    queue = [noise["steps"][i] for i in reversed(range(S))]                                # loop order i = S-1 .. 0
+    orig = ddpm.noise_like
+    ddpm.noise_like = lambda shape, device, repeat=False: queue.pop(0)
+    try:
+        kw = dict(cond=ctx, struct_cond=init, guidance_scale=-10.0, lr_images=None, flows=flows, masks=masks, batch_size=1,
+                  timesteps=S, time_replace=S, x_T=xT, return_intermediates=True, verbose=False)
+        if c["canvas"]:
+            x0, _ = model.sample_canvas(tile_size=64, tile_overlap=32, batch_size_sample=1, **kw)
+        else:
+            x0, _ = model.sample(**kw)
+    finally:
+        ddpm.noise_like = orig
+    print("sampled", flush=True)
+    del model
+    _, fea = vq.encode(x)
+    nrm = lambda t: np.array([float(t.double().norm()), float(t.double().mean())])
+    for w, sfx in ((1.0, ""), (0.5, "_w05")):
+        vq.decoder.fusion_w = w
+        dec = vq.decode(x0 * 1. / 0.18215, fea)
+        out = torch.clamp((cf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, min=0.0, max=1.0)
+        extra.update({f"dec{sfx}_s": dec[:, :, ::st, ::st].clone(), f"dec{sfx}_norm": nrm(dec), f"out{sfx}_s": out[:, :, ::st, ::st].clone(),
+                      f"out{sfx}_norm": nrm(out)})
+        del dec, out
+    save(f"g_work_{name}_S{S}", init=init, xT=xT, x0=x0, fea0_norm=nrm(fea[0]), fea1_norm=nrm(fea[1]), **extra)
+
+
 class _AD(dict):
     """dict with attribute access (the scripts read `config.model`, instantiate_from_config reads it as a dict)"""
     __getattr__ = dict.__getitem__
@@ -704,6 +761,9 @@ def gen_spliter():
 if __name__ == "__main__":
     if len(sys.argv) > 1:            # e.g. `make_golden.py raft`: regenerate selected fixtures only
         for what in sys.argv[1:]:
+            if what.startswith("workload:"):          # workload:<case>:<steps>
+                gen_workload(*what.split(":")[1:])
+                continue
             fn = globals()["gen_" + what]
             if what == "pstep":
                 fn(*build_ref_model())

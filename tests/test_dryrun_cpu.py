@@ -35,7 +35,8 @@ def dry(monkeypatch):
 
     def igemm(a, w, out, *, mode=0, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None, act=0, alpha=1.0,
               beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0, M=None, N=None, K=None,
-              tap_inner=0):
+              tap_inner=0, w2=None, **_):
+        assert w2 is None or (w2.shape == w.shape and w2.dtype == w.dtype)
         M = M if M is not None else out.shape[0]
         N = N if N is not None else w.shape[0]
         K = K if K is not None else w.shape[1]

@@ -142,6 +142,17 @@ def test_colorfix(hip):
     assert rel_l2(out.cpu(), ocf.wavelet_reconstruction(content, style)) < 1e-5
 
 
+@pytest.mark.parametrize("n,c,h,w", [(2, 3, 512, 512), (1, 3, 33, 31), (1, 2, 1100, 1100)])   # 16 chunks / unaligned planes / the 64-chunk cap
+def test_adain_chunked_planes(hip, n, c, h, w):
+    """AdaIN statistics over many blocks per plane (fp64 partial sums per 64 KiB chunk, combined in the apply kernel's prologue)"""
+    content = rnd(n, c, h, w, seed=14) * 0.4 + 0.1
+    style = rnd(n, c, h, w, seed=15) * 0.2 - 0.3
+    out = torch.empty(n, c, h, w, device=DEV)
+    work = torch.empty(512 * n * c + 8, dtype=torch.float32, device=DEV)
+    hip.adain(content.to(DEV), style.to(DEV), out, work)
+    assert rel_l2(out.cpu(), ocf.adaptive_instance_normalization(content, style)) < 1e-5
+
+
 def test_tile_ops(hip):
     n, c, H, W = 2, 4, 24, 32
     src = rnd(n, c, H, W, seed=13)

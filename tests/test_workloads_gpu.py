@@ -1,0 +1,67 @@
+"""BASELINE configs[1]-[4] at their stated workloads, FULL width, against outputs of the REFERENCE's own classes
+(tests/golden/g_work_<case>_S<steps>.npz, generated in the build container by tests/golden/make_golden.py::gen_workload; inputs are
+regenerated from the synth recipes in tests/golden/cases.py, so nothing of the reference travels):
+
+    c2  S=4, S=50   8 frames 512x512, flow warp off                      configs[1]; configs[4]: the T = 8 video decoder + AdaIN
+    c2g S=4         8 frames 512x512, flow-guided latent warp            configs[2]: one rank's share of the sharded 32-frame clip
+    c4  S=4         4 frames 1024x1024, guided aggregation sampling      configs[3]: sample_canvas, nine 64x64 latent tiles, overlap 32
+
+north_star tolerance: 1e-3 relative L2 on the OUTPUTS (sampled latents in full, HR frames on the stored strided slice), asserted at
+1e-3.  The script's default decoder blend (dec_w = 0.5) is checked on the same latents."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from cases import case_inputs  # noqa: E402
+from test_nets_gpu import G, record, rel_l2  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # BASELINE.json north_star: outputs within 1e-3 rel-L2 of the reference
+
+
+def _have(name):
+    return os.path.exists(os.path.join(HERE, "golden", name + ".npz"))
+
+
+@pytest.mark.parametrize("case,S", [("c2", 4), ("c2g", 4), ("c4", 4), ("c2", 50)])
+def test_workload_vs_reference(hip, case, S):
+    name = f"g_work_{case}_S{S}"
+    if not _have(name):
+        pytest.skip(f"{name}.npz not generated (make_golden.py workload:{case}:{S})")
+    from mgld_vsr_amd.flowops import adaptive_instance_normalization
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    g = G(name)
+    c = case_inputs(case, S)
+    Tn, H, st = c["T"], c["H"], c["stride"]
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=model_configs(Tn))
+    flows = masks = None
+    if c["ff"] is not None:
+        flows, masks = (c["ff"][None], c["fb"][None]), (g["focc"][None, :, None], g["bocc"][None, :, None])
+    out, lat = pipe.run_segment(c["x"], flows=flows, masks=masks, guidance_scale=-10.0, noise=c["noise"], return_latents=True,
+                                tile=(64, 32) if c["canvas"] else None)
+    assert out.shape == (Tn, 3, H, H) and bool(torch.isfinite(out).all())
+    got = {f"work_{case}_S{S}_latent": rel_l2(lat, g["x0"]), f"work_{case}_S{S}_frames": rel_l2(out[:, :, ::st, ::st], g["out_s"])}
+    # the script's default decoder blend (--dec_w 0.5) on the product's own latents
+    vq = pipe.vq_model
+    x = c["x"].cuda()
+    _, fea = vq.encode(x)
+    vq.decoder.fusion_w = 0.5
+    dec05 = vq.decode(lat * (1.0 / pipe.model.scale_factor), fea)
+    out05 = torch.clamp((adaptive_instance_normalization(dec05, x) + 1.0) / 2.0, 0.0, 1.0)
+    got[f"work_{case}_S{S}_frames_w05"] = rel_l2(out05[:, :, ::st, ::st], g["out_w05_s"])
+    # decoder alone on the REFERENCE's latents (single-evaluation figure, recorded)
+    vq.decoder.fusion_w = 1.0
+    dec = vq.decode(g["x0"].cuda() * (1.0 / pipe.model.scale_factor), fea)
+    got[f"work_{case}_S{S}_decoder_only"] = rel_l2(dec[:, :, ::st, ::st], g["dec_s"])
+    for k, v in got.items():
+        record(k, v)
+    assert got[f"work_{case}_S{S}_latent"] < TOL and got[f"work_{case}_S{S}_frames"] < TOL, got
+    assert got[f"work_{case}_S{S}_frames_w05"] < TOL, got
+    assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
