@@ -951,7 +951,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv3p_kernel(cons
 // and tap (dy, dx) of output pixel (y, x) reads low-res pixel ((y+dy-1)>>1, (x+dx-1)>>1); zero padding of the upsampled image falls on
 // out-of-image low-res pixels.  256-pixel tiles (16x16, 8x32) run eight waves of 64 pixels x 32 channels: 3 fragment reads per 2 MFMAs
 // instead of 2 per 1 and half the weight bytes per FLOP of the 128-pixel tiles.  Weights: the tiled layout of tap_inner = 2 only.
-template <int TY, int TX, int BN, int WM, int WN, bool UP2, int PF = 1>
+// NWB = 3 (round 3): a THIRD weight buffer.  With two, a block has one weight stage in flight while it computes on the other and drains
+// `vmcnt(0)` + barrier at every stage: the two blocks of a CU fall into step, both waiting for their DMA, then both computing (PMC round 2:
+// matrix pipe busy 37 %, waves parked 44 % on vmcnt / barrier).  With three, stage g + 2 is issued during stage g, the wait at the top of a
+// stage is COUNTED (`vmcnt(n)`: only what the stage reads must have landed, the newest weight stage — and the piece of the next slice's
+// patch issued with it — stay in flight across the raw `s_barrier`), so a stage's DMA has two stage times to land.  Only where the LDS
+// budget keeps the resident blocks per CU (8x32 x 64: 2 x 80 KiB = all 160 KiB; 16x16 x 128: one block either way; 16x16 x 64).
+template <int TY, int TX, int BN, int WM, int WN, bool UP2, int PF = 1, int NWB = 2>
 __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kernel(const MgldIGemm p, float* __restrict__ ws, int hchunk,
                                                                                   int tiles_x, int tiles_y, int order) {
   constexpr int BM = TY * TX;
@@ -967,6 +973,7 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
   constexpr int B_BASE = 2 * A_BYTES;
   static_assert(NW == 4 || NW == 8, "four or eight waves per block");
   static_assert(ASLOTS <= 3, "the patch must arrive within the three stages of a slice");
+  static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
   static_assert((TX & (TX - 1)) == 0 && TX >= 8 && (TY % 2) == 0 && BM % WM == 0 && BN % 64 == 0, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1092,20 +1099,32 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
 
   const int ns = h1 - h0;                     // channel slices of this block (of this K split)
   const int nv = two ? 2 * ns : ns;           // slice visits: residual pass, then main pass
+  // weight-stage issue cursor: stage (visit iv, kernel row idy) of slice ih goes into ring buffer ibuf (plain scalars in this scope)
+  int ih = h0, idy = 0, iv = 0, ibuf = 0;
+#define MGLD_Q_ISSUE_W()                                                          \
+  if (iv < nv) {                                                                  \
+    issue_b(ibuf, ih, idy, two && iv < ns);                                       \
+    ibuf = (ibuf + 1 == NWB) ? 0 : ibuf + 1;                                      \
+    if (++idy == 3) { idy = 0; ++iv; ih = (two && iv == ns) ? h0 : ih + 1; }      \
+  }
+  // DMA instructions this wave issues per weight stage / per patch slot (the counted waits of the three-buffer ring)
+  int nw_me = 0, na_me[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < BSLOTS; ++k) nw_me += (k * NW + wave < NPB) ? 1 : 0;
+#pragma unroll
+  for (int s = 0; s < ASLOTS; ++s) na_me[s] = (s * NW + wave < NPA) ? 1 : 0;
   if (h0 < h1) {
     MGLD_Q_ISSUE_A(0, 0)
     MGLD_Q_ISSUE_A(1, 0)
     MGLD_Q_ISSUE_A(2, 0)
-    issue_b(0, h0, 0, two);
+    MGLD_Q_ISSUE_W()
+    if constexpr (NWB == 3) { MGLD_Q_ISSUE_W() }
   }
   int cur = 0;
-  int h = h0;
   for (int v = 0; v < nv; ++v) {
     const int pa = v & 1;
     const bool more = (v + 1 < nv);
     const bool wrap = two && (v + 1 == ns);   // the next visit starts the main pass: its patch is slice h0 again
-    const int hn = wrap ? h0 : h + 1;
-    const bool lo = two && (v < ns), lo_next = two && (v + 1 < ns);
     if (two && v == ns) {                     // residual pass done: acc = w2_scale * (A W2^T), then A W^T accumulates on top
       const float sc2 = p.w2_scale;
 #pragma unroll
@@ -1121,15 +1140,31 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if constexpr (NWB == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      } else {
+        // in flight, oldest first: ..., W[g] (issued two stages ago), then last stage's issues: [patch slot s-1 of the NEXT slice, W[g+1]].
+        // This stage reads W[g] and (s == 0) the whole patch, whose last slot is one of last stage's issues: allow W[g+1], and
+        // for s != 0 also last stage's patch piece, to stay in flight.
+        int allow = (3 * v + s + 1 < 3 * nv) ? nw_me : 0;
+        if (s != 0 && more) allow += na_me[s - 1];
+        switch (allow) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) first
+      }
       if (more) {
         if (s == 0) { MGLD_Q_ISSUE_A(0, pa ^ 1) }
         if (s == 1) { MGLD_Q_ISSUE_A(1, pa ^ 1) }
         if (s == 2) { MGLD_Q_ISSUE_A(2, pa ^ 1) }
       }
-      if (s < 2) issue_b(cur ^ 1, h, s + 1, lo);
-      else if (more) issue_b(cur ^ 1, hn, 0, lo_next);
+      MGLD_Q_ISSUE_W()                         // NWB = 2: the next stage, into the buffer read last stage; NWB = 3: the one after
       const int abase = pa * A_BYTES;
       const int bb = B_BASE + cur * B_BYTES;
       // fragments of step u + PF are fetched from LDS while the MFMAs of step u run (PF + 1 register sets, static indices);
@@ -1153,11 +1188,11 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
           for (int mi = 0; mi < MI; ++mi)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u % (PF + 1)][ni], fa[u % (PF + 1)][mi], acc[ni][mi], 0, 0, 0);
       }
-      cur ^= 1;
+      cur = (cur + 1 == NWB) ? 0 : cur + 1;
     }
-    h = hn;
   }
 #undef MGLD_Q_ISSUE_A
+#undef MGLD_Q_ISSUE_W
   tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, 0, RowMap2D<TX>{frame * p.Hout * p.Wout, y0, x0, p.Hout, p.Wout}, bn0, wm, wn, wave,
                                 lane, acc, smem);
 }
@@ -1430,19 +1465,28 @@ int launch_conv3p(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
 //   6: 8x8 x 128, 32x32 (8 waves): the 8x8 UNet level, one tile per frame
 // (fragments prefetched TWO steps ahead — template parameter PF = 2 — measured identical to PF = 1 on every shape: not instantiated)
 constexpr int Q3_NVAR = 7;
-template <int TY, int TX, int BN, int WM, int WN, bool UP2>
+template <int TY, int TX, int BN, int WM, int WN, bool UP2, int NWB = 2>
 constexpr int conv3q_lds() {
   constexpr int PW = UP2 ? TX / 2 + 2 : TX + 2, PH = UP2 ? TY / 2 + 2 : TY + 2;
   constexpr int NPA = (PW * PH + 15) / 16, NW = (TY * TX / WM) * (BN / WN);
-  constexpr int stages = 2 * NPA * 1024 + 2 * 3 * BN * PB, epi = NW * 32 * (WN + 4) * 4;
+  constexpr int stages = 2 * NPA * 1024 + NWB * 3 * BN * PB, epi = NW * 32 * (WN + 4) * 4;
   return stages > epi ? stages : epi;
 }
+// weight buffers of variant `id`: three for the variants whose LDS budget keeps the resident blocks per CU (see the kernel); env
+// MGLD_CONV3Q_NWB = 2 forces the two-buffer form everywhere (A/B runs)
+inline int q3_nwb(int id, bool up2) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("MGLD_CONV3Q_NWB"); force = e ? atoi(e) : 0; }
+  if (force == 2 || up2) return 2;
+  return (id == 1 || id == 3 || id == 4) ? 3 : 2;
+}
 inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
+  const bool w3 = q3_nwb(id, up2) == 3;
   switch (id) {
-    case 1: *ty = 16; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<16, 16, 64, 64, 32, true>() : conv3q_lds<16, 16, 64, 64, 32, false>(); break;
+    case 1: *ty = 16; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<16, 16, 64, 64, 32, true>() : (w3 ? conv3q_lds<16, 16, 64, 64, 32, false, 3>() : conv3q_lds<16, 16, 64, 64, 32, false>()); break;
     case 2: *ty = 8; *tx = 16; *bn = 128; *lds = conv3q_lds<8, 16, 128, 64, 32, false>(); break;
-    case 3: *ty = 16; *tx = 16; *bn = 128; *lds = conv3q_lds<16, 16, 128, 64, 64, false>(); break;
-    case 4: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 32, false>(); break;
+    case 3: *ty = 16; *tx = 16; *bn = 128; *lds = w3 ? conv3q_lds<16, 16, 128, 64, 64, false, 3>() : conv3q_lds<16, 16, 128, 64, 64, false>(); break;
+    case 4: *ty = 8; *tx = 32; *bn = 64; *lds = w3 ? conv3q_lds<8, 32, 64, 64, 32, false, 3>() : conv3q_lds<8, 32, 64, 64, 32, false>(); break;
     case 5: *ty = 8; *tx = 16; *bn = 64; *lds = conv3q_lds<8, 16, 64, 64, 32, false>(); break;
     case 6: *ty = 8; *tx = 8; *bn = 128; *lds = conv3q_lds<8, 8, 128, 32, 32, false>(); break;
     default: *ty = 8; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<8, 16, 64, 32, 32, true>() : conv3q_lds<8, 16, 64, 32, 32, false>(); break;
@@ -1490,12 +1534,12 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   return true;
 }
 
-template <int TY, int TX, int BN, int WM, int WN, bool UP2, int PF = 1>
+template <int TY, int TX, int BN, int WM, int WN, bool UP2, int PF = 1, int NWB = 2>
 int launch_conv3q(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
-  constexpr int lds = conv3q_lds<TY, TX, BN, WM, WN, UP2>();
+  constexpr int lds = conv3q_lds<TY, TX, BN, WM, WN, UP2, NWB>();
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF, NWB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const int frames = p->M / (p->Hout * p->Wout);
@@ -1507,7 +1551,7 @@ int launch_conv3q(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
   if (forder == -2) { const char* e = getenv("MGLD_CONV3Q_ORDER"); forder = e ? atoi(e) : -1; }
   const double wbytes = 2.0 * p->N * p->K, abytes = 2.0 * p->M * p->Cin / (UP2 ? 4 : 1);
   const int order = forder >= 0 ? forder : (wbytes > 2.0 * abytes ? 1 : 0);
-  hipLaunchKernelGGL((conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF>), grid, dim3(THREADS), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk,
+  hipLaunchKernelGGL((conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF, NWB>), grid, dim3(THREADS), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk,
                      tiles_x, tiles_y, order);
   if (splits > 1) {
     const int64_t total = (int64_t)p->M * ((p->N + 3) >> 2);
@@ -1520,11 +1564,12 @@ int launch_conv3q(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
 
 int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int hchunk) {
   if (p->up2) return id == 1 ? launch_conv3q<16, 16, 64, 64, 32, true>(p, s, splits, hchunk) : launch_conv3q<8, 16, 64, 32, 32, true>(p, s, splits, hchunk);
+  const bool w3 = q3_nwb(id, false) == 3;
   switch (id) {
-    case 1: return launch_conv3q<16, 16, 64, 64, 32, false>(p, s, splits, hchunk);
+    case 1: return w3 ? launch_conv3q<16, 16, 64, 64, 32, false, 1, 3>(p, s, splits, hchunk) : launch_conv3q<16, 16, 64, 64, 32, false>(p, s, splits, hchunk);
     case 2: return launch_conv3q<8, 16, 128, 64, 32, false>(p, s, splits, hchunk);
-    case 3: return launch_conv3q<16, 16, 128, 64, 64, false>(p, s, splits, hchunk);
-    case 4: return launch_conv3q<8, 32, 64, 64, 32, false>(p, s, splits, hchunk);
+    case 3: return w3 ? launch_conv3q<16, 16, 128, 64, 64, false, 1, 3>(p, s, splits, hchunk) : launch_conv3q<16, 16, 128, 64, 64, false>(p, s, splits, hchunk);
+    case 4: return w3 ? launch_conv3q<8, 32, 64, 64, 32, false, 1, 3>(p, s, splits, hchunk) : launch_conv3q<8, 32, 64, 64, 32, false>(p, s, splits, hchunk);
     case 5: return launch_conv3q<8, 16, 64, 64, 32, false>(p, s, splits, hchunk);
     case 6: return launch_conv3q<8, 8, 128, 32, 32, false>(p, s, splits, hchunk);
     default: return launch_conv3q<8, 16, 64, 32, 32, false>(p, s, splits, hchunk);
@@ -1555,8 +1600,8 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
   int cfg, splits, kchunk;
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
     static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32}};
-    snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s, %d>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false",
-             1);
+    snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s, %d, %d>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false",
+             1, q3_nwb(cfg, p->up2 != 0));
     return splits;
   }
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) {

@@ -10,8 +10,9 @@ outside the per-step hot path.  Two modes:
   `model.transformer.resblocks.N.{ln_1, attn.in_proj_*, attn.out_proj, ln_2, mlp.c_fc, mlp.c_proj}`, `model.ln_final`,
   `model.text_projection`, `model.logit_scale`), so the `cond_stage_model.*` entries of the public checkpoint load as they
   are, and `forward` runs it on the C-ABI kernels (LayerNorm, igemm with fused bias / GELU / residual, fp32 logits +
-  causal row softmax).  open_clip (the tokenizer's BPE vocabulary) is not available here: the empty prompt — the only one the
-  inference scripts use — tokenises to [SOT, EOT, 0, ...] without it; other prompts need `open_clip` importable.
+  causal row softmax).  Tokenisation: mgld_vsr_amd/tokenizer.py restates the CLIP BPE algorithm; its merge table is open_clip's
+  data file (found in an installed open_clip / clip package or via $MGLD_BPE_VOCAB).  The empty prompt — the only one the
+  inference scripts use — tokenises to [SOT, EOT, 0, ...] without the table.
 """
 import warnings
 
@@ -103,13 +104,23 @@ class FrozenOpenCLIPEmbedder(nn.Module):
             if t == "":
                 toks[i, 0], toks[i, 1] = self.vocab_size - 2, self.vocab_size - 1
                 continue
-            try:
-                import open_clip
-            except ImportError as e:
-                raise NotImplementedError("only the empty prompt can be tokenised without open_clip's BPE vocabulary "
-                                          "(the inference scripts use no other)") from e
-            toks[i] = open_clip.tokenize([t])[0]
+            toks[i] = self._bpe().tokenize([t], self.max_length)[0]
         return toks
+
+    def _bpe(self):
+        """the BPE tokenizer over open_clip's merge table (mgld_vsr_amd/tokenizer.py: the algorithm is restated there, the table is
+        looked up in $MGLD_BPE_VOCAB / an installed open_clip or clip package); built on first use by a non-empty prompt"""
+        tk = getattr(self, "_tokenizer", None)
+        if tk is None:
+            from .tokenizer import SimpleTokenizer, find_vocab
+            path = find_vocab()
+            if path is None:
+                raise NotImplementedError("non-empty prompts need open_clip's BPE merge table (bpe_simple_vocab_16e6.txt.gz): set "
+                                          "MGLD_BPE_VOCAB or install open_clip; the empty prompt — the only one the inference "
+                                          "scripts use — works without it")
+            tk = self._tokenizer = SimpleTokenizer(path, vocab_size=self.vocab_size)
+            assert tk.eot == self.vocab_size - 1, "BPE table and text tower disagree on the vocabulary size"
+        return tk
 
     # ---- forward ------------------------------------------------------------------------------------------------
     @torch.no_grad()

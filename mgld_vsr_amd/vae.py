@@ -321,32 +321,38 @@ class VideoDecoder_Mix(nn.Module):
     def run(self, eng, z, enc_fea):
         """z: Act [n,h,w,8] (post_quant_conv output, padded); enc_fea: [Act level1 (H/2), Act level2 (H/4)].
         Returns fp32 token-major output Act [n*H*W, out_ch]."""
-        h = _conv3(eng, self.conv_in, z)
-        h = self.mid.block_1.run(eng, h)
-        h = self.temporal_mixing.run(eng, h)
-        h = self.mid.attn_1.run(eng, h)
-        h = self.mid.block_2.run(eng, h)
+        # (precision scopes, engine.w2_scopes: vae_dec_mid / vae_dec_up<level> / vae_dec_fuse / vae_dec_out inside the caller's vae_dec)
+        with eng.scope("vae_dec_mid"):
+            h = _conv3(eng, self.conv_in, z)
+            h = self.mid.block_1.run(eng, h)
+            h = self.temporal_mixing.run(eng, h)
+            h = self.mid.attn_1.run(eng, h)
+            h = self.mid.block_2.run(eng, h)
         for lvl in reversed(range(self.num_resolutions)):
             fuse = lvl != self.num_resolutions - 1 and lvl != 0
             nb = self.num_res_blocks + 1
             cat = None
-            for b in range(nb):
-                h = self.up[lvl].block[b].run(eng, h)
-                o = None
-                if fuse and b == nb - 1:
-                    ef = enc_fea[lvl - 1]
-                    cat = eng.act(h.n, h.h, h.w, ef.C + h.C)
-                    hip.copy2d(ef.v, cat.v[:, :ef.C])
-                    eng.launches += 1
-                    o = cat.cols(ef.C, ef.C + h.C)
-                h = self.up[lvl].temporal_mixing[b].run(eng, h, out=o)
+            with eng.scope(f"vae_dec_up{lvl}"):
+                for b in range(nb):
+                    h = self.up[lvl].block[b].run(eng, h)
+                    o = None
+                    if fuse and b == nb - 1:
+                        ef = enc_fea[lvl - 1]
+                        cat = eng.act(h.n, h.h, h.w, ef.C + h.C)
+                        hip.copy2d(ef.v, cat.v[:, :ef.C])
+                        eng.launches += 1
+                        o = cat.cols(ef.C, ef.C + h.C)
+                    h = self.up[lvl].temporal_mixing[b].run(eng, h, out=o)
             if fuse:
-                h = getattr(self, f"fusion_layer_{lvl}").run(eng, cat, self.fusion_w)
+                with eng.scope("vae_dec_fuse"):
+                    h = getattr(self, f"fusion_layer_{lvl}").run(eng, cat, self.fusion_w)
             if lvl != 0:
-                h = self.up[lvl].upsample.run(eng, h)
+                with eng.scope(f"vae_dec_up{lvl}"):
+                    h = self.up[lvl].upsample.run(eng, h)
         t = _gn(eng, self.norm_out, h, True)
         out = Act(eng.arena.alloc((h.rows, self.out_ch), torch.float32), h.n, h.h, h.w)
-        return _conv3(eng, self.conv_out, t, out=out)
+        with eng.scope("vae_dec_out"):
+            return _conv3(eng, self.conv_out, t, out=out)
 
 
 class DiagonalGaussianDistribution(object):

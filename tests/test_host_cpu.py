@@ -478,3 +478,81 @@ def test_frame_writer_writes_everything_and_reraises(tmp_path):
     with pytest.raises(FileNotFoundError):
         w.close()
     assert (tmp_path / "ok.png").exists()
+
+
+# ---- BPE tokenizer (modules.py:174 `open_clip.tokenize`) ----------------------------------------------------------
+_TOY_MERGES = [("h", "e"), ("l", "l"), ("he", "ll"), ("hell", "o</w>"), ("w", "o"), ("r", "l"), ("wo", "rl"), ("worl", "d</w>"),
+               ("a", "n"), ("an", "d</w>"), ("t", "h"), ("th", "e</w>"), ("i", "n"), ("in", "g</w>"), ("e", "r"), ("o", "n</w>")]
+
+
+def _bpe_bruteforce(word, merges):
+    """independent statement of greedy BPE: repeatedly merge the adjacent pair of lowest rank (first occurrence class: all occurrences,
+    left to right), until no adjacent pair is in the table"""
+    sym = list(word[:-1]) + [word[-1] + "</w>"]
+    rank = {m: i for i, m in enumerate(merges)}
+    while len(sym) > 1:
+        pairs = [(rank.get((a, b), 1 << 30), i) for i, (a, b) in enumerate(zip(sym[:-1], sym[1:]))]
+        best = min(pairs)[0]
+        if best == 1 << 30:
+            break
+        a, b = merges[best]
+        out, i = [], 0
+        while i < len(sym):
+            if i < len(sym) - 1 and sym[i] == a and sym[i + 1] == b:
+                out.append(a + b)
+                i += 2
+            else:
+                out.append(sym[i])
+                i += 1
+        sym = out
+    return sym
+
+
+def test_bpe_tokenizer_algorithm():
+    from mgld_vsr_amd.tokenizer import SimpleTokenizer, bytes_to_unicode
+    tk = SimpleTokenizer(merges=_TOY_MERGES, vocab_size=256 + 256 + len(_TOY_MERGES) + 2)
+    b2u = bytes_to_unicode()
+    assert len(b2u) == 256 and len(set(b2u.values())) == 256 and b2u[ord("a")] == "a" and b2u[ord(" ")] != " "
+    assert len(tk.encoder) == 512 + len(_TOY_MERGES) + 2 and tk.sot == len(tk.encoder) - 2 and tk.eot == len(tk.encoder) - 1
+    # whole words that are in the table become ONE token; case and whitespace are normalised; punctuation splits off
+    ids = tk.encode("  Hello   WORLD!! ")
+    assert ids[0] == tk.encoder["hello</w>"] and ids[1] == tk.encoder["world</w>"] and tk.decode(ids) == "hello world !! "
+    # greedy lowest-rank merging == the brute-force statement, on random lower-case words
+    import random
+    rnd = random.Random(7)
+    for _ in range(300):
+        wrd = "".join(rnd.choice("helowrdantig") for _ in range(rnd.randint(1, 9)))
+        assert tk.bpe(wrd).split(" ") == _bpe_bruteforce(wrd, _TOY_MERGES), wrd
+    # contractions and digits follow the CLIP pattern: 's is its own pre-token (two symbols here: the toy table has no merge for
+    # it), every digit is its own token
+    assert [tk.decoder[i] for i in tk.encode("the ring's 42")] == ["the</w>", "r", "ing</w>", "'", "s</w>", "4</w>", "2</w>"]
+    # utf-8 bytes outside ASCII go through the byte table and round-trip
+    assert tk.decode(tk.encode("café 中")) == "café 中 "
+    # tokenize: [SOT, ..., EOT, 0 ...]; the empty prompt is [SOT, EOT]; over-long prompts are cut and still end in EOT
+    t = tk.tokenize(["", "hello and the world", "hello " * 100], context_length=12)
+    assert t.dtype == torch.long and t.shape == (3, 12)
+    assert t[0].tolist() == [tk.sot, tk.eot] + [0] * 10
+    assert t[1, 0] == tk.sot and t[1, 5] == tk.eot and int((t[1] != 0).sum()) == 6
+    assert t[2, 0] == tk.sot and t[2, -1] == tk.eot and bool((t[2, 1:-1] == tk.encoder["hello</w>"]).all())
+
+
+def test_text_embedder_tokenizes_with_a_merge_table_file(tmp_path, monkeypatch):
+    """the embedder's tokenize(): empty prompt without any table; other prompts through the gzip'ed merge table open_clip ships (same file
+    format: a header line, then one merge per line), located through $MGLD_BPE_VOCAB"""
+    import gzip
+    from ldm.modules.encoders.modules import FrozenOpenCLIPEmbedder
+    from mgld_vsr_amd import tokenizer
+    vs = 512 + len(_TOY_MERGES) + 2
+    emb = FrozenOpenCLIPEmbedder(context_dim=64, vocab_size=vs)
+    assert emb.tokenize([""])[0].tolist()[:3] == [vs - 2, vs - 1, 0]
+    monkeypatch.delenv("MGLD_BPE_VOCAB", raising=False)
+    if tokenizer.find_vocab() is None:
+        with pytest.raises(NotImplementedError):
+            emb.tokenize(["hello"])
+    path = tmp_path / tokenizer.VOCAB_FILE
+    with gzip.open(path, "wt", encoding="utf-8") as fh:
+        fh.write('"bpe_simple_vocab_16e6.txt#version: 0.2\n' + "\n".join(" ".join(m) for m in _TOY_MERGES) + "\nz z\n")   # one line past the cut
+    monkeypatch.setenv("MGLD_BPE_VOCAB", str(path))
+    emb2 = FrozenOpenCLIPEmbedder(context_dim=64, vocab_size=vs)
+    t = emb2.tokenize(["Hello world", ""])
+    assert t.shape == (2, 77) and t[0, :4].tolist() == [vs - 2, 512 + 3, 512 + 7, vs - 1] and t[1, :2].tolist() == [vs - 2, vs - 1]
