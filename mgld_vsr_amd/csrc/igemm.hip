@@ -972,8 +972,8 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
   constexpr int BSUB = BN * PB, B_BYTES = 3 * BSUB, NPB = 3 * BN / 16, BSLOTS = (NPB + NW - 1) / NW;
   constexpr int B_BASE = 2 * A_BYTES;
   static_assert(NW == 4 || NW == 8, "four or eight waves per block");
-  static_assert(ASLOTS <= 3, "the patch must arrive within the three stages of a slice");
-  static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
+  static_assert(ASLOTS <= 6, "the patch must arrive within the three stages of a slice (at most two pieces per wave and stage)");
+  static_assert(NWB == 2 || (NWB == 3 && ASLOTS <= 3), "two or three weight buffers (three: one patch piece per wave and stage)");
   static_assert((TX & (TX - 1)) == 0 && TX >= 8 && (TY % 2) == 0 && BM % WM == 0 && BN % 64 == 0, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1112,11 +1112,14 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
 #pragma unroll
   for (int k = 0; k < BSLOTS; ++k) nw_me += (k * NW + wave < NPB) ? 1 : 0;
 #pragma unroll
-  for (int s = 0; s < ASLOTS; ++s) na_me[s] = (s * NW + wave < NPA) ? 1 : 0;
+  for (int s = 0; s < (ASLOTS < 3 ? ASLOTS : 3); ++s) na_me[s] = (s * NW + wave < NPA) ? 1 : 0;
   if (h0 < h1) {
     MGLD_Q_ISSUE_A(0, 0)
     MGLD_Q_ISSUE_A(1, 0)
     MGLD_Q_ISSUE_A(2, 0)
+    MGLD_Q_ISSUE_A(3, 0)
+    MGLD_Q_ISSUE_A(4, 0)
+    MGLD_Q_ISSUE_A(5, 0)
     MGLD_Q_ISSUE_W()
     if constexpr (NWB == 3) { MGLD_Q_ISSUE_W() }
   }
@@ -1159,10 +1162,10 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) first
       }
-      if (more) {
-        if (s == 0) { MGLD_Q_ISSUE_A(0, pa ^ 1) }
-        if (s == 1) { MGLD_Q_ISSUE_A(1, pa ^ 1) }
-        if (s == 2) { MGLD_Q_ISSUE_A(2, pa ^ 1) }
+      if (more) {     // (four-wave blocks with large patches carry two pieces per wave and stage: slots s and s + 3)
+        if (s == 0) { MGLD_Q_ISSUE_A(0, pa ^ 1) MGLD_Q_ISSUE_A(3, pa ^ 1) }
+        if (s == 1) { MGLD_Q_ISSUE_A(1, pa ^ 1) MGLD_Q_ISSUE_A(4, pa ^ 1) }
+        if (s == 2) { MGLD_Q_ISSUE_A(2, pa ^ 1) MGLD_Q_ISSUE_A(5, pa ^ 1) }
       }
       MGLD_Q_ISSUE_W()                         // NWB = 2: the next stage, into the buffer read last stage; NWB = 3: the one after
       const int abase = pa * A_BYTES;
@@ -1463,8 +1466,10 @@ int launch_conv3p(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
 //   0: 8x16 x 64, 32x32 (8 waves)      1: 16x16 x 64, 64x32 (8 waves)     2: 8x16 x 128, 64x32 (8 waves)
 //   3: 16x16 x 128, 64x64 (8 waves)    4: 8x32 x 64, 64x32 (8 waves)      5: 8x16 x 64, 64x32 (4 waves)
 //   6: 8x8 x 128, 32x32 (8 waves): the 8x8 UNet level, one tile per frame
+//   7: 8x32 x 64, 64x64 (4 waves)      8: 8x32 x 128, 64x64 (8 waves)    (round 3: 2 x 2 MFMA tiles per wave = 1 KiB of LDS fragment
+//      reads per MFMA instead of 1.5: the 64x32 wave tiles run at the LDS read bandwidth)
 // (fragments prefetched TWO steps ahead — template parameter PF = 2 — measured identical to PF = 1 on every shape: not instantiated)
-constexpr int Q3_NVAR = 7;
+constexpr int Q3_NVAR = 9;
 template <int TY, int TX, int BN, int WM, int WN, bool UP2, int NWB = 2>
 constexpr int conv3q_lds() {
   constexpr int PW = UP2 ? TX / 2 + 2 : TX + 2, PH = UP2 ? TY / 2 + 2 : TY + 2;
@@ -1472,12 +1477,13 @@ constexpr int conv3q_lds() {
   constexpr int stages = 2 * NPA * 1024 + NWB * 3 * BN * PB, epi = NW * 32 * (WN + 4) * 4;
   return stages > epi ? stages : epi;
 }
-// weight buffers of variant `id`: three for the variants whose LDS budget keeps the resident blocks per CU (see the kernel); env
-// MGLD_CONV3Q_NWB = 2 forces the two-buffer form everywhere (A/B runs)
+// weight buffers of variant `id`: env MGLD_CONV3Q_NWB = 3 selects the three-buffer ring for the variants whose LDS budget keeps the
+// resident blocks per CU (see the kernel); default two
 inline int q3_nwb(int id, bool up2) {
   static int force = -1;
   if (force < 0) { const char* e = getenv("MGLD_CONV3Q_NWB"); force = e ? atoi(e) : 0; }
-  if (force == 2 || up2) return 2;
+  // measured (profiles/r03_conv3q_nwb.txt): the third buffer is 1-3 % slower launch by launch, 0.5 % end to end -> opt-in only
+  if (force != 3 || up2) return 2;
   return (id == 1 || id == 3 || id == 4) ? 3 : 2;
 }
 inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
@@ -1489,6 +1495,8 @@ inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
     case 4: *ty = 8; *tx = 32; *bn = 64; *lds = w3 ? conv3q_lds<8, 32, 64, 64, 32, false, 3>() : conv3q_lds<8, 32, 64, 64, 32, false>(); break;
     case 5: *ty = 8; *tx = 16; *bn = 64; *lds = conv3q_lds<8, 16, 64, 64, 32, false>(); break;
     case 6: *ty = 8; *tx = 8; *bn = 128; *lds = conv3q_lds<8, 8, 128, 32, 32, false>(); break;
+    case 7: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 64, false>(); break;
+    case 8: *ty = 8; *tx = 32; *bn = 128; *lds = conv3q_lds<8, 32, 128, 64, 64, false>(); break;
     default: *ty = 8; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<8, 16, 64, 32, 32, true>() : conv3q_lds<8, 16, 64, 32, 32, false>(); break;
   }
 }
@@ -1572,6 +1580,8 @@ int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int h
     case 4: return w3 ? launch_conv3q<8, 32, 64, 64, 32, false, 1, 3>(p, s, splits, hchunk) : launch_conv3q<8, 32, 64, 64, 32, false>(p, s, splits, hchunk);
     case 5: return launch_conv3q<8, 16, 64, 64, 32, false>(p, s, splits, hchunk);
     case 6: return launch_conv3q<8, 8, 128, 32, 32, false>(p, s, splits, hchunk);
+    case 7: return launch_conv3q<8, 32, 64, 64, 64, false>(p, s, splits, hchunk);
+    case 8: return launch_conv3q<8, 32, 128, 64, 64, false>(p, s, splits, hchunk);
     default: return launch_conv3q<8, 16, 64, 32, 32, false>(p, s, splits, hchunk);
   }
 }
@@ -1599,7 +1609,8 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
   MGLD_REQUIRE(p && buf && buflen > 0, "igemm_kernel_name: null");
   int cfg, splits, kchunk;
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
-    static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32}};
+    static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32},
+                                      {8, 32, 64, 64, 64}, {8, 32, 128, 64, 64}};
     snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s, %d, %d>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false",
              1, q3_nwb(cfg, p->up2 != 0));
     return splits;
@@ -1654,7 +1665,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
                  "igemm: tap_inner needs a gather mode with Cin % 64 == 0 and no upsample fold");
   if (p->W2) {
     MGLD_REQUIRE((((uintptr_t)p->W2) & 15) == 0 && p->w2_scale > 0.f, "igemm: W2 must be 16-byte aligned with a positive w2_scale");
-    MGLD_REQUIRE(p->tune != 9, "igemm: the register-staged LINEAR variant does not take W2");
+    MGLD_REQUIRE(!(p->mode == MGLD_MODE_LINEAR && p->tune == 9), "igemm: the register-staged LINEAR variant does not take W2");
   }
   if (p->rowvec) MGLD_REQUIRE(p->rows_per_frame > 0, "igemm: rows_per_frame");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");

@@ -483,7 +483,12 @@ class LatentDiffusionVSRTextWT(nn.Module):
 
     @torch.no_grad()
     def _sample_loop(self, cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                     return_intermediates, log_every_t, noise, tile, use_graph=True):
+                     return_intermediates, log_every_t, noise, tile, use_graph=True, hooks=None):
+        """hooks: the option branches of the reference loop (ddpm.py:4501-4599) that sit BETWEEN steps — start_T (skip the schedule
+        indices above a timestep), mask + x0 (inpainting blend with a re-noised x0 after every step; optional mask_noise
+        [steps, ...] instead of fresh draws), adain_fea (latent-space AdaIN after the last step), callback(i) /
+        img_callback(img, i).  They run as stream-ordered work between the replays of the captured step graph."""
+        hooks = {k: v for k, v in (hooks or {}).items() if v is not None}
         eng = self.engine()
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=eng.device)
@@ -507,9 +512,16 @@ class LatentDiffusionVSRTextWT(nn.Module):
             lat = struct_cond.to(dev, torch.float32).contiguous()
             ctx = cond["c_crossattn"][0] if isinstance(cond, dict) else (cond[0] if isinstance(cond, list) else cond)
             ctx = ctx.to(dev, torch.float32)[:1].contiguous()
+            idxs = list(reversed(range(S)))
+            if "start_T" in hooks:       # ddpm.py:4541-4550: `continue` while the step's (original) timestep is above start_T
+                idxs = [i for i in idxs if (self.ori_timesteps[i] if use_t_replace else i) <= hooks["start_T"]]
+            if "mask" in hooks:
+                assert "x0" in hooks, "mask needs x0 (ddpm.py:4522-4524)"
+                m_mask, m_x0 = hooks["mask"].to(dev, torch.float32), hooks["x0"].to(dev, torch.float32)
+                assert m_x0.shape[2:3] == m_mask.shape[2:3]
             st = {
                 "x": x, "coef": self._coef_table(S, use_t_replace).to(dev), "noise": noise, "noise_stride": x.numel(),
-                "step_idx": torch.tensor([S - 1], dtype=torch.int32, device=dev), "tvals": torch.zeros(1, device=dev),
+                "step_idx": torch.tensor([idxs[0] if idxs else 0], dtype=torch.int32, device=dev), "tvals": torch.zeros(1, device=dev),
                 "ctx": self.model.diffusion_model.context_cache(eng, ctx), "guided": flows is not None,
                 "gscale": float(guidance_scale), "tiles": None,
             }
@@ -562,7 +574,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
             intermediates = [x.clone()]
             graph = None
             eng.pieces = None
-            for k, i in enumerate(reversed(range(S))):
+            for k, i in enumerate(idxs):
                 if self.precompute_structcond and k % Wn == 0:  # a new hoisting window: schedule indices i .. i-Wn+1
                     self._precompute_structcond(eng, st, lat_in, i, max(0, i - Wn + 1))
                     if hoist_spade and k > 0:
@@ -598,8 +610,20 @@ class LatentDiffusionVSRTextWT(nn.Module):
                             graph.end()
                             eng.arena.frozen = False
                     graph.launch()
+                if hooks:
+                    if "adain_fea" in hooks and i < 1:          # ddpm.py:4565-4567
+                        from .flowops import adaptive_instance_normalization
+                        x.copy_(adaptive_instance_normalization(x, hooks["adain_fea"].to(dev, torch.float32)))
+                    if "mask" in hooks:                         # ddpm.py:4568-4570: img = q_sample(x0, ts) * mask + (1 - mask) * img
+                        mn = hooks["mask_noise"][i].to(dev, torch.float32) if "mask_noise" in hooks else None
+                        img_orig = self.q_sample(m_x0, torch.full((max(1, T_total // self.num_frames),), i, dtype=torch.long), noise=mn)
+                        x.copy_(img_orig * m_mask + (1.0 - m_mask) * x)
                 if return_intermediates and (i % log_every_t == 0 or i == S - 1):
                     intermediates.append(x.clone())
+                if "callback" in hooks:
+                    hooks["callback"](i)
+                if "img_callback" in hooks:
+                    hooks["img_callback"](x.clone(), i)
             self.last_launches_per_step = eng.launches
             self.last_graph_pieces = eng.pieces.n_graphs if eng.pieces is not None else (1 if graph is not None else 0)
             eng.pieces = None
@@ -721,26 +745,29 @@ class LatentDiffusionVSRTextWT(nn.Module):
                use_graph=True, **kwargs):
         """ddpm.py:4696-4719 -> p_sample_loop.  Extra kwargs: `noise` [steps,T,C,h,w] (injected noise indexed by
         the schedule index; the reference draws randn per step) and `use_graph`."""
-        self._check_unsupported(lr_images=lr_images, mask=mask, x0=x0, adain_fea=adain_fea, interfea_path=interfea_path,
-                                start_T=start_T)
+        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
         if shape is None:
             shape = tuple(struct_cond.shape) if x_T is None else tuple(x_T.shape)
         if cond is not None and not isinstance(cond, (dict, list)):
             cond = cond[:batch_size]
+        hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, start_T=start_T, mask_noise=kwargs.get("mask_noise"),
+                     callback=kwargs.get("callback"), img_callback=kwargs.get("img_callback"))
         return self._sample_loop(cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, None, noise, None, use_graph)
+                                 return_intermediates, None, noise, None, use_graph, hooks=hooks)
 
     @torch.no_grad()
     def p_sample_loop(self, cond, struct_cond, shape, guidance_scale=-1.0, lr_images=None, flows=None, masks=None,
                       return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None, quantize_denoised=False,
                       mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, time_replace=None, adain_fea=None,
                       interfea_path=None):
-        """ddpm.py:4501-4616, the loop `sample` enters: same arguments; the whole loop runs as the captured step graph, so the
-        per-step hooks (callback / img_callback) and the inpainting / feature-dump options are refused rather than ignored."""
-        self._check_unsupported(lr_images=lr_images, callback=callback, mask=mask, x0=x0, img_callback=img_callback,
-                                start_T=start_T, adain_fea=adain_fea, interfea_path=interfea_path)
+        """ddpm.py:4501-4616, the loop `sample` enters: same arguments.  A step runs as the captured step graph; the options that act
+        BETWEEN steps (start_T, mask / x0 inpainting, adain_fea, callback / img_callback) run as stream-ordered work between the
+        replays.  interfea_path (PCA pictures of the struct-cond features, a debugging aid: ddpm.py:4574-4597) and lr_images (another
+        guidance term, compute_temporal_condition_v2) are refused rather than ignored."""
+        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
+        hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, start_T=start_T, callback=callback, img_callback=img_callback)
         return self._sample_loop(cond, struct_cond, tuple(shape), guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, log_every_t, None, None, True)
+                                 return_intermediates, log_every_t, None, None, True, hooks=hooks)
 
     @torch.no_grad()
     def p_sample_loop_canvas(self, cond, struct_cond, shape, guidance_scale=-1.0, lr_images=None, flows=None, masks=None,
@@ -750,10 +777,10 @@ class LatentDiffusionVSRTextWT(nn.Module):
         """ddpm.py:4619-4693, the loop `sample_canvas` enters (`batch_size` = tiles per UNet pass in the reference; here every
         tile of a step goes through one pass)."""
         assert tile_size is not None
-        self._check_unsupported(lr_images=lr_images, callback=callback, mask=mask, x0=x0, img_callback=img_callback,
-                                start_T=start_T, adain_fea=adain_fea, interfea_path=interfea_path)
+        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
+        hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, start_T=start_T, callback=callback, img_callback=img_callback)
         return self._sample_loop(cond, struct_cond, tuple(shape), guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, log_every_t, None, (tile_size, tile_overlap), True)
+                                 return_intermediates, log_every_t, None, (tile_size, tile_overlap), True, hooks=hooks)
 
     @torch.no_grad()
     def sample_canvas(self, cond, struct_cond, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, batch_size=16,
@@ -762,8 +789,10 @@ class LatentDiffusionVSRTextWT(nn.Module):
                       tile_overlap=32, batch_size_sample=4, log_every_t=None, noise=None, use_graph=True, **kwargs):
         """ddpm.py:4722-4746 -> p_sample_loop_canvas: aggregation sampling over overlapping latent tiles.  All tiles
         of a step are batched into one struct-cond + UNet pass (each tile is an independent clip)."""
-        self._check_unsupported(lr_images=lr_images, mask=mask, x0=x0, adain_fea=adain_fea, interfea_path=interfea_path)
+        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
         if shape is None:
             shape = tuple(struct_cond.shape) if x_T is None else tuple(x_T.shape)
+        hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, mask_noise=kwargs.get("mask_noise"), callback=kwargs.get("callback"),
+                     img_callback=kwargs.get("img_callback"))
         return self._sample_loop(cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, log_every_t, noise, (tile_size, tile_overlap), use_graph)
+                                 return_intermediates, log_every_t, noise, (tile_size, tile_overlap), use_graph, hooks=hooks)

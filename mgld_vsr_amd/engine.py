@@ -113,7 +113,10 @@ def split_residual(w32, scale=None):
 #   first     the first-stage (image) encoder that produces the init latent / struct-cond input
 #   unet_io   the UNet's input_blocks.0 and out convolutions
 #   unet      every contraction of the UNet and the struct-cond encoder
-W2_DEFAULT = "vae_dec"
+#   vae_dec_mid / vae_dec_up<0..3> / vae_dec_fuse / vae_dec_out   parts of the video decoder (level 0 = 512^2)
+# Default (measured on the full-width 8 x 512^2 workload, profiles/r03_w2_scopes_*: frame error -4.5 %, latent -4 % for +1.4 % segment
+# time; the whole decoder would be -9 % for +4.7 %, the fusion layers alone +1.9 % time for -0.3 %):
+W2_DEFAULT = "vae_dec_mid,vae_dec_up2,vae_dec_up3,vae_dec_out,unet_io"
 
 
 def w2_scopes():

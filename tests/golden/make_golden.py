@@ -411,6 +411,48 @@ def gen_workload(name="c2", S=4):
     save(f"g_work_{name}_S{S}", init=init, xT=xT, x0=x0, fea0_norm=nrm(fea[0]), fea1_norm=nrm(fea[1]), **extra)
 
 
+def gen_sample_opts(model=None, ddpm=None):
+    """The option branches of p_sample_loop that sit between steps (ddpm.py:4501-4599) on the reduced model, 4-step schedule, unguided:
+    start_T (skip the indices whose original timestep is above it), mask + x0 (inpainting blend with q_sample(x0, ts): its randn_like
+    draws come from the global generator, seeded here and regenerated on the test side), adain_fea (latent-space AdaIN after the
+    last step), callback / img_callback (call order + the images passed)."""
+    if model is None:
+        model, ddpm = build_ref_model()
+    S, h, w = 4, 16, 16
+    respace(model, S)
+    ctx = model.cond_stage_model([""])
+    lat = synth.synth_tensor("opts/lat", (T, 4, h, w), 0.5)
+    xT = synth.synth_tensor("opts/xT", (T, 4, h, w))
+    noises = [synth.synth_tensor(f"opts/noise{i}", (T, 4, h, w)) for i in range(S)]          # indexed by schedule index i
+    x0m = synth.synth_tensor("opts/x0", (T, 4, h, w), 0.7)
+    mask = (synth.synth_tensor("opts/mask", (T, 1, h, w)) > 0.3).float()
+    fea = synth.synth_tensor("opts/adain", (T, 4, h, w), 0.4) + 0.2
+    out = {"lat": lat, "xT": xT, "noise": torch.stack(noises), "x0m": x0m, "mask": mask, "adain_fea": fea, "ctx": ctx,
+           "ori_timesteps": np.array(model.ori_timesteps, dtype=np.int64)}
+    orig = ddpm.noise_like
+
+    def run(**opt):
+        # the loop draws noise_like once per EXECUTED step, in loop order i = S-1 .. 0 (skipped steps draw nothing)
+        st = opt.get("start_T")
+        order = [i for i in reversed(range(S)) if st is None or model.ori_timesteps[i] <= st]
+        queue = [noises[i] for i in order]
+        ddpm.noise_like = lambda shape, device, repeat=False: queue.pop(0)
+        torch.manual_seed(4242)
+        try:
+            return model.p_sample_loop(ctx, lat, (T, 4, h, w), guidance_scale=-10.0, x_T=xT, verbose=False, timesteps=S, time_replace=S,
+                                       **opt)
+        finally:
+            ddpm.noise_like = orig
+    out["x_start_T"] = run(start_T=600)
+    out["x_mask"] = run(mask=mask, x0=x0m)
+    out["x_adain"] = run(adain_fea=fea)
+    calls, imgs = [], []
+    out["x_cb"] = run(callback=lambda i: calls.append(("cb", i)), img_callback=lambda img, i: (calls.append(("img", i)), imgs.append(img.clone())))
+    out["cb_order"] = np.array([[0 if k == "cb" else 1, i] for k, i in calls], dtype=np.int64)
+    out["cb_imgs"] = torch.stack(imgs)
+    save("g_sample_opts", **out)
+
+
 class _AD(dict):
     """dict with attribute access (the scripts read `config.model`, instantiate_from_config reads it as a dict)"""
     __getattr__ = dict.__getitem__
@@ -765,7 +807,7 @@ if __name__ == "__main__":
                 gen_workload(*what.split(":")[1:])
                 continue
             fn = globals()["gen_" + what]
-            if what == "pstep":
+            if what in ("pstep", "sample_opts"):
                 fn(*build_ref_model())
             else:
                 fn()
@@ -781,3 +823,4 @@ if __name__ == "__main__":
     gen_first_stage(model)
     gen_sample(model, ddpm)
     gen_pstep(model, ddpm)
+    gen_sample_opts(model, ddpm)

@@ -155,6 +155,44 @@ def test_sample_small_vs_golden(hip, tag):
     assert torch.isfinite(loss)
 
 
+def test_sample_loop_options_vs_golden(hip):
+    """the option branches of p_sample_loop that sit between steps (ddpm.py:4501-4599): start_T, mask + x0 (inpainting), adain_fea,
+    callback / img_callback — against runs of the reference's own loop (g_sample_opts.npz).  In the golden run the noise list holds one
+    draw per EXECUTED step; here noise is indexed by schedule index, so skipped indices are simply never read."""
+    g = G("g_sample_opts")
+    model = _small_model()
+    S = 4
+    _respace(model, S)
+    assert list(model.ori_timesteps) == g["ori_timesteps"].tolist()
+    shape = tuple(g["xT"].shape)
+    kw = dict(guidance_scale=-10.0, x_T=g["xT"], verbose=False, timesteps=S, time_replace=S)
+    model._opts_noise = g["noise"]
+
+    def loop(**opt):       # p_sample_loop takes no `noise=`: route through sample() for the injected draws, p_sample_loop for the hooks
+        return model._sample_loop(g["ctx"], g["lat"], shape, -10.0, None, None, g["xT"], S, S, False, None, g["noise"], None, True, hooks=opt)
+    x = loop(start_T=600)
+    assert record("opts_start_T", rel_l2(x, g["x_start_T"])) < 2e-3
+    # q_sample(x0, ts) inside the loop draws randn_like(x0) from the global generator, seeded 4242 in the golden run, one draw per step
+    torch.manual_seed(4242)
+    mn = torch.zeros(S, *shape)
+    for i in reversed(range(S)):
+        mn[i] = torch.randn(shape)
+    x = loop(mask=g["mask"], x0=g["x0m"], mask_noise=mn)
+    assert record("opts_mask", rel_l2(x, g["x_mask"])) < 2e-3
+    x = loop(adain_fea=g["adain_fea"])
+    assert record("opts_adain", rel_l2(x, g["x_adain"])) < 2e-3
+    calls, imgs = [], []
+    x = loop(callback=lambda i: calls.append((0, i)), img_callback=lambda img, i: (calls.append((1, i)), imgs.append(img.clone())))
+    assert calls == [tuple(r) for r in g["cb_order"].tolist()]
+    assert record("opts_callbacks", rel_l2(torch.stack(imgs), g["cb_imgs"])) < 2e-3 and rel_l2(x, g["x_cb"]) < 2e-3
+    # the public entries accept the options (no NotImplementedError) and agree with the loop
+    x2 = model.sample(cond=g["ctx"], struct_cond=g["lat"], guidance_scale=-10.0, batch_size=1, timesteps=S, time_replace=S, x_T=g["xT"],
+                      noise=g["noise"], start_T=600)
+    assert rel_l2(x2, g["x_start_T"]) < 2e-3
+    with pytest.raises(NotImplementedError):
+        model.sample(cond=g["ctx"], struct_cond=g["lat"], timesteps=S, time_replace=S, x_T=g["xT"], interfea_path="/tmp/x")
+
+
 def test_single_step_api_and_decode_first_stage_vs_golden(hip):
     """p_mean_variance / p_sample / p_mean_variance_canvas / p_sample_canvas (ddpm.py:4157-4442) as eager single steps and
     decode_first_stage (ddpm.py:3786 -> AutoencoderKL.decode) against the reference's outputs (g_pstep.npz)"""
