@@ -973,8 +973,8 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
   constexpr int B_BASE = 2 * A_BYTES;
   static_assert(NW == 4 || NW == 8, "four or eight waves per block");
   static_assert(ASLOTS <= 6, "the patch must arrive within the three stages of a slice (at most two pieces per wave and stage)");
-  static_assert(NWB == 2 || (NWB == 3 && ASLOTS <= 3), "two or three weight buffers (three: one patch piece per wave and stage)");
-  static_assert((TX & (TX - 1)) == 0 && TX >= 8 && (TY % 2) == 0 && BM % WM == 0 && BN % 64 == 0, "tile shape");
+  static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
+  static_assert((TX & (TX - 1)) == 0 && TX >= 8 && (TY % 2) == 0 && BM % WM == 0 && BN % 32 == 0 && BN % WN == 0, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1042,9 +1042,10 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
   for (int k = 0; k < BSLOTS; ++k) {
     const int b = k * NW + wave;
     const int dxi = b / (BN / 16), rb = b - dxi * (BN / 16);
-    const int g64 = (bn0 >> 6) + (rb >> 2);
+    const int gr = (bn0 >> 4) + rb;             // 16-row group of the weight matrix (BN = 160 tiles start inside a 64-row group)
+    const int g64 = gr >> 2;
     fw_ok[k] = (g64 * 64 < ((N + 63) & ~63)) && (b < NPB);
-    fw_ptr[k] = (const char*)(W + (((int64_t)g64 * nh * 3 * 4 + (rb & 3)) * 3 + dxi) * 512 + lane * 8);
+    fw_ptr[k] = (const char*)(W + (((int64_t)g64 * nh * 3 * 4 + (gr & 3)) * 3 + dxi) * 512 + lane * 8);
   }
   // W2 (MgldIGemm): the slices are walked TWICE — first against the scaled fp16 residual of the weights (same tiled layout, `wdelta` bytes
   // away), then, after ONE multiplication of the accumulators by w2_scale, against the weights themselves.  `lo` selects the matrix.
@@ -1108,11 +1109,11 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
     if (++idy == 3) { idy = 0; ++iv; ih = (two && iv == ns) ? h0 : ih + 1; }      \
   }
   // DMA instructions this wave issues per weight stage / per patch slot (the counted waits of the three-buffer ring)
-  int nw_me = 0, na_me[3] = {0, 0, 0};
+  int nw_me = 0, na_me[3] = {0, 0, 0};       // (patch pieces of stage s: slots s and s + 3)
 #pragma unroll
   for (int k = 0; k < BSLOTS; ++k) nw_me += (k * NW + wave < NPB) ? 1 : 0;
 #pragma unroll
-  for (int s = 0; s < (ASLOTS < 3 ? ASLOTS : 3); ++s) na_me[s] = (s * NW + wave < NPA) ? 1 : 0;
+  for (int s = 0; s < ASLOTS; ++s) na_me[s % 3] += (s * NW + wave < NPA) ? 1 : 0;
   if (h0 < h1) {
     MGLD_Q_ISSUE_A(0, 0)
     MGLD_Q_ISSUE_A(1, 0)
@@ -1157,7 +1158,13 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
           case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
           case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
           case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+          case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+          case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;     // (8 weight + 2 patch pieces: the 160-row variant)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) first
@@ -1468,8 +1475,11 @@ int launch_conv3p(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
 //   6: 8x8 x 128, 32x32 (8 waves): the 8x8 UNet level, one tile per frame
 //   7: 8x32 x 64, 64x64 (4 waves)      8: 8x32 x 128, 64x64 (8 waves)    (round 3: 2 x 2 MFMA tiles per wave = 1 KiB of LDS fragment
 //      reads per MFMA instead of 1.5: the 64x32 wave tiles run at the LDS read bandwidth)
+//   9: 8x32 x 160, 64x160 (4 waves, ONE block per CU, three weight buffers): the N = 320 convolutions of the 64x64 UNet level as
+//      128 pixel tiles x 2 column tiles = exactly one block per CU (no partial round: the 64-row tiles leave 640 blocks on 512 slots);
+//      10 MFMAs per 7 fragment reads (0.7 KiB of LDS per MFMA), 160 accumulator registers per lane
 // (fragments prefetched TWO steps ahead — template parameter PF = 2 — measured identical to PF = 1 on every shape: not instantiated)
-constexpr int Q3_NVAR = 9;
+constexpr int Q3_NVAR = 10;
 template <int TY, int TX, int BN, int WM, int WN, bool UP2, int NWB = 2>
 constexpr int conv3q_lds() {
   constexpr int PW = UP2 ? TX / 2 + 2 : TX + 2, PH = UP2 ? TY / 2 + 2 : TY + 2;
@@ -1486,8 +1496,21 @@ inline int q3_nwb(int id, bool up2) {
   if (force != 3 || up2) return 2;
   return (id == 1 || id == 3 || id == 4) ? 3 : 2;
 }
+// weight buffers of the 160-row variant (one block per CU: nothing else on the CU covers a DMA round trip): env MGLD_CONV3Q_NWB160 = 2 / 3
+inline int q3_nwb160() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MGLD_CONV3Q_NWB160"); v = e ? atoi(e) : 3; }
+  return v == 2 ? 2 : 3;
+}
+// nearest-2x fold with four 64x64 waves per 16x16 tile (variant 7 with up2): env MGLD_CONV3Q_UP2W64 = 0 / 1 (A/B)
+inline bool q3_up2_wave64() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MGLD_CONV3Q_UP2W64"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
 inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
   const bool w3 = q3_nwb(id, up2) == 3;
+  if (up2 && id == 7) { *ty = 16; *tx = 16; *bn = 64; *lds = conv3q_lds<16, 16, 64, 64, 64, true>(); return; }
   switch (id) {
     case 1: *ty = 16; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<16, 16, 64, 64, 32, true>() : (w3 ? conv3q_lds<16, 16, 64, 64, 32, false, 3>() : conv3q_lds<16, 16, 64, 64, 32, false>()); break;
     case 2: *ty = 8; *tx = 16; *bn = 128; *lds = conv3q_lds<8, 16, 128, 64, 32, false>(); break;
@@ -1497,6 +1520,7 @@ inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {
     case 6: *ty = 8; *tx = 8; *bn = 128; *lds = conv3q_lds<8, 8, 128, 32, 32, false>(); break;
     case 7: *ty = 8; *tx = 32; *bn = 64; *lds = conv3q_lds<8, 32, 64, 64, 64, false>(); break;
     case 8: *ty = 8; *tx = 32; *bn = 128; *lds = conv3q_lds<8, 32, 128, 64, 64, false>(); break;
+    case 9: *ty = 8; *tx = 32; *bn = 160; *lds = q3_nwb160() == 3 ? conv3q_lds<8, 32, 160, 64, 160, false, 3>() : conv3q_lds<8, 32, 160, 64, 160, false>(); break;
     default: *ty = 8; *tx = 16; *bn = 64; *lds = up2 ? conv3q_lds<8, 16, 64, 32, 32, true>() : conv3q_lds<8, 16, 64, 32, 32, false>(); break;
   }
 }
@@ -1522,12 +1546,24 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   const int64_t t832 = (int64_t)frames * cdiv(p->Hout, 8) * cdiv(p->Wout, 32) * cdiv(N, 64);
   const int64_t t256 = (int64_t)frames * cdiv(p->Hout, 16) * cdiv(p->Wout, 16) * cdiv(N, 64);
   int v;
-  if (p->up2) v = (t256 >= 448) ? 1 : 0;
+  if (p->up2) v = (t256 >= 448) ? (q3_up2_wave64() ? 7 : 1) : 0;
   else if (p->Wout == 8) v = 6;
   else if (p->Wout == 16 && p->Hout == 16 && (N & 127) == 0) v = 3;
-  else v = (p->Wout >= 32 && t832 >= 448) ? 4 : 5;
-  if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1) && p->Wout >= 16 && force != 6) v = force;
-  if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2) && p->Wout >= 16 && p->tune != 7) v = p->tune - 1;
+  // round 3 (profiles/r03_conv3q_variants.txt): 8x32 tiles run by FOUR waves of 64 pixels x 64 channels (2 x 2 MFMA tiles per wave: a third
+  // less LDS fragment traffic per MFMA than the eight 64x32 waves of variant 4) are 5-10 % faster wherever there is at least ~1.25 block per CU
+  else v = (p->Wout >= 32 && t832 >= 320) ? 7 : 5;
+  {
+    // the 160-row one-block-per-CU variant where its blocks fill whole rounds of the chip (N = 320 / 640 at 64x64, 8 frames)
+    static int v160 = -1;
+    if (v160 < 0) { const char* e = getenv("MGLD_CONV3Q_V160"); v160 = e ? atoi(e) : 0; }
+    if (v160 && !p->up2 && p->Wout >= 32 && (N % 160) == 0) {
+      const int64_t t160 = (int64_t)frames * cdiv(p->Hout, 8) * cdiv(p->Wout, 32) * (N / 160);
+      const int64_t cus = num_cus(), rem = t160 % cus;
+      if (t160 >= cus * 3 / 4 && (rem == 0 || rem >= cus * 3 / 4)) v = 9;
+    }
+  }
+  if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1 && force != 7) && p->Wout >= 16 && force != 6) v = force;
+  if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2 && p->tune != 8) && p->Wout >= 16 && p->tune != 7) v = p->tune - 1;
   int ty, tx, bn, lds;
   q3_geom(v, &ty, &tx, &bn, &lds, p->up2 != 0);
   const int64_t tiles = (int64_t)frames * cdiv(p->Hout, ty) * cdiv(p->Wout, tx) * cdiv(N, bn);
@@ -1571,7 +1607,10 @@ int launch_conv3q(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
 }
 
 int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int hchunk) {
-  if (p->up2) return id == 1 ? launch_conv3q<16, 16, 64, 64, 32, true>(p, s, splits, hchunk) : launch_conv3q<8, 16, 64, 32, 32, true>(p, s, splits, hchunk);
+  if (p->up2) {
+    if (id == 7) return launch_conv3q<16, 16, 64, 64, 64, true>(p, s, splits, hchunk);
+    return id == 1 ? launch_conv3q<16, 16, 64, 64, 32, true>(p, s, splits, hchunk) : launch_conv3q<8, 16, 64, 32, 32, true>(p, s, splits, hchunk);
+  }
   const bool w3 = q3_nwb(id, false) == 3;
   switch (id) {
     case 1: return w3 ? launch_conv3q<16, 16, 64, 64, 32, false, 1, 3>(p, s, splits, hchunk) : launch_conv3q<16, 16, 64, 64, 32, false>(p, s, splits, hchunk);
@@ -1582,6 +1621,7 @@ int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int h
     case 6: return launch_conv3q<8, 8, 128, 32, 32, false>(p, s, splits, hchunk);
     case 7: return launch_conv3q<8, 32, 64, 64, 64, false>(p, s, splits, hchunk);
     case 8: return launch_conv3q<8, 32, 128, 64, 64, false>(p, s, splits, hchunk);
+    case 9: return q3_nwb160() == 3 ? launch_conv3q<8, 32, 160, 64, 160, false, 1, 3>(p, s, splits, hchunk) : launch_conv3q<8, 32, 160, 64, 160, false>(p, s, splits, hchunk);
     default: return launch_conv3q<8, 16, 64, 32, 32, false>(p, s, splits, hchunk);
   }
 }
@@ -1610,9 +1650,11 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
   int cfg, splits, kchunk;
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
     static const int g[Q3_NVAR][5] = {{8, 16, 64, 32, 32}, {16, 16, 64, 64, 32}, {8, 16, 128, 64, 32}, {16, 16, 128, 64, 64}, {8, 32, 64, 64, 32}, {8, 16, 64, 64, 32}, {8, 8, 128, 32, 32},
-                                      {8, 32, 64, 64, 64}, {8, 32, 128, 64, 64}};
-    snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s, %d, %d>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4], p->up2 ? "true" : "false",
-             1, q3_nwb(cfg, p->up2 != 0));
+                                      {8, 32, 64, 64, 64}, {8, 32, 128, 64, 64}, {8, 32, 160, 64, 160}};
+    if (p->up2 && cfg == 7) snprintf(buf, buflen, "conv3q_kernel<16, 16, 64, 64, 64, true, 1, 2>");
+    else
+      snprintf(buf, buflen, "conv3q_kernel<%d, %d, %d, %d, %d, %s, %d, %d>", g[cfg][0], g[cfg][1], g[cfg][2], g[cfg][3], g[cfg][4],
+               p->up2 ? "true" : "false", 1, cfg == 9 ? q3_nwb160() : q3_nwb(cfg, p->up2 != 0));
     return splits;
   }
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) {

@@ -418,6 +418,7 @@ class _AutoencoderBase(nn.Module):
             if any(k.startswith(ik) for ik in ignore_keys):
                 del sd[k]
         missing, unexpected = self.load_state_dict(sd, strict=False)
+        self.last_load = (list(missing), list(unexpected))       # (the reference prints both lists and returns `missing`)
         return missing
 
 

@@ -453,6 +453,41 @@ def gen_sample_opts(model=None, ddpm=None):
     save("g_sample_opts", **out)
 
 
+def gen_ckpt_keys():
+    """The key / shape list of the checkpoints the scripts load (oldcanvas_tile.py:91-108, :296-306): `state_dict` of the FULL-width
+    LatentDiffusionVSRTextWT exactly as the shipped YAML builds it (mgldvsr_512_realbasicvsr_deg.yaml: UNet, struct-cond encoder,
+    first-stage KL-VAE, RAFT_SR flow net, 1000-step schedule buffers) and of the video VAE (video_autoencoder_kl_64x64x4_resi.yaml), read
+    from the reference's own classes.  The `cond_stage_model.*` entries cannot come from the reference here — FrozenOpenCLIPEmbedder needs
+    open_clip, which is not installed — so that part of the list is open_clip's published ViT-H-14 TEXT tower layout (width 1024, 24
+    layers, vocabulary 49408, context 77; `visual` is deleted by the embedder, modules.py:153) and is marked as such in the fixture.
+    Names and shapes only (JSON, ~300 KB): the test builds an all-keys state dict from it and loads it through VSRPipeline."""
+    from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
+    ae = ref_import.ref("ldm.models.autoencoder")
+    model, _ = build_ref_model(dict(UNET_FULL), dict(STRUCT_FULL), dict(VAE_DD_FULL), 5,
+                               flownet_config={"target": "basicsr.archs.raft_arch.RAFT_SR", "params": {"model": "normal", "load_path": None}})
+    ldm_keys = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()]
+    vq = ae.VideoAutoencoderKLResi(ddconfig=dict(VAE_DD_FULL), lossconfig={"target": "torch.nn.Identity"}, embed_dim=4, fusion_w=1.0,
+                                   freeze_dec=True, version=1)
+    vq_keys = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in vq.state_dict().items()]
+    W, L, V, C = 1024, 24, 49408, 77
+    tk = "cond_stage_model.model."
+    clip = [[tk + "positional_embedding", [C, W]], [tk + "text_projection", [W, W]], [tk + "logit_scale", []],
+            [tk + "token_embedding.weight", [V, W]]]
+    for i in range(L):
+        b = f"{tk}transformer.resblocks.{i}."
+        clip += [[b + "ln_1.weight", [W]], [b + "ln_1.bias", [W]], [b + "attn.in_proj_weight", [3 * W, W]], [b + "attn.in_proj_bias", [3 * W]],
+                 [b + "attn.out_proj.weight", [W, W]], [b + "attn.out_proj.bias", [W]], [b + "ln_2.weight", [W]], [b + "ln_2.bias", [W]],
+                 [b + "mlp.c_fc.weight", [4 * W, W]], [b + "mlp.c_fc.bias", [4 * W]], [b + "mlp.c_proj.weight", [W, 4 * W]],
+                 [b + "mlp.c_proj.bias", [W]]]
+    clip += [[tk + "ln_final.weight", [W]], [tk + "ln_final.bias", [W]]]
+    path = os.path.join(OUT, "g_ckpt_keys.json")
+    with open(path, "w") as fh:
+        json.dump({"ldm": ldm_keys, "vq": vq_keys, "cond_stage_openclip_vit_h_14_text": [k + ["float32"] for k in clip],
+                   "note": "ldm / vq: read from the reference classes; cond_stage: open_clip's published text-tower layout (unpinned: open_clip not installed)"},
+                  fh)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB), {len(ldm_keys)} + {len(vq_keys)} + {len(clip)} keys")
+
+
 class _AD(dict):
     """dict with attribute access (the scripts read `config.model`, instantiate_from_config reads it as a dict)"""
     __getattr__ = dict.__getitem__

@@ -556,3 +556,56 @@ def test_text_embedder_tokenizes_with_a_merge_table_file(tmp_path, monkeypatch):
     emb2 = FrozenOpenCLIPEmbedder(context_dim=64, vocab_size=vs)
     t = emb2.tokenize(["Hello world", ""])
     assert t.shape == (2, 77) and t[0, :4].tolist() == [vs - 2, 512 + 3, 512 + 7, vs - 1] and t[1, :2].tolist() == [vs - 2, vs - 1]
+
+
+def test_fullwidth_checkpoint_every_reference_key_loads(tmp_path):
+    """SURVEY 8(f) row 3 / VERDICT r2 "missing" #2: a FULL-width `{"state_dict": ...}` holding EVERY key of the reference's own model
+    (names, shapes, dtypes read from the reference classes: tests/golden/g_ckpt_keys.json — UNet, struct-cond encoder, first-stage VAE,
+    RAFT_SR `flownet_model.*`, the 1000-long schedule buffers) plus open_clip's ViT-H-14 text tower under `cond_stage_model.model.*`
+    goes through VSRPipeline.load_checkpoint the way the script loads it (oldcanvas_tile.py:91-108: strict=False) with NOTHING missing
+    and NOTHING unexpected, the schedule is respaced afterwards, and the video VAE's keys load strictly through init_from_ckpt from a
+    Lightning-style file (`state_dict` next to pickled non-tensor objects, autoencoder.py:1652-1672)."""
+    import json as _json
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    with open(os.path.join(HERE, "golden", "g_ckpt_keys.json")) as fh:
+        keys = _json.load(fh)
+
+    def fake(entries):      # stride-0 views: the 1.4 G parameters of the state dict cost no memory, load_state_dict copies from them
+        return {k: torch.zeros((), dtype=getattr(torch, dt)).expand(*shape) if shape else torch.zeros((), dtype=getattr(torch, dt))
+                for k, shape, dt in entries}
+    sd = fake(keys["ldm"] + keys["cond_stage_openclip_vit_h_14_text"])
+    assert sd["betas"].shape == (1000,) and sd["cond_stage_model.model.token_embedding.weight"].shape == (49408, 1024)
+    assert any(k.startswith("flownet_model.") for k in sd) and any(k.startswith("first_stage_model.decoder.") for k in sd)
+    pipe = VSRPipeline(num_frames=5, ddpm_steps=50, synthetic_weights=False, configs=model_configs(5))
+    missing, unexpected = pipe.load_checkpoint({"state_dict": sd, "global_step": 7}, verbose=False)
+    assert list(missing) == [] and list(unexpected) == [], (list(missing)[:5], list(unexpected)[:5])
+    m = pipe.model
+    assert m.betas.shape == (50,) and len(m.ori_timesteps) == 50 and pipe.sqrt_alphas_cumprod.shape == (1000,)
+    tower = m.cond_stage_model.model
+    assert tower is not None and len(tower.transformer.resblocks) == 24 and tower.token_embedding.weight.shape == (49408, 1024)
+    # and nothing of the model was left without a checkpoint entry (every parameter / persistent buffer has a key in the reference list)
+    assert set(m.state_dict().keys()) - set(sd.keys()) == set()
+
+    # the video VAE: a Lightning-style checkpoint file with a pickled callback object of a module that is not importable here
+    import sys
+    import types
+    mod = types.ModuleType("pytorch_lightning_fake_callbacks")
+
+    def _init(self):
+        self.best_k_models, self.monitor = {"a": 1.0}, "val/rec_loss"
+    ModelCheckpoint = type("ModelCheckpoint", (), {"__init__": _init, "__module__": mod.__name__, "__qualname__": "ModelCheckpoint"})
+    mod.ModelCheckpoint = ModelCheckpoint
+    sys.modules[mod.__name__] = mod
+    vsd = {k: (torch.zeros(shape, dtype=getattr(torch, dt)) + 0.25) for k, shape, dt in keys["vq"]}
+    ck = tmp_path / "vqgan.ckpt"
+    try:
+        torch.save({"state_dict": vsd, "callbacks": {"ckpt": ModelCheckpoint()}, "epoch": 11, "hyper_parameters": {"lr": 1e-4}}, ck)
+    finally:
+        del sys.modules[mod.__name__]
+    from mgld_vsr_amd.util import load_trusted_checkpoint
+    raw = load_trusted_checkpoint(str(ck))          # torch >= 2.6 weights_only default would refuse the callback object
+    assert raw["epoch"] == 11 and set(raw["state_dict"].keys()) == set(vsd.keys())
+    assert list(pipe.vq_model.init_from_ckpt(str(ck))) == []
+    assert pipe.vq_model.last_load == ([], [])
+    assert set(pipe.vq_model.state_dict().keys()) == set(vsd.keys())
+    assert float(pipe.vq_model.decoder.conv_out.weight.mean()) == 0.25

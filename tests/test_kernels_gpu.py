@@ -306,7 +306,7 @@ def test_igemm_conv3x3_patch(hip, n, cin, cout, h, w, ti, epi):
     assert rel_l2(_from_tok(out2.cpu().float(), n, h, w), ref) < 1e-3 and rel_l2(out2.float(), out.float()) < 3e-4
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8, 9])
 @pytest.mark.parametrize("n,cin,cout,h,w,epi", [
     (2, 64, 96, 24, 40, 0),        # ragged in both directions for every tile shape, ragged N
     (1, 128, 128, 136, 144, 1),    # W > 64 (the VAE's large levels), residual + SiLU epilogue
@@ -343,7 +343,7 @@ def test_igemm_conv3x3_tile2d(hip, variant, n, cin, cout, h, w, epi):
     assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 7])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 96, 12, 20), (1, 256, 256, 64, 64), (2, 1280, 1280, 8, 8)])
 def test_igemm_conv3x3_tile2d_upsample(hip, variant, n, cin, cout, h, w):
     """conv3q with the nearest-2x upsample folded into the tap offsets (Upsample blocks: openaimodel.py:185, model.py:96) vs
