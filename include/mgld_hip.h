@@ -247,6 +247,16 @@ int mgld_fb_consistency(const float* fwd_flow, const float* bwd_flow, float alph
 /* bilinear resize (align_corners=False) of [n,2,h,w] flow to [n,2,oh,ow] with u,v rescaled */
 int mgld_resize_flow(const float* flow, float* out, int n, int h, int w, int oh, int ow, void* stream);
 
+/* ---- G1 tail / A4 / H4: per-segment scalar arithmetic around the networks ------------------------------- */
+/* init = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise): DiagonalGaussianDistribution.sample + get_first_stage_encoding
+ * (distributions.py:24-40, ddpm.py:3382-3389) on the encoder's moments [n, 2c, hw] (mean planes then logvar planes per frame), and,
+ * when x_T != NULL, x_T = sqrt_ac * init + sqrt_one_minus_ac * n0: q_sample_respace at ONE timestep (ddpm.py:403-406; the scripts
+ * noise every frame to t = 999).  noise, n0, init, x_T: [n, c, hw] fp32 */
+int mgld_init_latent(const float* moments, const float* noise, const float* n0, float* init, float* x_T, int n, int c, int64_t hw,
+                     float scale, float sqrt_ac, float sqrt_one_minus_ac, void* stream);
+/* out = clamp((x + 1) / 2, 0, 1): the final mapping of decoded frames to [0,1] (oldcanvas_tile.py:471); in place allowed */
+int mgld_to01(const float* x, float* out, int64_t n, void* stream);
+
 /* ---- H1/H2: colour fix (wavelet_color_fix.py:44-119) --------------------------------------------------- */
 /* out = (x-mean_x)/sqrt(var_x+eps)*sqrt(var_s+eps)+mean_s per (n,c) plane; unbiased variance; fp32 NCHW.
  * work: >= 512 * planes floats, 8-byte aligned (fp64 partial sums of up to 64 chunks per plane and tensor) */

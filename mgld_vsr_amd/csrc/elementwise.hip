@@ -606,6 +606,46 @@ extern "C" int mgld_copy2d(const void* src, int lds_, void* dst, int ldd, int64_
   return mgld_check_launch("copy2d");
 }
 
+// ---- segment prologue / epilogue arithmetic that used to run as vendor elementwise kernels -----------------------------
+// init = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise)  (distributions.py:24-40 sample(), ddpm.py:3382-3389) and, when
+// x_T != NULL, x_T = sa * init + soma * n0 (q_sample_respace, ddpm.py:403-406, with both schedule coefficients of t as scalars).
+// moments: [n, 2c, hw] (mean planes, then logvar planes per frame); noise / n0 / outputs: [n, c, hw]
+namespace {
+__global__ void init_latent_kernel(const float* __restrict__ mom, const float* __restrict__ noise, const float* __restrict__ n0,
+                                   float* __restrict__ init, float* __restrict__ xT, int n, int c, int64_t hw, float scale, float sa,
+                                   float soma) {
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = idx / (c * hw), r = idx - f * (c * hw);
+    const float mean = mom[f * 2 * c * hw + r];
+    const float lv = fminf(fmaxf(mom[f * 2 * c * hw + c * hw + r], -30.f), 20.f);
+    const float z = mean + expf(0.5f * lv) * noise[idx];
+    const float v = scale * z;
+    init[idx] = v;
+    if (xT) xT[idx] = sa * v + soma * n0[idx];
+  }
+}
+// out = clamp((x + 1) / 2, 0, 1): the scripts' final mapping of the decoded frames (oldcanvas_tile.py:471)
+__global__ void to01_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.f), 1.f);
+}
+}  // namespace
+
+extern "C" int mgld_init_latent(const float* moments, const float* noise, const float* n0, float* init, float* x_T, int n, int c,
+                                int64_t hw, float scale, float sqrt_ac, float sqrt_one_minus_ac, void* stream) {
+  MGLD_REQUIRE(moments && noise && init && n > 0 && c > 0 && hw > 0 && (x_T == nullptr || n0 != nullptr), "init_latent: bad args");
+  hipLaunchKernelGGL(init_latent_kernel, dim3(egrid((int64_t)n * c * hw)), dim3(256), 0, S_(stream), moments, noise, n0, init, x_T, n, c,
+                     hw, scale, sqrt_ac, sqrt_one_minus_ac);
+  return mgld_check_launch("init_latent");
+}
+
+extern "C" int mgld_to01(const float* x, float* out, int64_t n, void* stream) {
+  MGLD_REQUIRE(x && out && n > 0, "to01: bad args");
+  hipLaunchKernelGGL(to01_kernel, dim3(egrid(n)), dim3(256), 0, S_(stream), x, out, n);
+  return mgld_check_launch("to01");
+}
+
 extern "C" int mgld_axpby(const void* x, int ldx, void* y, int ldy, int64_t rows, int cols, float a, float b, void* stream) {
   MGLD_REQUIRE(x && y && rows > 0 && cols > 0, "axpby: bad args");
   MGLD_REQUIRE((cols & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0, "axpby: cols/ld % 8");

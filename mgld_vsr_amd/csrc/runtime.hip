@@ -57,7 +57,7 @@ extern "C" int mgld_graph_end(void* stream, void** graph_exec_out) {
   HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &graph), "hipStreamEndCapture");
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) {
     mgld_set_error("hipGraphInstantiate", e);
     return MGLD_E_LAUNCH;

@@ -60,7 +60,7 @@ EXPORTS = [
     "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
     "mgld_ddpm_step", "mgld_flow_warp", "mgld_guidance", "mgld_guidance_loss", "mgld_step_advance",
     "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
-    "mgld_adain", "mgld_wavelet_reconstruction",
+    "mgld_adain", "mgld_wavelet_reconstruction", "mgld_init_latent", "mgld_to01",
     "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize", "mgld_copy_step",
     "mgld_resize_bicubic", "mgld_resize_bilinear_crop", "mgld_reflect_pad", "mgld_replicate_pad", "mgld_to_uint8_hwc",
     "mgld_avgpool2", "mgld_corr_lookup", "mgld_gru_rh", "mgld_gru_gate", "mgld_flow_update", "mgld_convex_upsample",
@@ -452,6 +452,31 @@ def adain(content, style, out, work):
     with timed("adain", {"bytes": 4.0 * 3 * content.numel()}):
         _chk(lib().mgld_adain(_p(content), _p(style), _p(out), n * c, C.c_int64(h * w), C.c_float(1e-5), _p(work), stream_ptr()),
              "adain")
+    return out
+
+
+def init_latent(moments, noise, scale, n0=None, sqrt_ac=0.0, sqrt_one_minus_ac=0.0):
+    """-> (init_latent, x_T or None): posterior sample * scale and, with n0, its q_sample at one timestep (include/mgld_hip.h)"""
+    _req_cuda(moments, noise)
+    n, c2, h, w = moments.shape
+    c = c2 // 2
+    assert moments.dtype == torch.float32 and moments.is_contiguous() and noise.shape == (n, c, h, w) and noise.is_contiguous()
+    init = torch.empty_like(noise)
+    xT = None
+    if n0 is not None:
+        _req_cuda(n0)
+        assert n0.shape == noise.shape and n0.is_contiguous()
+        xT = torch.empty_like(noise)
+    _chk(lib().mgld_init_latent(_p(moments), _p(noise), _p(n0), _p(init), _p(xT), n, c, C.c_int64(h * w), C.c_float(scale),
+                                C.c_float(sqrt_ac), C.c_float(sqrt_one_minus_ac), stream_ptr()), "init_latent")
+    return init, xT
+
+
+def to01(x, out=None):
+    _req_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    _chk(lib().mgld_to01(_p(x), _p(out), C.c_int64(x.numel()), stream_ptr()), "to01")
     return out
 
 

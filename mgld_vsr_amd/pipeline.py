@@ -81,6 +81,7 @@ class VSRPipeline:
         m.num_timesteps = 1000
         self.sqrt_alphas_cumprod = copy.deepcopy(m.sqrt_alphas_cumprod)
         self.sqrt_one_minus_alphas_cumprod = copy.deepcopy(m.sqrt_one_minus_alphas_cumprod)
+        self._sa999, self._soma999 = float(self.sqrt_alphas_cumprod[999]), float(self.sqrt_one_minus_alphas_cumprod[999])   # t = 999 (:449)
         use = set(space_timesteps(1000, [steps]))
         last, nb = 1.0, []
         for i, ac in enumerate(m.alphas_cumprod):
@@ -232,17 +233,26 @@ class VSRPipeline:
         if fs is not None:         # first-stage encode of this rank's frames, latents of the whole clip by all-gather
             post = m.encode_first_stage(fs.local(x).contiguous())
             init_latent = fs.all_gather(m.get_first_stage_encoding(post, fs.local(pn)).contiguous())
+            post = None
         else:
             if init_from_vq:
                 post, enc_fea = vq.encode(x)
             else:
                 post = m.encode_first_stage(x)
-            init_latent = m.get_first_stage_encoding(post, pn if pn is not None else torch.randn(post.mean.shape))
+            init_latent = None
         ctx = m.cond_stage_model([""])
         n0 = noise.get("x_T")
-        n0 = torch.randn_like(init_latent) if n0 is None else n0.to(eng.device)
-        t = torch.full((T,), 999, dtype=torch.long, device=eng.device)
-        x_T = m.q_sample_respace(init_latent, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, n0)
+        if fs is None:
+            # posterior sample * scale_factor and its q_sample at t = 999 in ONE launch (mgld_init_latent; ddpm.py:3382-3389, 403-406)
+            from . import hip
+            pn = (pn if pn is not None else torch.randn(post.mean.shape)).to(eng.device, torch.float32).contiguous()   # drawn on the host, as the reference does
+            n0 = (torch.randn(pn.shape, device=eng.device) if n0 is None else n0.to(eng.device, torch.float32)).contiguous()
+            init_latent, x_T = hip.init_latent(post.parameters.contiguous(), pn, float(m.scale_factor), n0,
+                                               self._sa999, self._soma999)
+        else:
+            n0 = torch.randn_like(init_latent) if n0 is None else n0.to(eng.device)
+            t = torch.full((T,), 999, dtype=torch.long, device=eng.device)
+            x_T = m.q_sample_respace(init_latent, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, n0)
         kw = dict(cond=ctx, struct_cond=init_latent, guidance_scale=guidance_scale, flows=flows, masks=masks, batch_size=1,
                   timesteps=self.ddpm_steps, time_replace=self.ddpm_steps, x_T=x_T, noise=noise.get("steps"), use_graph=use_graph)
         if tile is None:
@@ -267,7 +277,11 @@ class VSRPipeline:
             x_samples = wavelet_reconstruction(x_samples, x)
         # clamp01=False: colour-fixed frames in [-1,1] as they are (the script's large-image branch averages overlapping
         # patches BEFORE the final clamp, oldcanvas_tile.py:469-471)
-        out = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0) if clamp01 else x_samples
+        if clamp01:
+            from . import hip
+            out = hip.to01(x_samples.contiguous())
+        else:
+            out = x_samples
         if shard is not None and gather and shard.world > 1:
             out, samples = shard.all_gather(out), shard.all_gather(samples)
         if fs is not None:

@@ -360,13 +360,29 @@ class DiagonalGaussianDistribution(object):
 
     def __init__(self, parameters, deterministic=False):
         self.parameters = parameters
-        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
-        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.mean, self._raw_logvar = torch.chunk(parameters, 2, dim=1)          # views: no launch
         self.deterministic = deterministic
-        self.std = torch.exp(0.5 * self.logvar)
-        self.var = torch.exp(self.logvar)
-        if self.deterministic:
-            self.var = self.std = torch.zeros_like(self.mean)
+        self._lv = self._std = self._var = None
+
+    # clamp / exp run only if somebody asks for these tensors: the segment path samples through mgld_init_latent (one launch for
+    # clamp + exp + sample + scale + q_sample) instead of five vendor elementwise kernels
+    @property
+    def logvar(self):
+        if self._lv is None:
+            self._lv = torch.clamp(self._raw_logvar, -30.0, 20.0)
+        return self._lv
+
+    @property
+    def std(self):
+        if self._std is None:
+            self._std = torch.zeros_like(self.mean) if self.deterministic else torch.exp(0.5 * self.logvar)
+        return self._std
+
+    @property
+    def var(self):
+        if self._var is None:
+            self._var = torch.zeros_like(self.mean) if self.deterministic else torch.exp(self.logvar)
+        return self._var
 
     def sample(self, noise=None):
         if noise is None:  # the reference draws on the CPU then moves (distributions.py:35-37)

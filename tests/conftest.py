@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU tests that take many minutes (heavy fixture regeneration); they run only with "
+                                       "MGLD_SLOW=1 (or `-m slow`), so that the default `-m \"not gpu\"` suite stays at a few minutes")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("MGLD_SLOW") == "1" or "slow" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="slow: set MGLD_SLOW=1 (or run `-m slow`) to regenerate the heavy fixtures")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -306,7 +306,7 @@ def test_igemm_conv3x3_patch(hip, n, cin, cout, h, w, ti, epi):
     assert rel_l2(_from_tok(out2.cpu().float(), n, h, w), ref) < 1e-3 and rel_l2(out2.float(), out.float()) < 3e-4
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("n,cin,cout,h,w,epi", [
     (2, 64, 96, 24, 40, 0),        # ragged in both directions for every tile shape, ragged N
     (1, 128, 128, 136, 144, 1),    # W > 64 (the VAE's large levels), residual + SiLU epilogue

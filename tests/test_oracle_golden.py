@@ -304,6 +304,43 @@ def test_golden_generator_reproduces_committed_fixtures(tmp_path):
                 assert str(old[k]) == str(new[k]), (f, k)
 
 
+def _regen_and_compare(tmp_path, what, names, timeout):
+    import subprocess
+    env = dict(os.environ, MGLD_GOLDEN_OUT=str(tmp_path))
+    gen = os.path.join(HERE, "golden", "make_golden.py")
+    r = subprocess.run([sys.executable, gen] + list(what), env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for f in names:
+        new, old = np.load(os.path.join(tmp_path, f)), np.load(os.path.join(HERE, "golden", f))
+        assert sorted(new.files) == sorted(old.files), f
+        for k in old.files:
+            if old[k].dtype.kind in "fiu":
+                assert old[k].shape == new[k].shape and np.array_equal(old[k], new[k]), (f, k)
+            else:
+                assert str(old[k]) == str(new[k]), (f, k)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("what,names,timeout", [
+    (["fullwidth"], ["g_full_c1.npz"], 1800),                                   # configs[0] through the full-width reference networks
+    (["pstep"], ["g_pstep.npz"], 1200),                                         # single-step API + image decoder
+    (["harness"], ["g_harness.npz"], 3600),                                     # recorded run of the tiled entry script's main()
+    (["harness_old"], ["g_harness_old.npz"], 3600),                             # recorded runs of the _old / _w_latent scripts
+    (["text_hf"], ["g_text_hf.npz"], 1200),                                     # text tower vs transformers' CLIPTextModel
+    (["workload:c2:4"], ["g_work_c2_S4.npz"], 3600),                            # BASELINE configs[1] / [4] workload, 4 steps
+    (["workload:c2g:4"], ["g_work_c2g_S4.npz"], 3600),                          # configs[2] share
+    (["workload:c4:4"], ["g_work_c4_S4.npz"], 7200),                            # configs[3]: 1024^2 aggregation sampling
+    (["workload:c2:50"], ["g_work_c2_S50.npz"], 14400)])                        # configs[1] at its 50 steps
+def test_heavy_fixtures_regenerate_bit_for_bit(tmp_path, what, names, timeout):
+    """The heavy fixtures (minutes to hours of CPU each) under the same pin as the light ones: re-run the generator against
+    /root/reference in a fresh process and compare every array bit for bit.  `slow`: only with MGLD_SLOW=1."""
+    for f in names:
+        if not os.path.exists(os.path.join(HERE, "golden", f)):
+            pytest.skip(f"{f} is not committed")
+    _regen_and_compare(tmp_path, what, names, timeout)
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the build container")
 def test_ref_import_refuses_the_products_own_modules():
     """ref_import.ref must hand back files of the reference tree even when the repo's `ldm` package is already imported"""
