@@ -314,12 +314,24 @@ def main():
     GRAPH = not args.no_graph
     if args.spawn_selftest:
         from mgld_vsr_amd import parallel
-        rank, world, local = dist_setup(args.gpus, "gloo")
+        backend = "gloo" if not torch.cuda.is_available() else args.backend
+        rank, world, local = dist_setup(args.gpus, backend)
+        if backend == "nccl":
+            torch.cuda.set_device(local)
         parallel.barrier(sync_device=False)
         dt = parallel.max_over_ranks(1e-3 * (rank + 1))
+        # the exchanges of the selected multi-GPU mode, replayed with dummy tensors through the same DistComm calls (launcher,
+        # rendezvous and transport check: gloo on CPU here, RCCL when a multi-GPU lease exists)
+        mode = "frame" if args.frame_shard else ("tile" if args.tile_shard else "segment")
+        plan = parallel.comm_plan(mode, T=args.frames, H=args.size, W=args.size, world=world, steps=args.ddpm_steps)
+        sent = parallel.comm_dry_run(plan, device="cuda" if backend == "nccl" else "cpu")
+        per_rank = parallel.gather_floats(float(sent))
         if rank == 0:
             print(json.dumps({"metric": "HR frames/sec at 512^2, 50 DDPM steps", "value": None, "n_gpus": world, "selftest": True,
-                              "max_over_ranks_ok": abs(dt - 1e-3 * world) < 1e-9}), flush=True)
+                              "world_size_seen": world, "backend": backend, "mode": mode,
+                              "max_over_ranks_ok": abs(dt - 1e-3 * world) < 1e-9,
+                              "comm_bytes_per_step_per_rank": plan["bytes_per_step"], "comm_bytes_per_segment_per_rank": plan["bytes_per_segment"],
+                              "dry_run_bytes_by_rank": per_rank}), flush=True)
         if world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()

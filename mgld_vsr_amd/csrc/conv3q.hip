@@ -611,9 +611,10 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   if (p->up2) v = (t256 >= 448) ? (q3_up2_wave64() ? 7 : 1) : 0;
   else if (p->Wout == 8) v = 6;
   else if (p->Wout == 16 && p->Hout == 16 && (N & 127) == 0) v = 3;
-  // round 3 (profiles/r03_conv3q_variants.txt): 8x32 tiles run by FOUR waves of 64 pixels x 64 channels (2 x 2 MFMA tiles per wave: a third
-  // less LDS fragment traffic per MFMA than the eight 64x32 waves of variant 4) are 5-10 % faster wherever there is at least ~1.25 block per CU
-  else v = (p->Wout >= 32 && t832 >= 320) ? 7 : 5;
+  // (round 3, profiles/r03_conv3q_variants.txt: variant 7 — 8x32 tiles run by FOUR waves of 64 pixels x 64 channels, a third less LDS
+  // fragment traffic per MFMA — is 5-7 % SLOWER than variant 4 on the UNet's 64x64 shapes and 2-4 % faster on three VAE shapes: not picked;
+  // p->tune = 8 / MGLD_CONV3Q_FORCE=7 select it)
+  else v = (p->Wout >= 32 && t832 >= 448) ? 4 : 5;
   if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1 && force != 7) && p->Wout >= 16 && force != 6) v = force;
   if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2 && p->tune != 8) && p->Wout >= 16 && p->tune != 7) v = p->tune - 1;
   int ty, tx, bn, lds;

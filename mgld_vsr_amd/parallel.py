@@ -273,3 +273,77 @@ class FrameShard:
 
     def halo(self, x, rows_per_frame, recv_left, recv_right):
         self.comm.exchange(x, rows_per_frame, recv_left, recv_right, self)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Communication plan of the sharded modes: what crosses xGMI, how often, how many bytes (DESIGN.md section 4 quotes these
+# figures; bench.py --spawn-selftest replays the plan with dummy tensors over the real process group: launcher + transport
+# check without a kernel, gloo on CPU / RCCL on GPUs).
+# ----------------------------------------------------------------------------------------------------------------------
+def comm_plan(mode, T=8, H=512, W=512, world=8, steps=50, n_tiles=9, ch=128, ch_mult=(1, 2, 4, 4), unet_mid_ch=1280):
+    """-> {"per_step": [...], "per_segment": [...], totals}: every exchange of ONE rank in mode
+    'segment' (no data-path exchange), 'frame' (FrameShard: halo send/recv + all-gathers) or 'tile' (TileShard: one all-gather per
+    step + the frame-split VAE).  Entry: (what, kind, count, bytes sent by this rank per occurrence).  Shipped geometry: latent
+    H/8 x W/8 x 4 (fp32), UNet mid block at 1/64 resolution with 1280 channels (fp16), video decoder levels ch * ch_mult."""
+    F = max(1, T // world)
+    h, w = H // 8, W // 8
+    per_step, per_seg = [], []
+    if mode == "segment" or world == 1:
+        return {"mode": mode, "per_step": [], "per_segment": [], "bytes_per_step": 0, "bytes_per_segment": 0, "steps": steps}
+    if mode == "frame":
+        mid = (h // 8) * (w // 8) * unet_mid_ch * 2                       # one frame of the UNet's 1/64-resolution level, fp16
+        per_step.append(("unet mid-block SpatialTemporalConv halo (x2, both neighbours)", "p2p", 2, 2 * mid))
+        per_step.append(("TemporalAttention q|k|v all-gather", "all_gather", 1, F * 3 * mid))
+        per_step.append(("guidance: latent all-gather", "all_gather", 1, F * 4 * h * w * 4))
+    elif mode == "tile":
+        per = -(-n_tiles // world)
+        per_step.append(("eps tiles all-gather", "all_gather", 1, per * T * 4 * 64 * 64 * 4))
+    # the frame-split video VAE decode (both sharded modes): one-frame halos of the 13 temporal convolutions, fp16
+    lv = [ch * m for m in ch_mult]
+    halos = [("decoder mid temporal_mixing", h * w * lv[-1] * 2)]
+    res = (h, w)
+    for i in reversed(range(len(ch_mult))):
+        halos += [(f"decoder up.{i} temporal_mixing x3", 3 * res[0] * res[1] * lv[i] * 2)]
+        if i:
+            res = (2 * res[0], 2 * res[1])
+    if mode == "frame" or T % world == 0:
+        for name, b in halos:
+            per_seg.append((name + " halo (both neighbours)", "p2p", 1, 2 * b))
+        per_seg.append(("init-latent all-gather (first-stage encode split)", "all_gather", 1, F * 4 * h * w * 4))
+        per_seg.append(("HR frames all-gather", "all_gather", 1, F * 3 * H * W * 4))
+    bs = sum(c * b for _, _, c, b in per_step)
+    bg = sum(c * b for _, _, c, b in per_seg)
+    return {"mode": mode, "T": T, "world": world, "per_step": per_step, "per_segment": per_seg, "bytes_per_step": bs,
+            "bytes_per_segment": bs * steps + bg, "steps": steps}
+
+
+def comm_dry_run(plan, device="cpu", step_repeats=2):
+    """replay the exchanges of `plan` (comm_plan) with dummy tensors over the initialised process group, through the same DistComm
+    calls the sharded modes make; returns the bytes this rank sent.  No kernels: a launcher / rendezvous / transport check."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    rank, world = dist.get_rank(), dist.get_world_size()
+    comm = DistComm()
+    sh = FrameShard(world, rank, world, comm) if plan["mode"] != "tile" else TileShard(world, rank, world, comm)
+    sent = 0
+
+    def run(entries, reps):
+        nonlocal sent
+        for _ in range(reps):
+            for what, kind, count, nbytes in entries:
+                n = max(1, min(nbytes, 1 << 20) // 2)          # transport check: at most 1 MiB per message
+                for _ in range(count):
+                    if kind == "all_gather":
+                        t = torch.full((1, n), float(rank), dtype=torch.float16, device=device)
+                        out = comm.all_gather(t, sh)
+                        assert out.shape[0] == world and float(out[world - 1, 0]) == world - 1
+                    else:
+                        x = torch.full((2, n), float(rank), dtype=torch.float16, device=device)
+                        left, right = torch.empty(1, n, dtype=torch.float16, device=device), torch.empty(1, n, dtype=torch.float16, device=device)
+                        comm.exchange(x, 1, left, right, sh)
+                        assert float(left[0, 0]) == (rank - 1 if rank > 0 else 0) and float(right[0, 0]) == (rank + 1 if rank < world - 1 else 0)
+                    sent += nbytes
+    run(plan["per_step"], step_repeats)
+    run(plan["per_segment"], 1)
+    return sent

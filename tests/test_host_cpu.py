@@ -321,11 +321,11 @@ def test_conv3p_planner_routes_the_unet_convolutions():
         p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, sc * h, sc * w, 1, 1, 1, up2
         return hip.igemm_config(p) % 1000000
 
-    assert qcode(8, 320, 320, 64, 64) == 400007         # 8x32-pixel tiles (640 blocks), four waves of 64 pixels x 64 channels (round 3)
-    assert qcode(8, 640, 640, 32, 32) == 400007         # 320 tiles of 256 pixels x 64 channels: still the 64x64-wave variant
-    assert qcode(8, 256, 128, 64, 64) == 400005         # 256 such tiles (one per CU, four waves each) would be too few: 8x16 tiles, four waves
+    assert qcode(8, 320, 320, 64, 64) == 400004         # 8x32-pixel tiles (640 blocks): 64-pixel x 32-channel wave tiles
+    assert qcode(8, 320, 320, 64, 64, tune=8) == 400007 # (round 3) the same tiles run by four waves of 64 pixels x 64 channels: opt-in
+    assert qcode(8, 640, 640, 32, 32) == 400005         # too few 256-pixel tiles for 256 CUs: 8x16 tiles, four waves
     assert qcode(8, 1280, 1280, 16, 16) == 400003       # 16x16 level: one tile per frame, 128 weight rows
-    assert qcode(8, 128, 128, 512, 512) == 400007       # the VAE's large levels (W > 64) stay on the patch path
+    assert qcode(8, 128, 128, 512, 512) == 400004       # the VAE's large levels (W > 64) stay on the patch path
     assert qcode(8, 512, 512, 64, 64, up2=1) == 400001  # nearest-2x upsample folded into the tap offsets (16x16 tiles)
     assert qcode(1, 64, 64, 8, 8, up2=1) == 400000
     assert qcode(8, 320, 320, 64, 64, tune=5) == 400004

@@ -217,3 +217,42 @@ def test_bench_spawns_its_own_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["max_over_ranks_ok"] is True
+
+
+@pytest.mark.parametrize("flags,mode,n", [([], "segment", 8), (["--frame-shard"], "frame", 8), (["--tile", "--tile-shard", "--size", "1024", "--frames", "4"], "tile", 4)])
+def test_bench_launcher_and_comm_plan_of_every_multi_gpu_mode(flags, mode, n):
+    """`bench.py --gpus 8` / `--frame-shard` / `--tile-shard` through the FULL launcher path (bench.py re-executes itself
+    under torch.distributed.run, one process per rank, rendezvous on 127.0.0.1) with the exchanges of the mode replayed over the real
+    process group (gloo here, RCCL on a multi-GPU lease): every rank completes, rank 0 reports the world size it saw and the bytes each
+    rank sends per step / per segment (parallel.comm_plan: the figures DESIGN.md section 4 quotes)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--spawn-selftest"] + flags, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == n and res["world_size_seen"] == n and res["mode"] == mode and res["max_over_ranks_ok"] is True
+    from mgld_vsr_amd import parallel
+    if mode == "segment":
+        assert res["comm_bytes_per_step_per_rank"] == 0 and res["comm_bytes_per_segment_per_rank"] == 0      # no data-path collective
+    else:
+        assert res["comm_bytes_per_step_per_rank"] > 0 and len(res["dry_run_bytes_by_rank"]) == n
+        assert len(set(res["dry_run_bytes_by_rank"])) == 1                                                    # every rank ran the whole plan
+
+
+def test_comm_plan_figures():
+    """the bytes of the frame-sharded mode at the shipped geometry (8 x 512^2 over 8 ranks): 2 + 1 + 1 exchanges per step, 13 halo
+    exchanges + 2 all-gathers per segment"""
+    from mgld_vsr_amd import parallel
+    p = parallel.comm_plan("frame", T=8, H=512, W=512, world=8, steps=50)
+    assert [e[1] for e in p["per_step"]] == ["p2p", "all_gather", "all_gather"] and p["per_step"][0][2] == 2
+    mid = 8 * 8 * 1280 * 2
+    assert p["per_step"][0][3] == 2 * mid and p["per_step"][1][3] == 3 * mid and p["per_step"][2][3] == 4 * 64 * 64 * 4
+    halos = [e for e in p["per_segment"] if e[1] == "p2p"]
+    assert len(halos) == 5 and halos[-1][3] == 2 * 3 * 512 * 512 * 128 * 2            # 1 + 4 x 3 = 13 temporal convolutions
+    assert p["bytes_per_segment"] == 50 * p["bytes_per_step"] + sum(e[2] * e[3] for e in p["per_segment"])
+    assert parallel.comm_plan("segment", world=8)["bytes_per_segment"] == 0
