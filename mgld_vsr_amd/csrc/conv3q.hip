@@ -569,7 +569,7 @@ inline int q3_nwb(int id, bool up2) {
 // nearest-2x fold with four 64x64 waves per 16x16 tile (variant 7 with up2): env MGLD_CONV3Q_UP2W64 = 0 / 1 (A/B)
 inline bool q3_up2_wave64() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("MGLD_CONV3Q_UP2W64"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = getenv("MGLD_CONV3Q_UP2W64"); v = e ? atoi(e) : 1; }   // measured -7..-8 % on every up-conv (profiles/r03_conv3q_variants.txt)
   return v != 0;
 }
 inline void q3_geom(int id, int* ty, int* tx, int* bn, int* lds, bool up2) {

@@ -326,7 +326,7 @@ def test_conv3p_planner_routes_the_unet_convolutions():
     assert qcode(8, 640, 640, 32, 32) == 400005         # too few 256-pixel tiles for 256 CUs: 8x16 tiles, four waves
     assert qcode(8, 1280, 1280, 16, 16) == 400003       # 16x16 level: one tile per frame, 128 weight rows
     assert qcode(8, 128, 128, 512, 512) == 400004       # the VAE's large levels (W > 64) stay on the patch path
-    assert qcode(8, 512, 512, 64, 64, up2=1) == 400001  # nearest-2x upsample folded into the tap offsets (16x16 tiles)
+    assert qcode(8, 512, 512, 64, 64, up2=1) == 400007  # nearest-2x upsample folded into the tap offsets (16x16 tiles, four 64x64 waves: round 3)
     assert qcode(1, 64, 64, 8, 8, up2=1) == 400000
     assert qcode(8, 320, 320, 64, 64, tune=5) == 400004
     assert hip.conv3p_applies(8, 256, 256, 128, 128) and hip.conv3p_applies(5, 512, 512, 90, 120) and hip.conv3p_applies(8, 512, 512, 64, 64, True)
