@@ -276,6 +276,51 @@ def test_oracle_fullwidth_config1_golden():
         assert rel_l2(out[:, :, ::4, ::4], g["out_s4"]) < 1e-4
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("case,S", [("c2g", 4), ("c4", 4)])
+def test_oracle_workload_golden(case, S):
+    """The oracle at WORKLOAD scale (slow: minutes of CPU, MGLD_SLOW=1): the full-width chain on the 8-frame guided 512^2 clip and the
+    4-frame 1024^2 aggregation-sampling clip against the reference's own outputs (g_work_<case>_S4.npz) — the multi-frame temporal
+    paths (Conv3d over T, temporal attention at T = 8, guidance chain, tile stitching) that the T = 1 fixture cannot pin."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from cases import case_inputs
+    from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
+    from ldm.models.autoencoder import AutoencoderKL, VideoAutoencoderKLResi
+    from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
+    g = G(f"g_work_{case}_S{S}")
+    c = case_inputs(case, S)
+    Tn, st, x, noise = c["T"], c["stride"], c["x"], c["noise"]
+    ucfg, scfg, dd = dict(UNET_FULL, num_frames=Tn), dict(STRUCT_FULL, num_frames=Tn), dict(VAE_DD_FULL, num_frames=Tn)
+
+    def names(m):
+        return [(k, tuple(v.shape)) for k, v in m.state_dict().items() if v.is_floating_point()]
+    fdd = dict(dd)
+    fdd.pop("num_frames")
+    usd = synth.synth_state_dict(names(InflatedUNetModelDualcondV2(**ucfg)), "unet")
+    ssd = synth.synth_state_dict(names(InflatedEncoderUNetModelWT(**scfg)), "structcond")
+    fsd = synth.synth_state_dict(names(AutoencoderKL(ddconfig=fdd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)), "first_stage")
+    vsd = synth.synth_state_dict(names(VideoAutoencoderKLResi(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)), "vae")
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        mean, logvar, _ = nets.vae_moments(fsd, dd, x)
+        init = 0.18215 * (mean + torch.exp(0.5 * logvar) * noise["posterior"])
+        assert rel_l2(init, g["init"]) < 1e-5
+        full, resp, ori = osched.respaced_schedule(S)
+        xT = osched.q_sample_respace(init, torch.full((Tn,), 999, dtype=torch.long), full["sqrt_alphas_cumprod"],
+                                     full["sqrt_one_minus_alphas_cumprod"], noise["x_T"])
+        assert rel_l2(xT, g["xT"]) < 1e-5
+        ctx = synth.synth_tensor("ctx", (1, 77, 1024))
+        flows, masks = (c["ff"][None], c["fb"][None]), (g["focc"][None, :, None], g["bocc"][None, :, None])
+        kw = dict(guidance_scale=-10.0, flows=flows, masks=masks)
+        if c["canvas"]:
+            kw["tile"] = (64, 32)
+        x0 = osamp.sample(usd, ucfg, ssd, scfg, ctx, init, xT, [noise["steps"][S - 1 - k] for k in range(S)], S, **kw)
+        assert rel_l2(x0, g["x0"]) < 1e-4
+        _, _, fea = nets.vae_moments(vsd, dd, x)
+        dec = nets.vae_decode(vsd, dd, g["x0"] / 0.18215, fea)
+        assert rel_l2(dec[:, :, ::st, ::st], g["dec_s"]) < 1e-4
+
+
 REF = os.environ.get("MGLD_REFERENCE", "/root/reference")
 
 
