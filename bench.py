@@ -142,11 +142,15 @@ HBM_PEAK_GBPS = 8000.0      # HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s a
 def _pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.sh).  PMC counters cannot be read from inside this process;
-    the file is only used when it was taken for THIS kernel name on THIS kernel source (sha256 of csrc/igemm.hip), else null."""
+    the file is only used when it was taken for THIS kernel name on THIS kernel source (sha256 of the GEMM family's three source files),
+    else null."""
     import hashlib
     try:
-        with open(os.path.join(ROOT, "mgld_vsr_amd", "csrc", "igemm.hip"), "rb") as fh:
-            sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+        src = b""
+        for f in ("igemm_common.h", "igemm.hip", "conv3q.hip"):
+            with open(os.path.join(ROOT, "mgld_vsr_amd", "csrc", f), "rb") as fh:
+                src += fh.read()
+        sha = hashlib.sha256(src).hexdigest()[:16]
     except OSError:
         return None
     for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
@@ -156,7 +160,7 @@ def _pmc_traffic(kernel):
         except (OSError, ValueError):
             continue
         ent = pm.get("kernels", {}).get(kernel)
-        if ent and pm.get("igemm_hip_sha16") == sha:
+        if ent and pm.get("gemm_src_sha16") == sha:
             return round(ent["hbm_bytes_per_launch"])
     return None
 

@@ -1,7 +1,8 @@
 # HBM traffic per launch of every GEMM-family / attention kernel (roofline.traffic): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
 # SEPARATE passes (counter collection only, no trace domains) over one eager segment of the default bench workload.
-# Writes gpurun_out/pmc_traffic.json keyed by the exact kernel instantiation name + the sha256 of csrc/igemm.hip it was taken on
-# (bench.py uses an entry only when both match the running build); copy it to profiles/r02_pmc_traffic.json.
+# Writes gpurun_out/pmc_traffic.json keyed by the exact kernel instantiation name + the sha256 of the GEMM family's sources
+# (csrc/igemm_common.h + igemm.hip + conv3q.hip) it was taken on (bench.py uses an entry only when both match the running build);
+# copy it to profiles/r03_pmc_traffic.json.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export MGLD_SC_PRECOMPUTE=0   # rocprofv3 --pmc segfaults inside its launch hook on the batched struct-cond passes (round 1); per-launch
@@ -31,8 +32,8 @@ for k, (n, f) in fe.items():
     w = wr.get(k, [0, 0.0])[1]
     kern[k] = {"launches": n, "fetch_size_kb_per_launch": f / n, "write_size_kb_per_launch": w / n,
                "hbm_bytes_per_launch": (2.0 * f + w) / n * 1024.0}
-sha = hashlib.sha256(open("mgld_vsr_amd/csrc/igemm.hip", "rb").read()).hexdigest()[:16]
-res = {"igemm_hip_sha16": sha, "kernels": kern,
+sha = hashlib.sha256(b"".join(open("mgld_vsr_amd/csrc/" + f, "rb").read() for f in ("igemm_common.h", "igemm.hip", "conv3q.hip"))).hexdigest()[:16]
+res = {"gemm_src_sha16": sha, "kernels": kern,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `MGLD_SC_PRECOMPUTE=0 bench.py --steps 1 --warmup 0 --no-graph` "
                "(one 8x512^2 50-step segment, eager launches); counters in KB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
                "doubled as MI355X_MICROARCH.md prescribes for gfx950 (it reports 1/2 of wide coalesced reads); WRITE_SIZE uncalibrated; "
