@@ -258,6 +258,14 @@ __global__ __launch_bounds__(64 * ((TY * TX) / WM) * (BN / WN)) void conv3q_kern
   // i.e. all pixel tiles of ~N/BN/8 weight tiles: the blocks sharing a WEIGHT tile share it through that XCD's L2 instead of
   // every XCD streaming the whole matrix (16x16 / 8x8 levels: W = 30-60 MB against 1-5 MB of activations; PMC showed 3-3.8x the
   // algorithmic bytes there).
+  // order bit 8 (env MGLD_CONV3Q_PRIO=1, A/B): static issue priority by hardware wave slot.  The blocks sharing a CU run the same stage
+  // structure and fall into lock-step (PMC: waves parked 44 % on the stage barrier / waitcnt, matrix pipe 40 % busy); raising the priority of
+  // the waves in the upper wave slots of every SIMD makes one co-resident block the pipe's owner and the other the filler of its gaps.
+  if (order & 0x100) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, bits 3:0 = wave slot on the SIMD
+    if (__builtin_amdgcn_readfirstlane(hwid) & 2) __builtin_amdgcn_s_setprio(1);
+  }
+  order &= 0xff;
   int tile_m = blockIdx.x, tile_n = blockIdx.y;
   if ((gridDim.x & 7) == 0) {
     const int lin = blockIdx.x + gridDim.x * blockIdx.y;
@@ -647,7 +655,9 @@ int launch_conv3q_(const MgldIGemm* p, hipStream_t s, int splits, int hchunk) {
   static int forder = -2;
   if (forder == -2) { const char* e = getenv("MGLD_CONV3Q_ORDER"); forder = e ? atoi(e) : -1; }
   const double wbytes = 2.0 * p->N * p->K, abytes = 2.0 * p->M * p->Cin / (UP2 ? 4 : 1);
-  const int order = forder >= 0 ? forder : (wbytes > 2.0 * abytes ? 1 : 0);
+  static int prio = -1;
+  if (prio < 0) { const char* e = getenv("MGLD_CONV3Q_PRIO"); prio = e ? atoi(e) : 0; }
+  const int order = (forder >= 0 ? forder : (wbytes > 2.0 * abytes ? 1 : 0)) | (prio ? 0x100 : 0);
   hipLaunchKernelGGL((conv3q_kernel<TY, TX, BN, WM, WN, UP2, PF, NWB, TWO>), grid, dim3(THREADS), lds, s, *p, splits > 1 ? g_ws : nullptr, hchunk,
                      tiles_x, tiles_y, order);
   if (splits > 1) launch_splitk_reduce(p, s, splits);
