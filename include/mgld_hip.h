@@ -172,6 +172,9 @@ int mgld_layernorm(const void* x, int ldx, const float* gamma, const float* beta
  * Element (b, row i, head h, dim d):  q: Q + b*q_sb + i*q_si + h*q_sh + d   (same for k, o)
  * V is consumed TRANSPOSED: vt element (b, h, d, key j) at Vt + b*vt_sb + h*vt_sh + d*vt_sd + j
  * (the V projection GEMM writes it that way; vt_sd % 4 == 0, rows zero-padded past Nkv).
+ * v_rowmajor = 1 (round 3): `Vt` points at V itself, laid out like K — element (b, key j, h, d) at Vt + b*vt_sb + j*vt_sd + h*vt_sh + d —
+ * so that q, k and v can be the three column blocks of ONE fused projection (attention.py:323-330: to_q / to_k / to_v as one
+ * GEMM with N = 3C); the kernel transposes on the LDS read (ds_read_b64_tr_b16).
  * head_dim in {64, 128}.
  */
 typedef struct MgldAttn {
@@ -182,6 +185,7 @@ typedef struct MgldAttn {
   int64_t vt_sb, vt_sh, vt_sd;
   int64_t o_sb, o_si, o_sh;
   float scale;
+  int32_t v_rowmajor;
 } MgldAttn;
 int mgld_attention(const MgldAttn* p, void* stream);
 /* TemporalAttention core (attention.py:124-143 -> 262-308): per pixel and head, softmax over the T frames.

@@ -21,7 +21,16 @@ namespace {
 
 // (amdgpu_waves_per_eu pins the register budget: 3 blocks per CU at D=64, 2 at D=128; it also makes the compiler keep
 //  the MFMA results in VGPRs, so the softmax reads them without v_accvgpr moves.)
-template <int D>
+// VRM (round 3): V arrives ROW-MAJOR — element (b, key j, h, d) at Vt + b*vt_sb + j*vt_sd + h*vt_sh + d — i.e. straight out of a fused
+// q|k|v projection (one GEMM with N = 3C instead of a q|k GEMM plus a transposed V^T GEMM).  The tile is staged as it lies,
+// sV[d / 32][key][d % 32] (64-byte rows: four consecutive keys cover all 64 banks, no padding), and the V^T fragment of the PV MFMA — a
+// lane wants 4 consecutive KEYS of one d — is what gfx950's transposing LDS read delivers: in every 16-lane group lane i passes the
+// address of key i/4, columns 4(i%4)..+3 of a [4 keys][16 d] block and receives the four keys of column i (ds_read_b64_tr_b16; probed on
+// the hardware, _variants/tr_probe.hip).  Same two 8-byte LDS reads per fragment as the V^T form, same MFMA k-slot order.
+typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) h4_t* lds_h4_ptr;
+
+template <int D, bool VRM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 2, D == 64 ? 3 : 2)))
 void flash_attn_kernel(const MgldAttn p) {
   constexpr int KT = 64;             // keys per tile
@@ -77,8 +86,13 @@ void flash_attn_kernel(const MgldAttn p) {
     const int v = tid + i * 256;
     krow[i] = v / (D / 8);
     kptr[i] = Kp + (v - krow[i] * (D / 8)) * 8;
-    vkey[i] = (v & 7) * 8;
-    vptr[i] = Vp + (int64_t)(v >> 3) * p.vt_sd;
+    if constexpr (VRM) {              // row-major V: the same (key, 8-d chunk) decomposition as K
+      vkey[i] = krow[i];
+      vptr[i] = Vp + (v - krow[i] * (D / 8)) * 8;
+    } else {
+      vkey[i] = (v & 7) * 8;
+      vptr[i] = Vp + (int64_t)(v >> 3) * p.vt_sd;
+    }
   }
   const int kv_last8 = ((Nkv + 7) & ~7) - 8;   // last 8-key group of a V^T row (rows are zero-padded to a multiple of 8)
   auto load_tile = [&](int kbase) {
@@ -86,18 +100,23 @@ void flash_attn_kernel(const MgldAttn p) {
 #pragma unroll
       for (int i = 0; i < NKV; ++i) {
         rk[i] = *(const f16x8*)(kptr[i] + (int64_t)(kbase + krow[i]) * p.k_si);
-        rv[i] = *(const f16x8*)(vptr[i] + kbase + vkey[i]);
+        if constexpr (VRM) rv[i] = *(const f16x8*)(vptr[i] + (int64_t)(kbase + vkey[i]) * p.vt_sd);
+        else rv[i] = *(const f16x8*)(vptr[i] + kbase + vkey[i]);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NKV; ++i) {
         rk[i] = *(const f16x8*)(kptr[i] + (int64_t)min(kbase + krow[i], Nkv - 1) * p.k_si);
-        const int key0 = kbase + vkey[i];
-        f16x8 t = *(const f16x8*)(vptr[i] + min(key0, kv_last8));
+        if constexpr (VRM) {   // keys past Nkv: a real row (finite values) — their probabilities are exactly 0
+          rv[i] = *(const f16x8*)(vptr[i] + (int64_t)min(kbase + vkey[i], Nkv - 1) * p.vt_sd);
+        } else {
+          const int key0 = kbase + vkey[i];
+          f16x8 t = *(const f16x8*)(vptr[i] + min(key0, kv_last8));
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (key0 + j >= Nkv) t[j] = (f16)0.f;   // the pad columns of a V^T row are not required to hold zeros
-        rv[i] = t;
+          for (int j = 0; j < 8; ++j)
+            if (key0 + j >= Nkv) t[j] = (f16)0.f;   // the pad columns of a V^T row are not required to hold zeros
+          rv[i] = t;
+        }
       }
     }
   };
@@ -109,10 +128,14 @@ void flash_attn_kernel(const MgldAttn p) {
       const int v = tid + i * 256;
       const int row = v / (D / 8), cv = v - row * (D / 8);
       *(f16x8*)(sK + row * KS + cv * 8) = rk[i];
-      const int d = v >> 3, kv = v & 7;
-      f16* dst = sV + d * VS + kv * 8;
-      *(f16x4*)(dst) = f16x4{rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
-      *(f16x4*)(dst + 4) = f16x4{rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
+      if constexpr (VRM) {           // sV[d / 32][key][d % 32]: one 16-byte store
+        *(f16x8*)(sV + ((cv >> 2) * KT + row) * 32 + (cv & 3) * 8) = rv[i];
+      } else {
+        const int d = v >> 3, kv = v & 7;
+        f16* dst = sV + d * VS + kv * 8;
+        *(f16x4*)(dst) = f16x4{rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
+        *(f16x4*)(dst + 4) = f16x4{rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
+      }
     }
   };
 
@@ -194,10 +217,21 @@ void flash_attn_kernel(const MgldAttn p) {
       for (int jj = 0; jj < 8; ++jj) pf[jj] = (f16)st[k2][c2 * 8 + jj];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const f16* vrow = sV + (dt * 32 + l31) * VS + k2 * 32 + c2 * 16 + lhi * 4;
-        const f16x4 v0 = *(const f16x4*)(vrow);
-        const f16x4 v1 = *(const f16x4*)(vrow + 8);
-        const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        f16x8 vf;
+        if constexpr (VRM) {
+          // this lane's 16-lane group covers d = dt*32 + (l31 & 16) .. +15; it passes the address of key key0 + (l31 & 15) / 4,
+          // columns 4 * (l31 & 3) .. +3 of that block and receives keys key0 .. key0+3 of ITS d (the transposing read)
+          const int key0 = k2 * 32 + c2 * 16 + lhi * 4;
+          const f16* blk = sV + (dt * KT + key0 + ((l31 & 15) >> 2)) * 32 + (l31 & 16) + (l31 & 3) * 4;
+          const h4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)(blk));
+          const h4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)(blk + 8 * 32));
+          vf = f16x8{(f16)t0[0], (f16)t0[1], (f16)t0[2], (f16)t0[3], (f16)t1[0], (f16)t1[1], (f16)t1[2], (f16)t1[3]};
+        } else {
+          const f16* vrow = sV + (dt * 32 + l31) * VS + k2 * 32 + c2 * 16 + lhi * 4;
+          const f16x4 v0 = *(const f16x4*)(vrow);
+          const f16x4 v1 = *(const f16x4*)(vrow + 8);
+          vf = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        }
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
       }
     }
@@ -257,10 +291,11 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
   MGLD_REQUIRE((p->q_sb & 7) == 0 && (p->q_si & 7) == 0 && (p->q_sh & 7) == 0, "attention: q strides % 8");
   MGLD_REQUIRE((p->k_sb & 7) == 0 && (p->k_si & 7) == 0 && (p->k_sh & 7) == 0, "attention: k strides % 8");
   MGLD_REQUIRE((p->vt_sb & 7) == 0 && (p->vt_sh & 7) == 0 && (p->vt_sd & 7) == 0, "attention: vt strides % 8");
+  MGLD_REQUIRE(p->v_rowmajor == 0 || p->v_rowmajor == 1, "attention: v_rowmajor must be 0 or 1");
   MGLD_REQUIRE((p->o_sb & 3) == 0 && (p->o_si & 3) == 0 && (p->o_sh & 3) == 0, "attention: o strides % 4");
   MGLD_REQUIRE((((uintptr_t)p->Q | (uintptr_t)p->K | (uintptr_t)p->Vt) & 15) == 0 && ((uintptr_t)p->O & 7) == 0,
                "attention: pointer alignment");
-  MGLD_REQUIRE(p->vt_sd >= ((p->Nkv + 7) & ~7), "attention: vt rows must be padded to a multiple of 8 keys");
+  if (!p->v_rowmajor) MGLD_REQUIRE(p->vt_sd >= ((p->Nkv + 7) & ~7), "attention: vt rows must be padded to a multiple of 8 keys");
   dim3 grid(cdiv(p->Nq, 128), p->heads, p->batch);
   constexpr int LDS64 = 2 * (64 * (64 + 8) + 64 * (64 + 4)) * 2, LDS128 = 2 * (64 * (128 + 8) + 128 * (64 + 4)) * 2;
   static bool attr_done = false;
@@ -268,7 +303,17 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
     (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
     attr_done = true;
   }
-  if (p->head_dim == 64)
+  if (p->v_rowmajor) {
+    static bool attr_done2 = false;
+    if (!attr_done2) {
+      (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+      attr_done2 = true;
+    }
+    if (p->head_dim == 64)
+      hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p);
+    else
+      hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, dim3(256), LDS128, (hipStream_t)stream, *p);
+  } else if (p->head_dim == 64)
     hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), LDS64, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), LDS128, (hipStream_t)stream, *p);

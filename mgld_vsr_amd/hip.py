@@ -45,7 +45,7 @@ class MgldAttn(C.Structure):
         ("k_sb", C.c_int64), ("k_si", C.c_int64), ("k_sh", C.c_int64),
         ("vt_sb", C.c_int64), ("vt_sh", C.c_int64), ("vt_sd", C.c_int64),
         ("o_sb", C.c_int64), ("o_si", C.c_int64), ("o_sh", C.c_int64),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("v_rowmajor", C.c_int32),
     ]
 
 
@@ -303,14 +303,20 @@ def layernorm(x, gamma, beta, y, eps=1e-5):
     return y
 
 
-def attention(q, k, vt, o, *, batch, heads, Nq, Nkv, head_dim, q_strides, k_strides, vt_strides, o_strides, scale):
+def attention(q, k, vt, o, *, batch, heads, Nq, Nkv, head_dim, q_strides, k_strides, vt_strides, o_strides, scale, v_rowmajor=False):
+    """v_rowmajor: `vt` is V itself, laid out like k (vt_strides = (batch, key row, head)) — the third column block of a fused q|k|v
+    projection; otherwise V^T [head][d][key] with vt_strides = (batch, head, d)."""
     _req_cuda(q, k, vt, o)
     p = MgldAttn()
     p.Q, p.K, p.Vt, p.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
     p.batch, p.heads, p.Nq, p.Nkv, p.head_dim = batch, heads, Nq, Nkv, head_dim
     p.q_sb, p.q_si, p.q_sh = q_strides
     p.k_sb, p.k_si, p.k_sh = k_strides
-    p.vt_sb, p.vt_sh, p.vt_sd = vt_strides
+    if v_rowmajor:
+        p.vt_sb, p.vt_sd, p.vt_sh = vt_strides
+        p.v_rowmajor = 1
+    else:
+        p.vt_sb, p.vt_sh, p.vt_sd = vt_strides
     p.o_sb, p.o_si, p.o_sh = o_strides
     p.scale = scale
     with timed("attention", {"flops": 4.0 * batch * heads * Nq * Nkv * head_dim, "bytes": 2.0 * batch * heads * head_dim * (2 * Nq + 2 * Nkv), "d": head_dim}):

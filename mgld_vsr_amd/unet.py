@@ -13,6 +13,8 @@ token-major (NHWC) fp16 activations:
   * cross-attention K / V^T of the (constant) text context are computed once and cached.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -182,9 +184,22 @@ class AttentionBlock(nn.Module):
             wqk = torch.cat([w[:, 0].reshape(C, C), w[:, 1].reshape(C, C)], 0)
             bqk = torch.cat([b[:, 0].reshape(C), b[:, 1].reshape(C)], 0)
             return wqk, bqk, w[:, 2].reshape(C, C), b[:, 2].reshape(C)
+        N = x.hw
+        if QKV_FUSED:      # the conv1d qkv (per head [q | k | v] rows, openaimodel.py:515-519, 582-594) re-ordered to [q | k | v] x heads: one GEMM
+            def fused(w, b):
+                wqk_, bqk_, wv_, bv_ = split(w, b)
+                return torch.cat([wqk_, wv_], 0), torch.cat([bqk_, bv_], 0)
+            wqkv, bqkv = eng.weight("qkv", (self.qkv.weight, self.qkv.bias), fused)
+            qkv = eng.linear(x=xn, w=wqkv, bias=bqkv)                 # [rows, 3C]: q | k | v, head-major inside each
+            o = eng.act(x.n, x.h, x.w, C)
+            hip.attention(qkv.v, qkv.v[:, C:], qkv.v[:, 2 * C:], o.v, batch=x.n, heads=H, Nq=N, Nkv=N, head_dim=ch,
+                          q_strides=(N * 3 * C, 3 * C, ch), k_strides=(N * 3 * C, 3 * C, ch), vt_strides=(N * 3 * C, 3 * C, ch),
+                          o_strides=(N * C, C, ch), scale=ch ** -0.5, v_rowmajor=True)
+            eng.launches += 1
+            wp = eng.weight("c1", (self.proj_out.weight,), pack_conv1x1)
+            return eng.linear(o, wp, eng.f32("b", self.proj_out.bias), out=out, resid=x)
         wqk, bqk = eng.weight("qk", (self.qkv.weight, self.qkv.bias), lambda w, b: split(w, b)[:2])
         wv, bv = eng.weight("v", (self.qkv.weight, self.qkv.bias), lambda w, b: split(w, b)[2:])
-        N = x.hw
         qk = eng.linear(x=xn, w=wqk, bias=bqk)                      # [rows, 2C]: q | k, head-major
         Np = (N + 7) // 8 * 8                                       # key axis padded to 16-byte rows
         vt = eng.arena.alloc((x.n * C, Np), torch.float16)          # per frame [C, Np] = V^T
@@ -228,9 +243,24 @@ class MemoryEfficientCrossAttention(nn.Module):
 MemoryEfficientSelfAttention = MemoryEfficientCrossAttention
 
 
+QKV_FUSED = os.environ.get("MGLD_QKV_FUSED", "1") != "0"    # q|k|v as ONE projection, V consumed row-major by the attention kernel
+
+
 def _self_attention(eng, attn, xn, frames, N, resid, out=None):
     """softmax(q k^T / sqrt(d)) v over the N tokens of each frame; xn: 2-D [frames*N, C] normalized tokens."""
     C, H, d = attn.heads * attn.dim_head, attn.heads, attn.dim_head
+    if QKV_FUSED:
+        # to_q | to_k | to_v (attention.py:323-330) as one GEMM with N = 3C: the normalised tokens are read once, and the attention
+        # kernel takes V as it lies (row-major, transposing LDS reads) — no transposed V^T projection, one launch less per block
+        wqkv = eng.weight("qkv", (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight), lambda q, k, v: torch.cat([q, k, v], 0))
+        qkv = eng.linear(xn, wqkv, None)
+        o = eng.empty(frames * N, C)
+        hip.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], o, batch=frames, heads=H, Nq=N, Nkv=N, head_dim=d,
+                      q_strides=(N * 3 * C, 3 * C, d), k_strides=(N * 3 * C, 3 * C, d), vt_strides=(N * 3 * C, 3 * C, d),
+                      o_strides=(N * C, C, d), scale=d ** -0.5, v_rowmajor=True)
+        eng.launches += 1
+        wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
+        return eng.linear(o, wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid)
     wqk = eng.weight("qk", (attn.to_q.weight, attn.to_k.weight), lambda q, k: torch.cat([q, k], 0))
     wv = eng.weight("w", (attn.to_v.weight,), lambda v: v)
     qk = eng.linear(xn, wqk, None)

@@ -75,9 +75,9 @@ def dry(monkeypatch):
             return outs[-1] if outs else None
         return f
 
-    def attention(q, k, vt, o, *, batch, heads, Nq, Nkv, head_dim, q_strides, k_strides, vt_strides, o_strides, scale):
+    def attention(q, k, vt, o, *, batch, heads, Nq, Nkv, head_dim, q_strides, k_strides, vt_strides, o_strides, scale, v_rowmajor=False):
         assert head_dim in (64, 128) and all(s % 8 == 0 for s in q_strides + k_strides + vt_strides)
-        assert vt_strides[2] >= (Nkv + 7) // 8 * 8
+        assert v_rowmajor or vt_strides[2] >= (Nkv + 7) // 8 * 8
         rec.calls.append(("attention", (q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr())))
         return o
 

@@ -629,6 +629,38 @@ def test_flash_attention(hip, B, H, Nq, Nkv, D):
     assert rel_l2(got, ref) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,Nq,Nkv,D", [(2, 5, 256, 256, 64), (1, 2, 200, 77, 64), (2, 4, 130, 130, 128), (1, 1, 64, 64, 64),
+                                          (1, 3, 1024, 1024, 64), (3, 2, 64, 5, 64), (1, 4, 300, 300, 128)])
+def test_flash_attention_rowmajor_v(hip, B, H, Nq, Nkv, D):
+    """v_rowmajor: q, k, v are the three column blocks of ONE fused projection [tokens, 3*H*D]; V is transposed by the LDS read
+    (ds_read_b64_tr_b16).  Must give the same bits as the V^T form on the same operands (same products, same summation order), ragged
+    last tiles included."""
+    q, k, v = h16(rnd(B, H, Nq, D, seed=41)), h16(rnd(B, H, Nkv, D, seed=42)), h16(rnd(B, H, Nkv, D, seed=43))
+    scale = D ** -0.5
+    ref = _attn_ref(q.float(), k.float(), v.float(), scale)
+    C_ = H * D
+    N = max(Nq, Nkv)
+    qkv = torch.zeros(B * N, 3 * C_, dtype=torch.half)          # one token-major buffer, q | k | v side by side (rows past Nq / Nkv unused)
+    qkv.view(B, N, 3 * C_)[:, :Nq, :C_] = q.permute(0, 2, 1, 3).reshape(B, Nq, C_)
+    qkv.view(B, N, 3 * C_)[:, :Nkv, C_:2 * C_] = k.permute(0, 2, 1, 3).reshape(B, Nkv, C_)
+    qkv.view(B, N, 3 * C_)[:, :Nkv, 2 * C_:] = v.permute(0, 2, 1, 3).reshape(B, Nkv, C_)
+    qkv = qkv.to(DEV)
+    o = torch.empty(B * Nq, C_, dtype=torch.half, device=DEV)
+    st = (N * 3 * C_, 3 * C_, D)
+    hip.attention(qkv, qkv[:, C_:], qkv[:, 2 * C_:], o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=st, k_strides=st,
+                  vt_strides=st, o_strides=(Nq * C_, C_, D), scale=scale, v_rowmajor=True)
+    got = o.cpu().float().reshape(B, Nq, H, D).permute(0, 2, 1, 3)
+    assert rel_l2(got, ref) < 2e-3
+    # against the V^T form
+    nkp = (Nkv + 7) // 8 * 8
+    vt = torch.zeros(B, H, D, nkp, dtype=torch.half)
+    vt[..., :Nkv] = v.permute(0, 1, 3, 2)
+    o2 = torch.empty_like(o)
+    hip.attention(qkv, qkv[:, C_:], vt.to(DEV), o2, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=st, k_strides=st,
+                  vt_strides=(H * D * nkp, D * nkp, nkp), o_strides=(Nq * C_, C_, D), scale=scale)
+    assert torch.equal(o, o2)
+
+
 def test_flash_attention_spike(hip):
     # force a large running-max jump in a late key tile (online-softmax rescale path)
     B, H, N, D = 1, 1, 192, 64
