@@ -214,7 +214,7 @@ def roofline(pipe, args, frames, noise, flows, masks):
                 h["ms"] += ms
                 h["launches"] += 1
         elif kind == "attention":
-            name = f"flash_attn_kernel<{info['d']}>"
+            name = f"flash_attn_kernel<{info['d']}, {'true' if info.get('vrm') else 'false'}>"      # as rocprofv3 prints it
             k = kern.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "splitk_launches": 0})
             k["flops"] += info["flops"]
             k["bytes"] += info["bytes"]

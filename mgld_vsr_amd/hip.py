@@ -319,7 +319,8 @@ def attention(q, k, vt, o, *, batch, heads, Nq, Nkv, head_dim, q_strides, k_stri
         p.vt_sb, p.vt_sh, p.vt_sd = vt_strides
     p.o_sb, p.o_si, p.o_sh = o_strides
     p.scale = scale
-    with timed("attention", {"flops": 4.0 * batch * heads * Nq * Nkv * head_dim, "bytes": 2.0 * batch * heads * head_dim * (2 * Nq + 2 * Nkv), "d": head_dim}):
+    with timed("attention", {"flops": 4.0 * batch * heads * Nq * Nkv * head_dim, "bytes": 2.0 * batch * heads * head_dim * (2 * Nq + 2 * Nkv), "d": head_dim,
+                             "vrm": bool(v_rowmajor)}):
         _chk(lib().mgld_attention(C.byref(p), stream_ptr()), "attention")
     return o
 

@@ -59,7 +59,7 @@ def test_structcond_small_vs_golden(hip, small_nets):
     out = sc(g["lat"].cuda(), g["t"].cuda())
     assert set(out.keys()) == {"16", "8", "4", "2"}
     for k, v in out.items():
-        assert record(f"structcond_small_{k}", rel_l2(v, g[f"sc_{k}"])) < 2e-3
+        assert record(f"structcond_small_{k}", rel_l2(v, g[f"sc_{k}"])) < {"16": 1.25e-3, "8": 1.6e-3, "4": 1.95e-3, "2": 2.2e-3}[k]   # 1.3 x measured
 
 
 def test_unet_small_vs_golden(hip, small_nets):
@@ -145,9 +145,9 @@ def test_sample_small_vs_golden(hip, tag):
               time_replace=S, x_T=g[f"{tag}_xT"], noise=noise)
     fn = model.sample if tag == "plain" else (lambda **k: model.sample_canvas(tile_size=16, tile_overlap=8, batch_size_sample=1, **k))
     x0_ng = fn(**kw)
-    assert record(f"sample_{tag}_noguid", rel_l2(x0_ng, g[f"{tag}_x0_noguid"])) < 1.6e-3
+    assert record(f"sample_{tag}_noguid", rel_l2(x0_ng, g[f"{tag}_x0_noguid"])) < 1.45e-3      # measured 1.08-1.10e-3 (reduced width, 4 steps)
     x0 = fn(flows=flows, masks=masks, **kw)
-    assert record(f"sample_{tag}_guided", rel_l2(x0, g[f"{tag}_x0"])) < 1.8e-3
+    assert record(f"sample_{tag}_guided", rel_l2(x0, g[f"{tag}_x0"])) < 1.45e-3                # measured 1.08-1.13e-3
     # hipGraph replay == eager launches, bit for bit
     x0_eager = fn(flows=flows, masks=masks, use_graph=False, **kw)
     assert torch.equal(x0_eager, x0)
@@ -171,20 +171,20 @@ def test_sample_loop_options_vs_golden(hip):
     def loop(**opt):       # p_sample_loop takes no `noise=`: route through sample() for the injected draws, p_sample_loop for the hooks
         return model._sample_loop(g["ctx"], g["lat"], shape, -10.0, None, None, g["xT"], S, S, False, None, g["noise"], None, True, hooks=opt)
     x = loop(start_T=600)
-    assert record("opts_start_T", rel_l2(x, g["x_start_T"])) < 2e-3
+    assert record("opts_start_T", rel_l2(x, g["x_start_T"])) < 1.15e-3
     # q_sample(x0, ts) inside the loop draws randn_like(x0) from the global generator, seeded 4242 in the golden run, one draw per step
     torch.manual_seed(4242)
     mn = torch.zeros(S, *shape)
     for i in reversed(range(S)):
         mn[i] = torch.randn(shape)
     x = loop(mask=g["mask"], x0=g["x0m"], mask_noise=mn)
-    assert record("opts_mask", rel_l2(x, g["x_mask"])) < 2e-3
+    assert record("opts_mask", rel_l2(x, g["x_mask"])) < 1.45e-3
     x = loop(adain_fea=g["adain_fea"])
-    assert record("opts_adain", rel_l2(x, g["x_adain"])) < 2e-3
+    assert record("opts_adain", rel_l2(x, g["x_adain"])) < 1.3e-3
     calls, imgs = [], []
     x = loop(callback=lambda i: calls.append((0, i)), img_callback=lambda img, i: (calls.append((1, i)), imgs.append(img.clone())))
     assert calls == [tuple(r) for r in g["cb_order"].tolist()]
-    assert record("opts_callbacks", rel_l2(torch.stack(imgs), g["cb_imgs"])) < 2e-3 and rel_l2(x, g["x_cb"]) < 2e-3
+    assert record("opts_callbacks", rel_l2(torch.stack(imgs), g["cb_imgs"])) < 1.45e-3 and rel_l2(x, g["x_cb"]) < 1.45e-3
     # the public entries accept the options (no NotImplementedError) and agree with the loop
     x2 = model.sample(cond=g["ctx"], struct_cond=g["lat"], guidance_scale=-10.0, batch_size=1, timesteps=S, time_replace=S, x_T=g["xT"],
                       noise=g["noise"], start_T=600)
@@ -216,11 +216,11 @@ def test_single_step_api_and_decode_first_stage_vs_golden(hip):
                                                                 t_replace=t_rep[:1], tile_size=16, tile_overlap=8, batch_size=1, tile_weights=tw)
             z = model.p_sample_canvas(x, g["ctx"], lat, ts, guidance_scale=-10.0, flows=flows, masks=masks, t_replace=t_rep[:1], tile_size=16,
                                       tile_overlap=8, batch_size=1, tile_weights=tw, noise=nz)
-        assert record(f"pstep_{tag}_x0", rel_l2(x0, g[f"{tag}_x0"])) < 1.7e-3
-        assert record(f"pstep_{tag}_mean", rel_l2(mean, g[f"{tag}_mean"])) < 1.6e-3
+        assert record(f"pstep_{tag}_x0", rel_l2(x0, g[f"{tag}_x0"])) < 1.55e-3          # measured 1.10 / 1.17e-3 (one network evaluation)
+        assert record(f"pstep_{tag}_mean", rel_l2(mean, g[f"{tag}_mean"])) < 1.4e-3
         assert abs(float(logvar.reshape(-1)[0]) - float(g[f"{tag}_logvar"].reshape(-1)[0])) < 1e-6
         assert abs(float(var.reshape(-1)[0]) - float(g[f"{tag}_var"].reshape(-1)[0])) < 1e-9
-        assert record(f"pstep_{tag}_z", rel_l2(z, g[f"{tag}_z"])) < 1.6e-3
+        assert record(f"pstep_{tag}_z", rel_l2(z, g[f"{tag}_z"])) < 1.35e-3
     dec = model.decode_first_stage(g["dec_z"].cuda())
     assert dec.shape == g["dec_out"].shape
     assert record("first_stage_image_decode", rel_l2(dec, g["dec_out"])) < 2e-3
@@ -265,7 +265,7 @@ def test_unet_fullwidth_vs_oracle(hip):
         eps_ref = onets.unet_forward(unet.state_dict(), ucfg, x, t, ctx, sc_ref)
     sc_out = sc(lat.cuda(), t.cuda())
     for k in sc_ref:
-        assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < 1.9e-3
+        assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < {"32": 1.0e-3, "16": 1.25e-3, "8": 1.5e-3, "4": 1.7e-3}[k]   # 1.3 x measured
     eps = unet(x.cuda(), t.cuda(), context=ctx.cuda(), struct_cond={k: v.cuda() for k, v in sc_ref.items()})
     assert record("unet_full", rel_l2(eps, eps_ref)) < 2.4e-3
 
@@ -306,7 +306,7 @@ def test_pipeline_small_end_to_end_vs_oracle(hip):
         _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
-    assert record("e2e_small_latent", rel_l2(lat, x0)) < 2e-3
+    assert record("e2e_small_latent", rel_l2(lat, x0)) < 1.55e-3
     # Reduced-width random-weight nets, 50 guided steps: the fp16-storage noise floor of this chain sits AT the north-star bar
     # and moves +-15 % between equally accurate kernel variants (8.9e-4 with the im2col conv, 1.05e-3 with the patch conv;
     # per-op parity identical, see unet_small / vae_small).  The 1e-3 bar itself is asserted on the full-width (SD-2.1
@@ -379,11 +379,10 @@ def test_pipeline_config0_fullwidth_vs_reference(hip):
         record(k, v)
     assert got["c1_full_structcond_8"] < 2e-3 and got["c1_full_vae_fea0"] < 2e-3
     assert got["c1_full_unet_eps"] < 2.6e-3 and got["c1_full_decoder"] < 2.5e-3
-    # the outputs.  The sampled latent meets the north_star tolerance (9.6e-4).  The colour-fixed frame of this config measures
-    # 1.03e-3: it inherits the video decoder's single-evaluation error (2.0e-3 here), of which 1.6e-3 is the rounding of the
-    # MFMA OPERANDS to fp16 alone (weights 1.1e-3 + activations 1.2e-3, tests/analysis/fp16_sim.py) — no storage
-    # format between the kernels can remove it, only a second MFMA pass per convolution would.  Bound: 1.1e-3.
-    assert got["c1_full_latent"] < 1e-3 and got["c1_full_frames"] < 1.1e-3, got
+    # the outputs, at the north_star tolerance.  The sampled latent measures 9.6e-4.  The colour-fixed frame of this one-frame config is the
+    # worst case of the path: it inherits the video decoder's single-evaluation error (2.0e-3 with plain fp16 weights -> frame 1.031e-3);
+    # with the weight-residual pass on the decoder (MgldIGemm.W2, engine.W2_DEFAULT) it measures 0.968e-3 (profiles/r03_w2_scopes_c1.json).
+    assert got["c1_full_latent"] < 1e-3 and got["c1_full_frames"] < 1e-3, got
     assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
 
 
@@ -422,7 +421,7 @@ def test_pipeline_frame_sharded_matches_unsharded(hip):
             assert rp.pos == len(rec.trace)                               # identical communication sequence
             assert o.shape[0] == Tn // world
             worst = max(worst, rp.worst, rel_l2(o, out0[sh.f0:sh.f1]), rel_l2(l, lat0[sh.f0:sh.f1]))
-    assert record("frame_sharded_vs_unsharded", worst) < 1.3e-3            # tile configs differ with M: fp16-level only
+    assert record("frame_sharded_vs_unsharded", worst) < 1.1e-3            # tile configs differ with M: fp16-level only
     # the same virtual ranks with the step replayed as hipGraph PIECES around its collectives (engine.GraphPieces: 2 halo
     # exchanges + the temporal-attention gather + the guidance gather = 5 pieces per step): bit-identical to eager launches
     for world, r in ((2, 1), (4, 2)):
@@ -480,7 +479,7 @@ def test_sample_canvas_tile_sharded_matches_unsharded(hip):
     finally:
         eng.tile_shard = None
     assert record("tile_sharded_vs_unsharded", worst) < 1e-3     # fewer tiles per pass -> other tile configs: fp16-level only
-    assert record("sample_canvas_guided_ref", rel_l2(x0, g["canvas_x0"])) < 1.8e-3
+    assert record("sample_canvas_guided_ref", rel_l2(x0, g["canvas_x0"])) < 1.45e-3
 
 
 def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
@@ -543,7 +542,7 @@ def test_sample_small_50_steps_vs_oracle(hip):
                           time_replace=S, x_T=xT, noise=noise)
         ref = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, ctx, lat, xT, [noise[S - 1 - k] for k in range(S)], S,
                            guidance_scale=-10.0, flows=fl, masks=mk)
-        assert record(f"sample50_small_{tag}", rel_l2(x0, ref)) < (1e-2 if fl is None else 5e-2)
+        assert record(f"sample50_small_{tag}", rel_l2(x0, ref)) < 7.5e-4         # measured 5.6 / 5.7e-4 (50 steps average the per-evaluation error down)
 
 
 def test_raft_flow_vs_oracle(hip):
@@ -590,7 +589,7 @@ def test_pipeline_estimate_flows_vs_oracle(hip):
     assert max(record("flowprep_fwd", rel_l2(f0[0], r0)), record("flowprep_bwd", rel_l2(f1[0], r1))) < 2.6e-3
     # the occlusion masks are thresholded (0/1): only pixels sitting on the threshold may flip
     flips = float((fo[0, :, 0].cpu() != rfo).float().mean()) + float((bo[0, :, 0].cpu() != rbo).float().mean())
-    assert record("flowprep_mask_flip_fraction", flips) < 1e-3
+    assert record("flowprep_mask_flip_fraction", flips) < 2.5e-4      # measured 1.2e-4 of the mask pixels
 
 
 def test_text_tower_vs_oracle(hip):
@@ -608,7 +607,7 @@ def test_text_tower_vs_oracle(hip):
     out = emb([""])
     ref = otext.encode_with_transformer(emb.state_dict(), toks[:1], heads=2, layer_idx=1)
     assert out.shape == (1, 77, 128)
-    assert record("text_tower", rel_l2(out, ref)) < 1e-3
+    assert record("text_tower", rel_l2(out, ref)) < 8.5e-4
     with pytest.raises(NotImplementedError):
         emb(["a photo"])
 
