@@ -114,10 +114,11 @@ def split_residual(w32, scale=None):
 #   unet_io   the UNet's input_blocks.0 and out convolutions
 #   unet      every contraction of the UNet and the struct-cond encoder
 #   vae_dec_mid / vae_dec_up<0..3> / vae_dec_fuse / vae_dec_out   parts of the video decoder (level 0 = 512^2)
-# Default = the video decoder without its fusion layers + the UNet's first / last convolution.  Measured per scope on the full-width
-# workloads (profiles/r03_w2_scopes_*): 8 x 512^2 frames -8 % / latent -1.7 % for +2.7 % segment time; BASELINE configs[0] (one frame, the
-# worst case: decoder error 2.0e-3) frames 1.031e-3 -> 0.968e-3.  The fusion layers alone cost +1.9 % time for -0.3 % / -1.2 %: not taken.
-W2_DEFAULT = "vae_dec_mid,vae_dec_up0,vae_dec_up1,vae_dec_up2,vae_dec_up3,vae_dec_out,unet_io"
+# Default = the video decoder's mid block, 64^2 / 128^2 / 512^2 levels and conv_out + the UNet's first / last convolution.  Measured per
+# scope on the full-width workloads (profiles/r03_w2_scopes_*): 8 x 512^2 frames -6 % / latent -1.7 % for ~+2 % segment time; BASELINE
+# configs[0] (one frame, the worst case: decoder error 2.0e-3) frames 1.031e-3 -> 0.986e-3.  Adding the 256^2 level (up1) gives 0.968e-3
+# for another +1.5 % time, the fusion layers cost +1.9 % for -0.3 % / -1.2 %: not taken.
+W2_DEFAULT = "vae_dec_mid,vae_dec_up0,vae_dec_up2,vae_dec_up3,vae_dec_out,unet_io"
 
 
 def w2_scopes():

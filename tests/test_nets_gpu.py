@@ -381,7 +381,7 @@ def test_pipeline_config0_fullwidth_vs_reference(hip):
     assert got["c1_full_unet_eps"] < 2.6e-3 and got["c1_full_decoder"] < 2.5e-3
     # the outputs, at the north_star tolerance.  The sampled latent measures 9.6e-4.  The colour-fixed frame of this one-frame config is the
     # worst case of the path: it inherits the video decoder's single-evaluation error (2.0e-3 with plain fp16 weights -> frame 1.031e-3);
-    # with the weight-residual pass on the decoder (MgldIGemm.W2, engine.W2_DEFAULT) it measures 0.968e-3 (profiles/r03_w2_scopes_c1.json).
+    # with the weight-residual pass on the decoder (MgldIGemm.W2, engine.W2_DEFAULT) it measures 0.986e-3 (profiles/r03_w2_scopes_c1.json).
     assert got["c1_full_latent"] < 1e-3 and got["c1_full_frames"] < 1e-3, got
     assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
 
