@@ -108,7 +108,8 @@ typedef struct MgldIGemm {
                              [Cout][ky][kx][Cin]; 0,0 (or 3,3) = the 3x3 kernel.  Other sizes use the per-lane gather path
                              (RAFT's 7x7, 1x5, 5x1 and strided 1x1 convolutions, raft_arch.py:216,383-389,430).         */
   int32_t tune;           /* 0 = the launcher picks the kernel variant.  > 0 (tuning runs / variant tests): force variant
-                             tune - 1 of the 2-D-tile patch conv where it applies (ids: csrc/igemm.hip "conv3q launch plan"). */
+                             tune - 1 of the 2-D-tile patch conv where it applies (ids: csrc/igemm.hip "conv3q launch plan");
+                             TCONV3: 15 = tiles of consecutive rows, 14 = the frame-interleaved row order whatever the frame size (bit-identical). */
   float w2_scale;         /* see W2 */
   const void* W2;         /* NULL, or the fp16 ROUNDING RESIDUAL of the weights in the layout / strides of W:
                              W2 = fp16((W_fp32 - fp32(W)) / w2_scale), w2_scale a power of two (2^-11 keeps the residual in fp16's normal

@@ -69,12 +69,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   // (big-M / small-N problems: the 64x64-level projections).  order 2: the M/BM blocks that share a W tile run on one XCD (XCD k
   // owns the column tiles k, k+8, ...): each XCD streams an eighth of the weights (small-M / deep-K problems).  Speed only.
   int tile_m = blockIdx.x, tile_n = blockIdx.y;
-  if (order == 1) {
+  if ((order & 0xff) == 1) {
     const int lin = blockIdx.x + gridDim.x * blockIdx.y;
     const int xcd = lin & 7, j = lin >> 3;
     tile_m = xcd + 8 * (j / (int)gridDim.y);
     tile_n = j % (int)gridDim.y;
-  } else if (order == 2) {
+  } else if ((order & 0xff) == 2) {
     const int lin = blockIdx.x + gridDim.x * blockIdx.y;
     const int xcd = lin & 7, j = lin >> 3;
     tile_n = xcd + 8 * (j / (int)gridDim.x);
@@ -82,6 +82,19 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
   }
   const int bm0 = tile_m * BM;
   const int bn0 = tile_n * BN;
+  // TCONV row order (order bits 8..: lg, set by the launcher): a tile takes 2^lg consecutive PIXELS of every frame of one clip instead of BM
+  // consecutive rows of one frame.  The three temporal taps of the tile then read the same BM rows (shifted by one frame): each frame
+  // row leaves HBM once per column tile and the other two taps hit this XCD's L2, instead of three passes 2*HW*C bytes apart (the VAE's
+  // 256^2 / 512^2 levels: 67 MB per frame).  Same K order per output element: bit-identical to the consecutive order.
+  RowMapFrames trows{bm0, 31, 0x7fffffff, 0, p.M};
+  if constexpr (MODE == MGLD_MODE_TCONV3) {
+    const int lg = order >> 8;
+    if (lg) {
+      const int tpc = p.HW >> lg;              // tiles per clip
+      const int clip = tile_m / tpc;
+      trows = RowMapFrames{clip * p.T * p.HW + ((tile_m - clip * tpc) << lg), lg, (1 << lg) - 1, p.HW, p.M};
+    }
+  }
   const bool splitk = (ws != nullptr);
   const int bz = splitk ? 0 : blockIdx.z;
   const int kz = splitk ? blockIdx.z : 0;
@@ -139,8 +152,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const int row = (j * NW + wave) * 8 + (lane >> 3);
-      const int m = bm0 + row;
-      const bool valid = m < M;
+      const int m = (MODE == MGLD_MODE_TCONV3) ? trows(row) : (bm0 + row < M ? bm0 + row : -1);
+      const bool valid = m >= 0;
       const int mm = valid ? m : 0;
       fa_step[j] = 0; fa_mask[j] = 0;
       if constexpr (MODE == MGLD_MODE_LINEAR) {
@@ -182,8 +195,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const int row = (j * NW + wave) * 8 + (lane >> 3);
-      const int m = bm0 + row;
-      ra[j].valid = m < M;
+      const int m = (MODE == MGLD_MODE_TCONV3) ? trows(row) : (bm0 + row < M ? bm0 + row : -1);
+      ra[j].valid = m >= 0;
       ra[j].base = 0; ra[j].iy0 = 0; ra[j].ix0 = 0;
       const int mm = ra[j].valid ? m : 0;  // computed unconditionally (branch-free); invalid rows read the zero page
       if constexpr (MODE == MGLD_MODE_LINEAR) {
@@ -454,7 +467,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_kernel(const
 #undef MGLD_AFTER_ISSUE
 #undef MGLD_SCALE_ACC
 
-  tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, RowMapLinear{bm0, M}, bn0, wm, wn, wave, lane, acc, smem);
+  if constexpr (MODE == MGLD_MODE_TCONV3) tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, trows, bn0, wm, wn, wave, lane, acc, smem);
+  else tile_epilogue<BM, BN, WM, WN>(p, ws, splitk, kz, bz, RowMapLinear{bm0, M}, bn0, wm, wn, wave, lane, acc, smem);
 }
 
 // split-K finish: out = alpha*act(sum_z ws[z] + bias + bias_m + rowvec) + beta*R.  One thread per 4 columns.
@@ -513,6 +527,26 @@ inline int tile_order(const MgldIGemm* p, int gx, int gy) {
   return o;
 }
 
+// TCONV row order (see the kernel): log2 of the pixels per frame a tile takes, 0 = BM consecutive rows.  Whole clips only (no frame
+// shard offset), T a power of two dividing BM, whole tiles per frame — and frames of >= 24 MB, where the three taps of a row tile are too
+// far apart for the L2s.  Measured (tools/tconv_bench.py, profiles/r03_tconv_rows.txt): 512^2 x 128 821 -> 766 us, 1024^2 x 128 (T = 4)
+// 1658 -> 1524, 256^2 x 256 with the residual pass 731 -> 688; 128^2 x 512 (17 MB frames) 339 -> 372: slower, hence the threshold.
+// The launch stays far from the HBM roofline either way (1.4 TB/s): what bounds it is the bytes a CU keeps in flight — two blocks x one
+// 32 KB stage, half of it weights — not the tap re-reads.  env MGLD_TCONV_ROWS=0: consecutive rows; =2: interleave regardless of the
+// frame size (tests); tune 15: consecutive rows for this launch.
+inline int tconv_rows_lg(const MgldIGemm* p, int BM) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MGLD_TCONV_ROWS"); on = e ? atoi(e) : 1; }
+  const int T = p->T;
+  if (!on || p->tune == 15 || p->t_off != 0 || T < 2 || (T & (T - 1)) || BM % T || BM / T < 8) return 0;
+  if (on != 2 && p->tune != 14 && (int64_t)p->HW * p->Cin * 2 < (24 << 20)) return 0;
+  const int ppt = BM / T;
+  if (p->HW % ppt || p->M % (T * p->HW)) return 0;
+  int lg = 0;
+  while ((1 << lg) < ppt) ++lg;
+  return lg;
+}
+
 template <int MODE, bool FAST, int BM, int BN, int WM, int WN, int NST, bool TWO = false>
 void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   constexpr int LDS = (NST == 0 ? 2 : NST) * (BM + BN) * ROWB;
@@ -525,8 +559,10 @@ void launch_fast(const MgldIGemm* p, hipStream_t s, int splits, int kchunk) {
   constexpr int THREADS = 64 * (BM / WM) * (BN / WN);
   const int gz = splits > 1 ? splits : (p->batch > 0 ? p->batch : 1);
   dim3 grid(cdiv(p->M, BM), cdiv(p->N, BN), gz);
+  int order = tile_order(p, (int)grid.x, (int)grid.y);
+  if constexpr (MODE == MGLD_MODE_TCONV3) order |= tconv_rows_lg(p, BM) << 8;
   hipLaunchKernelGGL((igemm_kernel<MODE, FAST, BM, BN, WM, WN, NST, TWO>), grid, dim3(THREADS), LDS, s, *p,
-                     splits > 1 ? g_ws : nullptr, kchunk, tile_order(p, (int)grid.x, (int)grid.y));
+                     splits > 1 ? g_ws : nullptr, kchunk, order);
 }
 
 // FAST: every 64-deep stage lies inside one tap and inside K (see the kernel)
@@ -611,7 +647,27 @@ void choose(const MgldIGemm* p, int* cfg, int* splits, int* kchunk) {
     if (can && (p->tune == 10 || (fulln && p->tune != 11 && M >= 16384 && (M % 128) == 0))) { *cfg = 128320; return; }
   }
   if (p->act == MGLD_ACT_GEGLU) { *cfg = (t128 >= 256 || M <= 64) ? 128128 : 64128; return; }
-  if (N <= 32) { *cfg = 128032; return; }
+  if (N <= 32) {
+    // skinny outputs over a deep K (the UNet's last conv: 320 -> 4 at 64x64, K = 2880): M / 128 blocks of one 45-stage chain each leave the
+    // CUs waiting on a DMA round trip per stage (72 us at 10 TF/s); a K split over grid.z runs the chains side by side, and the reduce pass
+    // over an M x 4 output costs nothing.  env MGLD_IGEMM_SKINNY_SPLIT=0: no split (A/B).
+    static int skinny = -1;
+    if (skinny < 0) { const char* e = getenv("MGLD_IGEMM_SKINNY_SPLIT"); skinny = e ? atoi(e) : 1; }
+    const int64_t t = (int64_t)cdiv(M, 128) * batch;
+    *cfg = 128032;
+    if (skinny && batch == 1 && K >= 1536 && t < 2 * num_cus() && g_ws != nullptr) {
+      int sp = (int)((4 * num_cus() + t - 1) / t);
+      if (sp > (int)(K / 512)) sp = (int)(K / 512);
+      if (sp > 8) sp = 8;
+      if (sp >= 2 && (size_t)sp * M * N * sizeof(float) <= g_ws_bytes) {
+        int kc = (int)((K + sp - 1) / sp);
+        kc = (kc + BK - 1) / BK * BK;
+        sp = (int)((K + kc - 1) / kc);
+        if (sp >= 2) { *splits = sp; *kchunk = kc; }
+      }
+    }
+    return;
+  }
   if (N <= 64) { *cfg = 128064; return; }
   // N = 64 (mod 128), e.g. the 320-channel level: 128-wide tiles would idle a sixth of the MFMA work on padding, 64-wide
   // tiles divide N exactly and fit three blocks per CU
@@ -699,7 +755,7 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
   }
   snprintf(buf, buflen, p->W2 ? "igemm_kernel<%d, %s, %d, %d, %d, %d, 2, true>" : "igemm_kernel<%d, %s, %d, %d, %d, %d, 2, false>", p->mode,
            fast_ok(p) ? "true" : "false", bm, bn, wm, wn);
-  return cfg == 128128 ? splits : 1;
+  return (cfg == 128128 || cfg == 128032) ? splits : 1;
 }
 
 extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
@@ -758,7 +814,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
       else launch_fast<MGLD_MODE_LINEAR, true, 128, 320, 32, 160, 2>(p, s, 1, kchunk);
       return mgld_check_launch("igemm");
     case 64128: return launch_cfg<64, 128, 32, 64>(p, s, 1, kchunk);
-    case 128032: return launch_cfg<128, 32, 32, 32>(p, s, 1, kchunk);
+    case 128032: return launch_cfg<128, 32, 32, 32>(p, s, splits, kchunk);
     case 128064: return launch_cfg<128, 64, 64, 32>(p, s, 1, kchunk);
     default: return launch_cfg<64, 64, 32, 32>(p, s, 1, kchunk);
   }

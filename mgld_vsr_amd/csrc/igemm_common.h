@@ -71,6 +71,10 @@ struct RowMapLinear {   // BM consecutive rows starting at bm0
   int bm0, M;
   __device__ __forceinline__ int operator()(int r) const { const int m = bm0 + r; return m < M ? m : -1; }
 };
+struct RowMapFrames {   // TCONV: 2^lg consecutive pixels of EVERY frame of a clip (rows >> lg = frame); lg = 31: consecutive rows
+  int m0, lg, mask, HW, M;
+  __device__ __forceinline__ int operator()(int r) const { const int m = m0 + (r >> lg) * HW + (r & mask); return m < M ? m : -1; }
+};
 template <int TX>
 struct RowMap2D {       // a TY x TX pixel tile of one frame, raster order inside the tile
   int fbase, y0, x0, H, W;

@@ -434,6 +434,51 @@ def test_igemm_tconv(hip, clips, T, c):
     assert rel_l2(_from_tok(out.cpu().float(), clips * T, h, w), ref) < 1e-3
 
 
+@pytest.mark.parametrize("clips,T,c,h,w", [(2, 8, 128, 8, 8), (1, 4, 64, 16, 8), (3, 8, 96, 4, 4), (1, 2, 256, 8, 8), (1, 8, 1280, 8, 8)])
+def test_igemm_tconv_frame_interleaved_rows(hip, clips, T, c, h, w):
+    """T a power of two and whole tiles per frame: the launcher hands a tile the same pixels of EVERY frame (the three temporal taps
+    re-read one set of rows; csrc/igemm.hip `tconv_rows_lg`, default for frames >= 24 MB, forced here by tune = 14).  Same arithmetic
+    per output element: bit-identical to tiles of consecutive rows (tune = 15), FAST and per-lane paths, split-K included; and both match Conv3d."""
+    hip.set_workspace(hip._test_ws)
+    x = h16(rnd(clips * T, c, h, w, seed=331))
+    wt = h16(rnd(c, c, 3, 1, 1, seed=332, scale=(3 * c) ** -0.5))
+    b = rnd(c, seed=333)
+    alpha = 0.6
+    x5 = x.float().reshape(clips, T, c, h, w).permute(0, 2, 1, 3, 4)
+    res = F.conv3d(x5, wt.float(), b, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(clips * T, c, h, w)
+    ref = alpha * res + (1 - alpha) * x.float()
+    xt = _to_tok(x).to(DEV)
+    wk = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, 3 * c).contiguous().to(DEV)
+    outs = []
+    for tune in (14, 15):             # 14: interleaved whatever the frame size (the launcher's own threshold is 24 MB per frame)
+        out = torch.full_like(xt, float("nan"))
+        hip.igemm(xt, wk, out, mode=hip.MODE_TCONV3, bias=b.to(DEV), resid=xt, alpha=alpha, beta=1 - alpha, tconv=(c, T, h * w), tune=tune)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(_from_tok(outs[0].float(), clips * T, h, w), ref) < 1e-3
+
+
+def test_igemm_skinny_output_splits_k(hip):
+    """N <= 32 over a deep K with fewer row tiles than 2 x CUs: the launcher splits K (csrc/igemm.hip choose()); result vs conv2d"""
+    hip.set_workspace(hip._test_ws)
+    n, cin, cout, h, w = 2, 320, 4, 32, 32
+    x = h16(rnd(n, cin, h, w, seed=341))
+    wt = h16(rnd(cout, cin, 3, 3, seed=342, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=343)
+    ref = F.conv2d(x.float(), wt.float(), b, padding=1)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    out = torch.full((n * h * w, cout), float("nan"), dtype=torch.half, device=DEV)
+    hip.IGEMM_LOG = []
+    try:
+        hip.igemm(_to_tok(x).to(DEV), wk, out, mode=hip.MODE_CONV3X3, bias=b.to(DEV), conv=(cin, h, w, h, w, 1, 1, 1, 0))
+        cfg = hip.igemm_config(hip.IGEMM_LOG[0])
+    finally:
+        hip.IGEMM_LOG = None
+    assert cfg % 1000000 == 128032 and cfg // 1000000 >= 2, cfg
+    assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
+
+
 # ---- W2: second MFMA pass on the fp16 rounding residual of the weights (MgldIGemm.W2) -------------------------------------
 def _w2_check(err_hi, err_w2):
     """fp32 weights are the truth; activations are exact fp16.  With fp16 weights the product carries their rounding (~2.3e-4 of the
@@ -465,7 +510,8 @@ def test_igemm_w2_linear(hip, M, N, K):
     (2, 1280, 1280, 8, 8, False),        # the 8x8 level
     (2, 128, 128, 16, 16, True),         # nearest-2x upsample folded in
     (1, 8, 128, 16, 16, False),          # Cin = 8: the per-lane gather path of igemm_kernel (conv_in of the decoders)
-    (1, 128, 3, 16, 16, False)])         # N = 3: conv_out
+    (1, 128, 3, 16, 16, False),          # N = 3: conv_out
+    (2, 320, 4, 32, 32, False)])         # N = 4 over K = 2880: the UNet's last conv, K split over grid.z (skinny-output split)
 def test_igemm_w2_conv3x3(hip, n, cin, cout, h, w, up2):
     """3x3 convolutions with the residual pass through the engine's own route (tiled weights where the patch kernel applies)"""
     from mgld_vsr_amd.engine import Act, Engine, pack_conv3x3, split_residual
