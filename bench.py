@@ -142,12 +142,12 @@ HBM_PEAK_GBPS = 8000.0      # HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s a
 def _pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.sh).  PMC counters cannot be read from inside this process;
-    the file is only used when it was taken for THIS kernel name on THIS kernel source (sha256 of the GEMM family's three source files),
+    the file is only used when it was taken for THIS kernel name on THIS kernel source (sha256 of the GEMM family's and the attention kernel's source files),
     else null."""
     import hashlib
     try:
         src = b""
-        for f in ("igemm_common.h", "igemm.hip", "conv3q.hip"):
+        for f in ("igemm_common.h", "igemm.hip", "conv3q.hip", "attention.hip"):
             with open(os.path.join(ROOT, "mgld_vsr_amd", "csrc", f), "rb") as fh:
                 src += fh.read()
         sha = hashlib.sha256(src).hexdigest()[:16]
@@ -238,9 +238,14 @@ def roofline(pipe, args, frames, noise, flows, masks):
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     gemm = [v for n, v in kern.items() if not n.startswith("flash_attn")]
     all_flops, all_ms = sum(v["flops"] for v in gemm), sum(v["ms"] for v in gemm)
-    by_kernel = [{"kernel": n, "ms_per_segment": round(v["ms"], 2), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                  "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4)}
-                 for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]]
+    def _entry(n, v):
+        e = {"kernel": n, "ms_per_segment": round(v["ms"], 2), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+             "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4), "algorithmic_bytes": round(v["bytes"] / v["launches"])}
+        tr = _pmc_traffic(n)          # HBM-side bytes per launch from the committed PMC pass, when it was taken on this build
+        if tr:
+            e["traffic"], e["traffic_over_algorithmic"] = tr, round(tr / max(1.0, v["bytes"] / v["launches"]), 2)
+        return e
+    by_kernel = [_entry(n, v) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]]
     hbm_out = {n: {"achieved_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "frac_of_peak": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                    "ms_per_segment": round(v["ms"], 2), "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2)}
                for n, v in hbm.items()}

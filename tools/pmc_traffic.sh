@@ -1,7 +1,7 @@
 # HBM traffic per launch of every GEMM-family / attention kernel (roofline.traffic): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
 # SEPARATE passes (counter collection only, no trace domains) over one eager segment of the default bench workload.
 # Writes gpurun_out/pmc_traffic.json keyed by the exact kernel instantiation name + the sha256 of the GEMM family's sources
-# (csrc/igemm_common.h + igemm.hip + conv3q.hip) it was taken on (bench.py uses an entry only when both match the running build);
+# (csrc/igemm_common.h + igemm.hip + conv3q.hip + attention.hip) it was taken on (bench.py uses an entry only when both match the running build);
 # copy it to profiles/r03_pmc_traffic.json.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -32,7 +32,7 @@ for k, (n, f) in fe.items():
     w = wr.get(k, [0, 0.0])[1]
     kern[k] = {"launches": n, "fetch_size_kb_per_launch": f / n, "write_size_kb_per_launch": w / n,
                "hbm_bytes_per_launch": (2.0 * f + w) / n * 1024.0}
-sha = hashlib.sha256(b"".join(open("mgld_vsr_amd/csrc/" + f, "rb").read() for f in ("igemm_common.h", "igemm.hip", "conv3q.hip"))).hexdigest()[:16]
+sha = hashlib.sha256(b"".join(open("mgld_vsr_amd/csrc/" + f, "rb").read() for f in ("igemm_common.h", "igemm.hip", "conv3q.hip", "attention.hip"))).hexdigest()[:16]
 res = {"gemm_src_sha16": sha, "kernels": kern,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `MGLD_SC_PRECOMPUTE=0 bench.py --steps 1 --warmup 0 --no-graph` "
                "(one 8x512^2 50-step segment, eager launches); counters in KB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
