@@ -4,6 +4,8 @@ as a reusable object.  Everything between "LR segment resident in HBM" and "HR f
 libmgld_hip launches on one stream.
 """
 import copy
+import os
+import time
 
 import numpy as np
 import torch
@@ -314,6 +316,10 @@ class SegmentPool:
         self._queues = [queue.Queue() for _ in self.pipes]
         self._threads = [threading.Thread(target=self._worker, args=(i,), daemon=True, name=f"mgld-segment-{i}") for i in range(len(self.pipes))]
         self._sem = threading.Semaphore(0)
+        # Entry offset between the workers.  Identical segments entered at the same instant run their launch sequences in lock-step — all in
+        # the 64x64-level convolutions together, all in the latency-bound 8x8 level together — and there is nothing left to fill the
+        # holes with; ANY offset of 2-26 ms breaks it: 670-675 -> 657 ms per segment at three in flight (profiles/r03_stagger.txt).
+        self.stagger_ms = float(os.environ.get("MGLD_STAGGER_MS", "4"))
         self.last_latency_ms = {}     # slot -> GPU-side latency of that job in the last _drive call (hipEvent pair on the worker's stream)
         for t in self._threads:
             t.start()
@@ -337,6 +343,8 @@ class SegmentPool:
                     if not ws_ready:
                         hip.ensure_workspace()                   # this thread's split-K scratch, for the thread's lifetime
                         ws_ready = True
+                    if self.stagger_ms > 0 and i > 0:            # worker i enters the GPU i * stagger_ms after worker 0 (see __init__)
+                        time.sleep(1e-3 * self.stagger_ms * i)
                     for slot, call in plan:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
