@@ -32,7 +32,7 @@ typedef __attribute__((address_space(3))) h4_t* lds_h4_ptr;
 
 template <int D, bool VRM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 2, D == 64 ? 3 : 2)))
-void flash_attn_kernel(const MgldAttn p) {
+void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   constexpr int KT = 64;             // keys per tile
   constexpr int KS = D + 8;          // K LDS row stride (halves): conflict-free ds_read_b128
   constexpr int VS = KT + 4;         // V^T LDS row stride (halves): 34 banks -> conflict-free ds_read_b64
@@ -47,8 +47,21 @@ void flash_attn_kernel(const MgldAttn p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // Workgroups go round-robin to the 8 XCDs in linear-id order, so the query blocks of one (batch, head) — which all stream the same K / V —
+  // land on eight different L2s and every XCD pulls every K / V through the fabric (PMC round 3: 187 MB per launch against 55 MB
+  // algorithmic).  xcd_order: XCD k takes the (batch, head) pairs k, k + 8, ... with all their query blocks back to back, K / V enter one
+  // L2 once.  (Launcher: only when batch * heads is a multiple of 8.)
+  int bx = blockIdx.x, b = blockIdx.z, h = blockIdx.y;
+  if (xcd_order) {
+    const int nqb = gridDim.x;
+    const int lin = bx + nqb * (h + (int)gridDim.y * b);
+    const int j = lin >> 3, jq = j / nqb;
+    const int g = (lin & 7) + 8 * jq;
+    bx = j - jq * nqb;
+    b = g / (int)gridDim.y;
+    h = g - b * (int)gridDim.y;
+  }
+  const int q0 = bx * 128 + wave * 32;
   const int Nq = p.Nq, Nkv = p.Nkv;
 
   const f16* __restrict__ Qp = (const f16*)p.Q + b * p.q_sb + h * p.q_sh;
@@ -297,6 +310,9 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
                "attention: pointer alignment");
   if (!p->v_rowmajor) MGLD_REQUIRE(p->vt_sd >= ((p->Nkv + 7) & ~7), "attention: vt rows must be padded to a multiple of 8 keys");
   dim3 grid(cdiv(p->Nq, 128), p->heads, p->batch);
+  static int xcd = -1;      // env MGLD_ATTN_XCD=0: dispatch order (A/B)
+  if (xcd < 0) { const char* e = getenv("MGLD_ATTN_XCD"); xcd = e ? atoi(e) : 1; }
+  const int order = (xcd && grid.x >= 2 && ((grid.y * grid.z) & 7) == 0) ? 1 : 0;
   constexpr int LDS64 = 2 * (64 * (64 + 8) + 64 * (64 + 4)) * 2, LDS128 = 2 * (64 * (128 + 8) + 128 * (64 + 4)) * 2;
   static bool attr_done = false;
   if (!attr_done) {
@@ -310,13 +326,13 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
       attr_done2 = true;
     }
     if (p->head_dim == 64)
-      hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p);
+      hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
     else
-      hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, dim3(256), LDS128, (hipStream_t)stream, *p);
+      hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, dim3(256), LDS128, (hipStream_t)stream, *p, order);
   } else if (p->head_dim == 64)
-    hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), LDS64, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
   else
-    hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), LDS128, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), LDS128, (hipStream_t)stream, *p, order);
   return mgld_check_launch("attention");
 }
 

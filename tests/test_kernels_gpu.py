@@ -655,7 +655,8 @@ def _attn_ref(q, k, v, scale):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nkv,D", [(2, 5, 256, 256, 64), (1, 2, 200, 77, 64), (2, 4, 130, 130, 128), (1, 1, 64, 64, 64),
-                                          (1, 3, 1024, 1024, 64), (3, 2, 64, 5, 64)])
+                                          (1, 3, 1024, 1024, 64), (3, 2, 64, 5, 64),
+                                          (8, 5, 300, 300, 64), (4, 6, 256, 77, 64)])   # batch * heads % 8 == 0: XCD-grouped block order
 def test_flash_attention(hip, B, H, Nq, Nkv, D):
     q, k, v = h16(rnd(B, H, Nq, D, seed=41)), h16(rnd(B, H, Nkv, D, seed=42)), h16(rnd(B, H, Nkv, D, seed=43))
     scale = D ** -0.5
@@ -676,7 +677,8 @@ def test_flash_attention(hip, B, H, Nq, Nkv, D):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nkv,D", [(2, 5, 256, 256, 64), (1, 2, 200, 77, 64), (2, 4, 130, 130, 128), (1, 1, 64, 64, 64),
-                                          (1, 3, 1024, 1024, 64), (3, 2, 64, 5, 64), (1, 4, 300, 300, 128)])
+                                          (1, 3, 1024, 1024, 64), (3, 2, 64, 5, 64), (1, 4, 300, 300, 128),
+                                          (8, 5, 300, 300, 64), (4, 6, 256, 77, 64)])
 def test_flash_attention_rowmajor_v(hip, B, H, Nq, Nkv, D):
     """v_rowmajor: q, k, v are the three column blocks of ONE fused projection [tokens, 3*H*D]; V is transposed by the LDS read
     (ds_read_b64_tr_b16).  Must give the same bits as the V^T form on the same operands (same products, same summation order), ragged
