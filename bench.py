@@ -382,8 +382,8 @@ def main():
     else:
         px = args.frames * args.size * args.size
         inflight = 3 if px <= 8 * 512 * 512 else (2 if px <= 16 * 512 * 512 else 1)
-    if shard is not None or (args.raft and args.guidance):
-        inflight = 1                          # the sharded modes spread ONE segment over the ranks; --raft estimates flows inside step()
+    if shard is not None:
+        inflight = 1                          # the sharded modes spread ONE segment over the ranks
     inflight = max(1, min(inflight, args.steps))
     if inflight > 1:
         # K segments as `inflight` concurrent streams of K / inflight segments: every worker thread owns a pipeline instance (its own
@@ -392,13 +392,17 @@ def main():
         from mgld_vsr_amd.pipeline import SegmentPool
         pool = SegmentPool(lambda: build_pipeline(args), inflight, first=pipe)
         ins = [(frames, noise, flows, masks)] + [make_inputs(pool.pipes[i], args, rank * inflight + i) for i in range(1, inflight)]
-        jobs = [((ins[j % inflight][0],), dict(flows=ins[j % inflight][2], masks=ins[j % inflight][3], noise=ins[j % inflight][1],
-                                               tile=TILE, use_graph=GRAPH)) for j in range(args.steps)]
+
+        def seg(pipe_i, j):                        # segment j on the instance that owns its inputs (j % inflight); --raft: the flows
+            fr, nz, fl, mk = ins[j % inflight]     # are estimated inside the segment, as in step()
+            if args.raft and args.guidance:
+                fl, mk = pipe_i.estimate_flows(fr)
+            return pipe_i.run_segment(fr, flows=fl, masks=mk, noise=nz, tile=TILE, use_graph=GRAPH)
         for i in range(inflight):                 # warm-up one instance at a time, on ITS inputs
-            pool.run_on(i, [jobs[i]] * args.warmup)
+            pool.map_on(i, seg, [i] * args.warmup)
         parallel.barrier()
         t0 = time.perf_counter()
-        outs = pool.run(jobs)
+        outs = pool.map(seg, list(range(args.steps)))
         parallel.barrier()
         dt_local = time.perf_counter() - t0
         dt = parallel.max_over_ranks(dt_local)
@@ -415,7 +419,7 @@ def main():
         for j in range(args.steps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            pipe.run_segment(frames, **kw)
+            step()
             b.record()
             e_lat.append((a, b))
         parallel.barrier()

@@ -401,6 +401,11 @@ class SegmentPool:
         res = self._drive([[(j, self._seg(job)) for j, job in enumerate(jobs)] if w == i else [] for w in range(len(self.pipes))])
         return [res[j] for j in range(len(jobs))]
 
+    def map_on(self, i, fn, items):
+        """results[j] = fn(pipeline instance i, items[j]) on instance i only, in order"""
+        res = self._drive([[(j, (lambda pipe, it=it: fn(pipe, it))) for j, it in enumerate(items)] if w == i else [] for w in range(len(self.pipes))])
+        return [res[j] for j in range(len(items))]
+
     def map(self, fn, items):
         """results[j] = fn(pipeline instance, items[j]); item j on instance j % k, every instance on its own thread + stream"""
         k = len(self.pipes)
