@@ -623,11 +623,6 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk) {
   // fragment traffic per MFMA — is 5-7 % SLOWER than variant 4 on the UNet's 64x64 shapes and 2-4 % faster on three VAE shapes: not picked;
   // p->tune = 8 / MGLD_CONV3Q_FORCE=7 select it)
   else v = (p->Wout >= 32 && t832 >= 448) ? 4 : 5;
-  {
-    static int w64 = -1;    // env MGLD_CONV3Q_W64=1 (A/B under segments in flight): four waves of 64x64 wherever eight of 64x32 are picked
-    if (w64 < 0) { const char* e = getenv("MGLD_CONV3Q_W64"); w64 = e ? atoi(e) : 0; }
-    if (w64 && v == 4) v = 7;
-  }
   if (force >= 0 && force < Q3_NVAR && !(p->up2 && force > 1 && force != 7) && p->Wout >= 16 && force != 6) v = force;
   if (p->tune > 0 && p->tune <= Q3_NVAR && !(p->up2 && p->tune > 2 && p->tune != 8) && p->Wout >= 16 && p->tune != 7) v = p->tune - 1;
   int ty, tx, bn, lds;
