@@ -612,3 +612,20 @@ def test_fullwidth_checkpoint_every_reference_key_loads(tmp_path):
     assert pipe.vq_model.last_load == ([], [])
     assert set(pipe.vq_model.state_dict().keys()) == set(vsd.keys())
     assert float(pipe.vq_model.decoder.conv_out.weight.mean()) == 0.25
+
+
+def test_pmc_traffic_table_matches_kernel_sources():
+    """bench.py reports `roofline.traffic` only from a PMC table taken on the CURRENT GEMM-family / attention sources (sha256 key).  A stale
+    table is not an error (the field is then null) — but it should be noticed here, not in the driver's bench line."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "r03_pmc_traffic.json")
+    if not os.path.exists(path):
+        pytest.skip("no PMC table")
+    src = b"".join(open(os.path.join(root, "mgld_vsr_amd", "csrc", f), "rb").read()
+                   for f in ("igemm_common.h", "igemm.hip", "conv3q.hip", "attention.hip"))
+    with open(path) as fh:
+        key = json.load(fh)["gemm_src_sha16"]
+    if key != hashlib.sha256(src).hexdigest()[:16]:
+        pytest.skip("profiles/r03_pmc_traffic.json was taken on other kernel sources: re-run tools/pmc_traffic.sh on the GPU")
