@@ -352,6 +352,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local)
     pipe = build_pipeline(args)
+    # the other instances of the segments-in-flight pool share this one's host weights (taken before its first launch)
+    spare = [pipe.clone_shared() for _ in range(2)] if (args.inflight == 0 or args.inflight > 1) and not (args.frame_shard or args.tile_shard) else []
     from mgld_vsr_amd import parallel
     shard = None
     if args.frame_shard and world > 1:
@@ -390,7 +392,8 @@ def main():
         # engine, arena, hipGraph), a stream and a split-K scratch (the library keeps that per host thread); weights are the same
         # synthetic ones in every instance, every segment's result is what the one-at-a-time loop produces
         from mgld_vsr_amd.pipeline import SegmentPool
-        pool = SegmentPool(lambda: build_pipeline(args), inflight, first=pipe)
+        pool = SegmentPool(lambda: build_pipeline(args), inflight, first=pipe, others=spare)
+        del spare[:]
         ins = [(frames, noise, flows, masks)] + [make_inputs(pool.pipes[i], args, rank * inflight + i) for i in range(1, inflight)]
 
         def seg(pipe_i, j):                        # segment j on the instance that owns its inputs (j % inflight); --raft: the flows

@@ -164,7 +164,9 @@ def main(argv=None, w_latent=False):
     if opt.inflight > 1:
         from .pipeline import SegmentPool
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state()
-        pool = SegmentPool(make_pipe, opt.inflight, first=pipe)
+        # the extra instances share the first one's host weights when it has not launched anything yet (else: built from scratch)
+        shared = [pipe.clone_shared() for _ in range(opt.inflight - 1)] if pipe.model._engine is None else None
+        pool = SegmentPool(make_pipe, opt.inflight, first=pipe, others=shared)
         torch.set_rng_state(rng_cpu)          # building the extra instances draws from the global generators (module initialisers):
         torch.cuda.set_rng_state(rng_dev)     # put them back, so that the segments' noise does not depend on --inflight
     pending = []

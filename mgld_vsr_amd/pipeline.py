@@ -130,6 +130,23 @@ class VSRPipeline:
         m._graph_key = None
         return missing, unexpected
 
+    def clone_shared(self):
+        """Another instance for `SegmentPool` that SHARES this one's parameter and buffer tensors (host memory and build time of one model
+        for k segments in flight) but owns its module objects — engines, packed device weights, caches, hipGraphs and streams hang off
+        those and stay per instance.  Call it before the first launch of this instance (nothing device-side to copy then)."""
+        if self.model._engine is not None:
+            raise RuntimeError("clone_shared(): call before the first launch of the source pipeline (its modules already carry an engine)")
+        memo = {}
+        for mod in (self.model, self.vq_model):
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                memo[id(t)] = t                 # deepcopy hands these back instead of copying them
+        new = copy.copy(self)
+        new.model = copy.deepcopy(self.model, memo)
+        new.vq_model = copy.deepcopy(self.vq_model, memo)
+        for a in ("_shared_gen", "_shared_gen_seed"):
+            new.__dict__.pop(a, None)
+        return new
+
     def engine(self):
         from .engine import Engine
         if self.model._engine is None:
@@ -304,10 +321,13 @@ class SegmentPool:
     `make_pipeline()` must return a fresh VSRPipeline (same weights in every instance); jobs are (args, kwargs) of run_segment and
     should inject their noise (`noise=`) so that results do not depend on which worker drew from the global generator first."""
 
-    def __init__(self, make_pipeline, k, first=None):
+    def __init__(self, make_pipeline, k, first=None, others=None):
         import queue
         import threading
-        self.pipes = ([first] if first is not None else []) + [make_pipeline() for _ in range(k - (1 if first is not None else 0))]
+        # instances: `first` (optional, may already be warm), then `others` (prebuilt, e.g. first.clone_shared() taken before its first
+        # launch), then fresh ones from make_pipeline()
+        self.pipes = ([first] if first is not None else []) + list(others or [])[:max(0, k - (1 if first is not None else 0))]
+        self.pipes += [make_pipeline() for _ in range(k - len(self.pipes))]
         self.streams = [torch.cuda.Stream() for _ in self.pipes]
         self.device = torch.cuda.current_device()
         # PERSISTENT workers: one host thread per instance for the pool's lifetime.  The kernel library keeps the split-K scratch per

@@ -629,3 +629,29 @@ def test_pmc_traffic_table_matches_kernel_sources():
         key = json.load(fh)["gemm_src_sha16"]
     if key != hashlib.sha256(src).hexdigest()[:16]:
         pytest.skip("profiles/r03_pmc_traffic.json was taken on other kernel sources: re-run tools/pmc_traffic.sh on the GPU")
+
+
+def test_pipeline_clone_shares_weights_not_modules():
+    """VSRPipeline.clone_shared(): the instances SegmentPool keeps in flight share parameter / buffer storage (one model in host memory) but
+    own their module objects; refused once the source has an engine attached."""
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    cfgs = model_configs(T, unet_overrides=dict(model_channels=32, context_dim=32, semb_channels=32, num_head_channels=32),
+                         struct_overrides=dict(model_channels=32, out_channels=32, num_heads=1), vae_overrides=dict(ch=32), context_dim=32)
+    a = VSRPipeline(num_frames=T, ddpm_steps=4, configs=cfgs)
+    b = a.clone_shared()
+    pa, pb = dict(a.model.named_parameters()), dict(b.model.named_parameters())
+    assert pa.keys() == pb.keys() and len(pa) > 100
+    assert all(pa[k].data_ptr() == pb[k].data_ptr() for k in pa)
+    va, vb = dict(a.vq_model.named_parameters()), dict(b.vq_model.named_parameters())
+    assert all(va[k].data_ptr() == vb[k].data_ptr() for k in va)
+    ba, bb = dict(a.model.named_buffers()), dict(b.model.named_buffers())
+    assert all(ba[k].data_ptr() == bb[k].data_ptr() for k in ba)
+    mods_a = {id(m) for m in a.model.modules()} | {id(m) for m in a.vq_model.modules()}
+    assert not any(id(m) in mods_a for m in b.model.modules()) and not any(id(m) in mods_a for m in b.vq_model.modules())
+    assert b.model._engine is None and b.ddpm_steps == a.ddpm_steps and b.model.num_timesteps == a.model.num_timesteps
+    b.vq_model.decoder.fusion_w = 0.25                       # per-instance attribute
+    assert a.vq_model.decoder.fusion_w != 0.25
+    a.model._engine = object()
+    with pytest.raises(RuntimeError):
+        a.clone_shared()
+    a.model._engine = None

@@ -621,7 +621,8 @@ def test_two_segments_in_flight_match_sequential(hip):
     cfgs = model_configs(Tn, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
                          struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
                          vae_overrides=dict(ch=32, resolution=H), context_dim=64)
-    pipes = [VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=cfgs) for _ in range(2)]
+    pipes = [VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=cfgs)]
+    pipes.append(pipes[0].clone_shared())      # the second instance shares the first one's host weights (own modules, engine, graphs)
     ins = []
     for i in range(2):
         x = synth.synth_tensor(f"inflight/x{i}", (Tn, 3, H, H), 0.5).clamp(-1, 1)
