@@ -70,6 +70,10 @@ def parse(argv=None):
     p.add_argument("--ckpt", type=str, default=REF_CKPT, help="synthetic weights (with a warning) when the default file is absent")
     p.add_argument("--vqgan_ckpt", type=str, default=REF_VQGAN_CKPT)
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--inflight", type=int, default=1,
+                   help="large frames: pixel patches of a segment kept in flight on this GPU (pipeline.SegmentPool; 1 = the reference's "
+                        "loop).  The reference re-seeds before every patch, so each patch's noise is a function of the seed and its shape "
+                        "alone: drawn on the main thread, patch by patch, the output does not depend on this option.")
     p.add_argument("--precision", type=str, default="autocast", choices=["full", "autocast"])
     p.add_argument("--select_idx", type=int, default=0)
     p.add_argument("--n_gpus", type=int, default=1)
@@ -126,6 +130,10 @@ def main(argv=None):
         pipe.load_checkpoint(opt.ckpt)                # 1000-step buffers first, respacing after; text tower from the checkpoint
     if opt.vqgan_ckpt:
         pipe.vq_model.init_from_ckpt(opt.vqgan_ckpt)
+    pool = None
+    if opt.inflight > 1:                         # extra instances share the first one's host weights (taken before its first launch)
+        from mgld_vsr_amd.pipeline import SegmentPool
+        pool = SegmentPool(None, opt.inflight, first=pipe, others=[pipe.clone_shared() for _ in range(opt.inflight - 1)])
     os.makedirs(opt.outdir, exist_ok=True)
     from mgld_vsr_amd.preproc import FrameWriter
     writer = FrameWriter()                          # PNG / .npy encoding overlaps the next segment's sampling
@@ -184,8 +192,30 @@ def main(argv=None):
                 im_sp = ImageSpliterTh(seg, ps, st, sf=1)
                 # flows [1,T-1,2,h,w] / masks [1,T-1,1,h,w] -> 4-D [T-1,c,h,w] for the latent-resolution spliters
                 aux = [ImageSpliterTh(t[0], ps // 8, st // 8, sf=1) for t in (flows[0], flows[1], masks[0], masks[1])]
-                for (pch, idx), (ff_, _), (fb_, _), (fo_, _), (bo_, _) in zip(im_sp, *aux):
-                    im_sp.update(one(pch, (ff_[None], fb_[None]), (fo_[None], bo_[None]), reseed=True), idx)
+                if pool is None:
+                    for (pch, idx), (ff_, _), (fb_, _), (fo_, _), (bo_, _) in zip(im_sp, *aux):
+                        im_sp.update(one(pch, (ff_[None], fb_[None]), (fo_[None], bo_[None]), reseed=True), idx)
+                else:
+                    # patches in flight: every patch is re-seeded (:428), so its draws depend on (seed, shape) only — made HERE, in the
+                    # order run_segment makes them (VSRPipeline.draw_noise), and injected; the patches then run on the pool's instances
+                    jobs = []
+                    for (pch, idx), (ff_, _), (fb_, _), (fo_, _), (bo_, _) in zip(im_sp, *aux):
+                        torch.manual_seed(opt.seed)
+                        h8_, w8_ = pch.shape[-2] // 8, pch.shape[-1] // 8
+                        nz = NOISE_HOOK(pch.shape[0], h8_, w8_, opt.ddpm_steps) if NOISE_HOOK is not None else pipe.draw_noise(pch.shape[0], h8_, w8_)
+                        jobs.append((pch, (ff_[None], fb_[None]), (fo_[None], bo_[None]), nz, idx))
+
+                    def patch(pipe_i, job):
+                        pch, fl, mk, nz, _ = job
+                        h8_, w8_ = pch.shape[-2] // 8, pch.shape[-1] // 8
+                        tl = None if (h8_ <= 64 and w8_ <= 64) else (64, opt.tile_overlap)
+                        return pipe_i.run_segment(pch, flows=fl, masks=mk, guidance_scale=opt.guidance_scale, tile=tl, clamp01=False,
+                                                  return_latents=True, noise=nz)
+                    for (out_, lat_), job in zip(pool.map(patch, jobs), jobs):
+                        latents.append(lat_)
+                        if CAPTURE is not None:
+                            CAPTURE.append({"flows": job[1], "masks": job[2], "x0": lat_})
+                        im_sp.update(out_, job[4])
                 x_samples = im_sp.gather()
             else:
                 x_samples = one(seg, flows, masks)
@@ -208,6 +238,8 @@ def main(argv=None):
                     base = os.path.splitext(os.path.basename(paths[s0 + k]))[0]
                     writer.npy(os.path.join(opt.latent_dir, seq, base + ".npy"), lat[k])
     writer.close()
+    if pool is not None:
+        pool.close()
 
 if __name__ == "__main__":
     main()

@@ -254,3 +254,41 @@ def test_fixed_size_cli_output_does_not_depend_on_segments_in_flight(tmp_path):
         assert np.array_equal(outs[1][key], outs[2][key]), key
     a, b = outs[1][("seq0", "0000.png")].astype(np.int32), outs[1][("seq1", "0000.png")].astype(np.int32)
     assert np.abs(a - b).mean() > 1.0            # (the two sequences are different inputs)
+
+
+@pytest.mark.gpu
+def test_tile_cli_output_does_not_depend_on_patches_in_flight(tmp_path):
+    """`--inflight 2` of the tile script: the 2 x 2 pixel patches of a large-frame segment run on two pipeline instances (shared host
+    weights, own engines / streams).  The reference re-seeds before every patch, so a patch's noise is a function of (seed, shape) alone;
+    drawn on the main thread in run_segment's own order (VSRPipeline.draw_noise), the written frames are byte-identical to the
+    one-patch-at-a-time loop."""
+    import importlib.util
+    import yaml
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from configs import STRUCT_SMALL, T, UNET_SMALL, VAE_DD_SMALL
+    from mgld_vsr_amd.pipeline import model_configs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g_harness.npz"))
+    seq = tmp_path / "in" / "seq0"
+    seq.mkdir(parents=True)
+    for k in range(T):
+        Image.fromarray(g["lr_u8"][k]).save(seq / f"{k:04d}.png")
+    dcfg, vcfg = model_configs(T, unet_overrides={k: v for k, v in UNET_SMALL.items() if k != "num_frames"},
+                               struct_overrides={k: v for k, v in STRUCT_SMALL.items() if k != "num_frames"},
+                               vae_overrides=dict(ch=VAE_DD_SMALL["ch"], resolution=512), context_dim=UNET_SMALL["context_dim"])
+    for name, cfg in (("diffusion.yaml", dcfg), ("vae.yaml", vcfg)):
+        with open(tmp_path / name, "w") as fh:
+            yaml.safe_dump({"model": cfg}, fh)
+    spec = importlib.util.spec_from_file_location("mgld_cli_tile2", os.path.join(ROOT, "scripts", "vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    frames = {}
+    for k in (1, 2):
+        cli.NOISE_HOOK, cli.CAPTURE = None, []
+        cli.main(["--seqs-path", str(tmp_path / "in"), "--outdir", str(tmp_path / f"out{k}"), "--ddpm_steps", "2", "--n_frames", str(T),
+                  "--config", str(tmp_path / "diffusion.yaml"), "--vqgan_config", str(tmp_path / "vae.yaml"), "--seed", "42", "--dec_w", "0.5",
+                  "--colorfix_type", "adain", "--vqgantile_size", "512", "--vqgantile_stride", "32", "--upscale", "4", "--inflight", str(k)])
+        assert len(cli.CAPTURE) == 4
+        frames[k] = np.stack([np.asarray(Image.open(tmp_path / f"out{k}" / "seq0" / f"{i:04d}.png").convert("RGB")) for i in range(T)])
+    assert frames[1].shape == tuple(g["hr_shape"]) and frames[1].std() > 1.0
+    assert np.array_equal(frames[1], frames[2])
