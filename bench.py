@@ -56,6 +56,7 @@ def parse():
                          "that, else 1 (arena memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-one-at-a-time", action="store_true", help="skip the second scheduling leg (profiling runs of the segments in flight)")
     ap.add_argument("--small", action="store_true", help="reduced-width nets (plumbing check only; not a valid bench)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--spawn-selftest", action="store_true",
@@ -419,7 +420,7 @@ def main():
         parallel.barrier()
         t1 = time.perf_counter()
         e_lat = []
-        for j in range(args.steps):
+        for j in range(0 if args.no_one_at_a_time else args.steps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             step()
@@ -428,7 +429,7 @@ def main():
         parallel.barrier()
         dt1 = parallel.max_over_ranks(time.perf_counter() - t1)
         l1 = sorted(a.elapsed_time(b) for a, b in e_lat)
-        one_at_a_time = {"value": round((1 if shard is not None else world) * args.frames * args.steps / dt1, 4), "ms_per_step": round(1e3 * dt1 / args.steps, 2),
+        one_at_a_time = None if args.no_one_at_a_time else {"value": round((1 if shard is not None else world) * args.frames * args.steps / dt1, 4), "ms_per_step": round(1e3 * dt1 / args.steps, 2),
                          "segment_latency_ms": round(l1[len(l1) // 2], 1), "steps": args.steps}
     else:
         for _ in range(args.warmup):
