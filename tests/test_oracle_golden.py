@@ -377,7 +377,8 @@ def _regen_and_compare(tmp_path, what, names, timeout):
     (["workload:c2g:4"], ["g_work_c2g_S4.npz"], 3600),                          # configs[2] share
     (["workload:c4:4"], ["g_work_c4_S4.npz"], 7200),                            # configs[3]: 1024^2 aggregation sampling
     (["workload:c2:50"], ["g_work_c2_S50.npz"], 14400),                         # configs[1] at its 50 steps
-    (["workload:c2g:50"], ["g_work_c2g_S50.npz"], 14400)])                      # configs[2] share, flow-guided, at its 50 steps
+    (["workload:c2g:50"], ["g_work_c2g_S50.npz"], 14400),                       # configs[2] share, flow-guided, at its 50 steps
+    (["workload:c4:50"], ["g_work_c4_S50.npz"], 21600)])                        # configs[3]: 1024^2 aggregation sampling at its 50 steps
 def test_heavy_fixtures_regenerate_bit_for_bit(tmp_path, what, names, timeout):
     """The heavy fixtures (minutes to hours of CPU each) under the same pin as the light ones: re-run the generator against
     /root/reference in a fresh process and compare every array bit for bit.  `slow`: only with MGLD_SLOW=1."""

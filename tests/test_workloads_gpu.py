@@ -30,7 +30,7 @@ def _have(name):
     return os.path.exists(os.path.join(HERE, "golden", name + ".npz"))
 
 
-@pytest.mark.parametrize("case,S", [("c2", 4), ("c2g", 4), ("c4", 4), ("c2", 50), ("c2g", 50)])
+@pytest.mark.parametrize("case,S", [("c2", 4), ("c2g", 4), ("c4", 4), ("c2", 50), ("c2g", 50), ("c4", 50)])
 def test_workload_vs_reference(hip, case, S):
     name = f"g_work_{case}_S{S}"
     if not _have(name):
