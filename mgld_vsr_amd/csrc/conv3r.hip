@@ -1,0 +1,348 @@
+// conv3r.hip — the 3x3 / stride 1 / pad 1 convolutions (openaimodel.py:176,221,401-405,429-436; model.py:114-118) on the ping-pong
+// structure of pp_common.h.  Same staging idea as conv3q.hip — a (TY+2) x (TX+2) input PATCH of a 32-channel slice is DMA'd once and all
+// nine taps read their fragments from it; weights stream in the tiled layout of MgldIGemm.tap_inner = 2 — but:
+//   * one 512-thread block per CU, two wave groups alternating between the matrix pipe and the LDS / DMA side (no per-stage block-wide
+//     drain: conv3q sat at 0.39 of the MFMA peak with the matrix pipe 39.7 % busy and the waves parked 43.7 % on the stage barrier,
+//     profiles/r03_pmc_conv3q.txt);
+//   * a PHASE is one tap of one slice (K = 32): the weights of a phase are one ring slot of BN x 64 B, the ring is NSW slots deep and
+//     filled NSW - 1 phases ahead with counted waits; the patch of the next slice arrives during taps 0..2 of the current one;
+//   * v_mfma_f32_16x16x32_f16, so the N = 320 layers run 256 pixels x 160 channels per block (= 256 blocks at 8 x 64^2) with 64 x 80
+//     wave tiles: 4.7 staged bytes per KFLOP;
+//   * fragment reads are one ds_read_b128 per 16-row fragment; the four k groups of the 16x16x32 pattern read the 16-byte chunks of a row
+//     in the order {0, 3, 1, 2} and the patch image is swizzled by (row >> 2) & 1: conflict-free for every tap shift (see the kernel);
+// Out-of-image patch pixels: the DMA lane's offset is pushed past the descriptor's range and the hardware writes zeros.
+// Covered: tap_inner = 2 weights, Cin % 32 == 0, N % BN == 0, no upsample fold, no K split, no weight-residual pass, fp16 out,
+// act in {none, SiLU}; everything else stays on conv3q.hip.
+#include "pp_common.h"
+
+#ifndef MGLD_PP_ABLATE
+#define MGLD_PP_ABLATE 0   // timing-only ablation builds (1-8: wrong results): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMA, 8 no barriers, 16 no setprio, 32 lgkmcnt(0) after the barrier, 64 tap offsets recomputed per phase
+#endif
+
+namespace {
+using namespace mgld_ig;
+constexpr int PPA = MGLD_PP_ABLATE;
+
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW>
+__global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const int tiles_x, const int tiles_y, const int order) {
+  constexpr int BM = TY * TX, WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+  // patch rows are laid out with a row stride of PW pixels, PW a multiple of 8 (TX + 2 rounded up; the pad columns are DMA'd as zeros):
+  // the chunk swizzle bit (row >> 2) & 1 of a fragment row is then the same for every tile row, i.e. the nine taps of every fragment are
+  // THREE per-lane offsets (dx) plus immediates — no address arithmetic in the loop
+  constexpr int PW = (TX + 2 + 7) & ~7, PH = TY + 2, PR = PW * PH;
+  constexpr int NPA = (PR + 15) / 16, NPT = (NPA + 7) / 8;      // 1-KiB patch pieces; pieces per wave (taps 0 .. NPT-1 of the previous slice)
+  constexpr int A_BYTES = NPT * 8 * 1024;
+  constexpr int WSLOT = BN * 64, NPW = BN / 16;                 // one tap of one slice: BN rows x 64 B = NPW pieces
+  constexpr int CWLO = NPW / 8, CWHI = (NPW + 7) / 8;
+  constexpr int D = NSW - 1;                                    // weights are issued D phases ahead
+  constexpr int W_BASE = 2 * A_BYTES;
+  static_assert(WGM * WGN == 8 && TX % 16 == 0 && WM % 16 == 0 && WN % 16 == 0 && BN % 16 == 0, "tile shape");
+  static_assert(WM % TX == 0, "a wave tile is whole tile rows");
+  static_assert(NPT <= 10 - D && D >= 2 && D <= 7 && W_BASE + NSW * WSLOT <= 160 * 1024, "ring");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const bool hi = wave < (NPW & 7);
+
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if ((gridDim.x & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    if ((order & 0xff) == 1) {
+      const int q = xcd * ((int)(gridDim.x * gridDim.y) >> 3) + j;
+      tile_n = q / (int)gridDim.x;
+      tile_m = q - tile_n * (int)gridDim.x;
+    } else {
+      tile_m = xcd + 8 * (j / (int)gridDim.y);
+      tile_n = j % (int)gridDim.y;
+    }
+  }
+  const int tpf = tiles_x * tiles_y;
+  const int frame = tile_m / tpf;
+  const int trem = tile_m - frame * tpf;
+  const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+  const int y0 = tyi * TY, x0 = txi * TX;
+  const int bn0 = tile_n * BN;
+  const int Hin = p.Hin, Win = p.Win, nh = p.Cin >> 5;
+
+  // ---- DMA sources
+  const int64_t fpix = (int64_t)frame * Hin * Win;
+  const uint32_t fbytes = (uint32_t)min((int64_t)0x7fffffff, (int64_t)Hin * Win * p.lda * 2);
+  const auto rsA = pp_make_rsrc((const f16*)p.A + fpix * p.lda, fbytes);
+  const auto rsW = pp_make_rsrc(p.W, 0xffffffffu);
+  uint32_t voffA[NPT];
+#pragma unroll
+  for (int s = 0; s < NPT; ++s) {
+    const int j = (s * 8 + wave) * 16 + (lane >> 2);
+    const int pr = j / PW, pc = j - pr * PW;
+    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+    const bool ok = (j < PR) && (pc < TX + 2) && ((unsigned)y < (unsigned)Hin) && ((unsigned)x < (unsigned)Win);
+    const int cl = (lane & 3) ^ ((j >> 2) & 1);       // patch image: chunk c of row j sits at c ^ ((j >> 2) & 1)
+    voffA[s] = ok ? (uint32_t)(((y * Win + x) * p.lda + cl * 8) * 2) : 0x80000000u;   // past num_records: the DMA writes zeros
+  }
+  const uint32_t voffW = lane * 16;
+  uint32_t wbase[CWHI];        // byte offset of this wave's weight pieces at (slice 0, tap 0)
+#pragma unroll
+  for (int k = 0; k < CWHI; ++k) {
+    const int gr = (bn0 >> 4) + k * 8 + wave;
+    wbase[k] = (uint32_t)((((gr >> 2) * nh * 3) * 4 + (gr & 3)) * 3) * 1024u;
+  }
+  auto issue_patch = [&](const int s, const int par, const int hh) __attribute__((always_inline)) {
+    pp_dma16(rsA, smem + par * A_BYTES + (s * 8 + wave) * 1024, voffA[s], (uint32_t)hh * 64u);
+  };
+  auto issue_w = [&](const int slot, const int hh, const int tap) __attribute__((always_inline)) {
+    const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+    const uint32_t so = (uint32_t)hh * (36u * 1024u) + (uint32_t)dy * (12u * 1024u) + (uint32_t)dx * 1024u;
+    char* dst = smem + W_BASE + slot * WSLOT + wave * 1024;
+#pragma unroll
+    for (int k = 0; k < CWHI; ++k) {
+      if (k >= CWLO && !hi) continue;
+      pp_dma16(rsW, dst + k * 8192, voffW, wbase[k] + so);
+    }
+  };
+
+  // ---- fragment read offsets
+  // k group g of a fragment reads the 16-byte chunk PG(g) = {0, 3, 1, 2}[g] of its 64-byte row (both operands alike, so the products pair
+  // up).  Found by enumeration over the ds_read_b128 lane groups of MI355X_MICROARCH.md: with this order the weight image (chunk swizzle
+  // (row >> 2) & 3, 16-aligned fragments) is conflict-free, and a patch image swizzled by (row >> 2) & 1 is conflict-free for EVERY
+  // alignment of the 16 consecutive patch rows a tap shifts a fragment to.
+  const int pg = (0x9c >> (2 * g)) & 3;
+  const int w_rd = W_BASE + (wn * WN + l15) * 64 + (((pg ^ (l15 >> 2)) & 3) << 4);
+  // patch row of this lane's pixel in fragment 0 at tap (0, 0); fragment mi / tap (dy, dx) add compile-time rows (multiples of 8, or 16)
+  const int R0 = wm * WM;
+  const int jb0 = (R0 / TX) * PW + (R0 & (TX - 1)) + l15;
+  int a_off[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int jj = jb0 + dx;
+    a_off[dx] = jj * 64 + ((((jj >> 2) & 1) ^ pg) << 4);
+  }
+  auto frag_rows = [](const int mi) { return ((mi * 16) / TX) * PW + ((mi * 16) & (TX - 1)); };   // rows of fragment mi below fragment 0
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: patch of slice 0, weights of phases 0 .. D-1; phase 0's operands landed and visible
+  const int F = 9 * nh;
+#pragma unroll
+  for (int s = 0; s < NPT; ++s) issue_patch(s, 0, 0);
+#pragma unroll
+  for (int f = 0; f < D; ++f)
+    if (f < F) issue_w(f, f / 9, f % 9);
+  if (hi) pp_wait_vm<(D - 1) * CWHI>(); else pp_wait_vm<(D - 1) * CWLO>();
+  pp_barrier();
+  if (grp == 1) pp_barrier();                      // group 1 runs one barrier behind group 0 from here on
+
+  f16x8 fa[MI], fw[NI];
+  if constexpr (PPA & 2) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const f16x8*)(smem + lane * 16 + mi * 1024);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const f16x8*)(smem + W_BASE + lane * 16 + ni * 1024);
+  }
+  int slot = 0;                                    // ring slot of the current phase
+  // one slice: nine phases.  MORE: there is a next slice (its patch is issued during taps 0 .. NPT-1, weights run ahead into it)
+  auto phase = [&](const int v, auto MORE_, auto T_) __attribute__((always_inline)) {
+    constexpr bool MORE = decltype(MORE_)::value;
+    constexpr int t = decltype(T_)::value;
+    constexpr int dy = t / 3, dx = t - dy * 3;
+    const int pa = v & 1;
+    const int abase = pa * A_BYTES;
+    // ---- L: fragments of this phase
+    const char* ws = smem + slot * WSLOT;
+    if constexpr (!(PPA & 2)) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      fw[ni] = *(const f16x8*)(ws + w_rd + ni * 1024);
+    }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      if constexpr (PPA & 2) continue;
+      fa[mi] = *(const f16x8*)(smem + abase + a_off[dx] + (dy * PW + frag_rows(mi)) * 64);
+    }
+    // ---- DMA: next slice's patch (taps 0 .. NPT-1), weights of phase f + D into the slot phase f - 1 read
+    if constexpr (MORE && t < NPT && !(PPA & 1)) issue_patch(t, pa ^ 1, v + 1);
+    if constexpr ((MORE || t + D < 9) && !(PPA & 1)) {
+      const int ns = (slot == 0) ? NSW - 1 : slot - 1;
+      if constexpr (t + D < 9) issue_w(ns, v, t + D); else issue_w(ns, v + 1, t + D - 9);
+    }
+    // ---- phase f + 1's operands must have landed: everything but the issues of the last D - 1 phases may stay in flight
+    {
+      constexpr int np = [] {      // patch pieces among them
+        int n = 0;
+        for (int i = 0; i < D - 1; ++i) { const int tau = t - i; if (tau >= 0 && MORE && tau < NPT) ++n; }
+        return n;
+      }();
+      constexpr int nw = [] {      // phases among them that issued weights
+        int n = 0;
+        for (int i = 0; i < D - 1; ++i) { const int tau = t - i; if (tau < 0 || MORE || tau + D < 9) ++n; }
+        return n;
+      }();
+      if (hi) pp_wait_vm<np + nw * CWHI>(); else pp_wait_vm<np + nw * CWLO>();
+    }
+    if constexpr (!(PPA & 32)) pp_wait_lgkm0();
+    if constexpr (!(PPA & 8)) pp_barrier(); else __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PPA & 32) { pp_wait_lgkm0(); __builtin_amdgcn_sched_barrier(0); }
+    // ---- M
+    if constexpr (!(PPA & 16)) __builtin_amdgcn_s_setprio(1);
+    if constexpr (PPA & 4) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[mi]));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fw[ni]));
+    } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if constexpr (!(PPA & 16)) __builtin_amdgcn_s_setprio(0);
+    if constexpr (!(PPA & 8)) pp_barrier(); else __builtin_amdgcn_sched_barrier(0);
+    slot = (slot + 1 == NSW) ? 0 : slot + 1;
+  };
+  // one slice: nine phases.  MORE: there is a next slice (its patch is issued during taps 0 .. NPT-1, weights run ahead into it)
+  auto slice = [&](const int v, auto MORE_) __attribute__((always_inline)) {
+    phase(v, MORE_, std::integral_constant<int, 0>{}); phase(v, MORE_, std::integral_constant<int, 1>{}); phase(v, MORE_, std::integral_constant<int, 2>{});
+    phase(v, MORE_, std::integral_constant<int, 3>{}); phase(v, MORE_, std::integral_constant<int, 4>{}); phase(v, MORE_, std::integral_constant<int, 5>{});
+    phase(v, MORE_, std::integral_constant<int, 6>{}); phase(v, MORE_, std::integral_constant<int, 7>{}); phase(v, MORE_, std::integral_constant<int, 8>{});
+  };
+  for (int v = 0; v + 1 < nh; ++v) slice(v, std::true_type{});
+  slice(nh - 1, std::false_type{});
+  if (grp == 0) pp_barrier();
+
+  if constexpr (PPA & 128) {                       // (ablation: no epilogue)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
+    return;
+  }
+  PPEpi e;
+  e.bias = p.bias; e.rowvec = p.rowvec; e.R = (const f16*)p.R; e.C = (f16*)p.C;
+  e.rows_per_frame = p.rows_per_frame; e.ld_rowvec = p.ld_rowvec; e.ldr = p.ldr; e.ldc = p.ldc; e.act = p.act; e.alpha = p.alpha; e.beta = p.beta;
+  e.noswap = (order & 0x100) != 0;
+  const int Hout = p.Hout, Wout = p.Wout;
+  const int fbase = frame * Hout * Wout;
+  pp_epilogue<MI, NI, false>(e, acc, lane, bn0 + wn * WN, [&](const int mi) {
+    const int R = wm * WM + mi * 16 + l15;
+    const int y = y0 + R / TX, x = x0 + (R & (TX - 1));
+    return (y < Hout && x < Wout) ? fbase + y * Wout + x : -1;
+  });
+}
+
+// ---- launch plan ----------------------------------------------------------------------------------------------------------
+//   id : pixel tile, weight rows, wave grid, wave tile, weight ring
+//    0 : 8 x 32, 160, 4 x 2,  64 x 80, 6 slots of 10 KiB       N = 320 k at 64^2 and larger
+//    1 : 8 x 16, 320, 2 x 4,  64 x 80, 4 slots of 20 KiB       N = 320 k, 128-pixel tiles
+//    2 : 8 x 32, 128, 4 x 2,  64 x 64, 6 slots of  8 KiB       N = 128 k (VAE 512^2, SPADE)
+//    3 : 8 x 32, 256, 2 x 4, 128 x 64, 5 slots of 16 KiB       N = 256 k (VAE 128^2, 256^2)
+//    4 : 16 x 16, 160, 4 x 2, 64 x 80, 6 slots                 square tiles (A/B)
+//    5 : 8 x 16, 160, 4 x 2,  32 x 80, 6 slots of 10 KiB       N = 320 k at 32^2 (one block per CU at 8 frames x 640 channels)
+//    6 : 16 x 32, 80, 8 x 1,  64 x 80, 5 slots of  5 KiB       512-pixel tiles: half the weight bytes per FLOP of configuration 0
+//    7 : 8 x 32, 80, 8 x 1,   32 x 80, 6 slots of  5 KiB       256-pixel tiles x 80 channels (32^2 level: one block per CU)
+//    8 : 16 x 32, 128, 8 x 1, 64 x 128, 5 slots of 8 KiB       512-pixel tiles for N = 128 k
+struct R3Cfg { int ty, tx, bn; };
+constexpr int R3_NCFG = 9;
+const R3Cfg R3_CFG[R3_NCFG] = {{8, 32, 160}, {8, 16, 320}, {8, 32, 128}, {8, 32, 256}, {16, 16, 160}, {8, 16, 160}, {16, 32, 80}, {8, 32, 80}, {16, 32, 128}};
+
+template <int TY, int TX, int BN, int NSW>
+constexpr int conv3r_lds() {
+  constexpr int PW = (TX + 2 + 7) & ~7, NPA = (PW * (TY + 2) + 15) / 16, NPT = (NPA + 7) / 8;
+  return 2 * NPT * 8 * 1024 + NSW * BN * 64;
+}
+
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW>
+int launch_conv3r(const MgldIGemm* p, hipStream_t s) {
+  constexpr int lds = conv3r_lds<TY, TX, BN, NSW>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv3r_kernel<TY, TX, BN, WGM, WGN, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  const int frames = p->M / (p->Hout * p->Wout);
+  const int tiles_x = cdiv(p->Wout, TX), tiles_y = cdiv(p->Hout, TY);
+  dim3 grid(frames * tiles_x * tiles_y, p->N / BN, 1);
+  static int forder = -2, noswap = -1;
+  if (forder == -2) { const char* e = getenv("MGLD_CONV3R_ORDER"); forder = e ? atoi(e) : -1; }
+  if (noswap < 0) { const char* e = getenv("MGLD_PP_NOSWAP"); noswap = e ? atoi(e) : 0; }
+  const double wbytes = 2.0 * p->N * p->K, abytes = 2.0 * p->M * p->Cin;
+  const int order = (forder >= 0 ? forder : (wbytes > 2.0 * abytes ? 1 : 0)) | (noswap ? 0x100 : 0);
+  hipLaunchKernelGGL((conv3r_kernel<TY, TX, BN, WGM, WGN, NSW>), grid, dim3(512), lds, s, *p, tiles_x, tiles_y, order);
+  return mgld_check_launch("igemm(conv3r)");
+}
+
+}  // namespace
+
+namespace mgld_ig {
+// does the ping-pong patch convolution take this problem?  p->tune: 30 = yes wherever it is covered, 31 + id = that configuration,
+// 0 = the planner decides; other values: no.  env MGLD_CONV3R = 0 switches the family off.
+bool conv3r_plan(const MgldIGemm* p, int* id) {
+  static int knob = -1;
+  if (knob < 0) { const char* e = getenv("MGLD_CONV3R"); knob = e ? atoi(e) : 1; }
+  if (!knob || p->mode != MGLD_MODE_CONV3X3 || p->tap_inner != 2) return false;
+  if (p->tune != 0 && (p->tune < 30 || p->tune > 30 + R3_NCFG)) return false;
+  if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
+  if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->W2 || p->out_f32 || p->bias_m || (p->Cin & 31)) return false;
+  if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU)) return false;
+  if (p->Hout != p->Hin || p->Wout != p->Win || p->Wout < 16 || p->Hout < 8 || (p->M % (p->Hout * p->Wout))) return false;
+  if ((p->lda & 7) || (p->ldc & 7) || (((uintptr_t)p->C) & 15) || (p->R && ((p->ldr & 7) || (((uintptr_t)p->R) & 15)))) return false;
+  if ((p->bias && (((uintptr_t)p->bias) & 15)) || (p->rowvec && ((((uintptr_t)p->rowvec) & 15) || (p->ld_rowvec & 3)))) return false;
+  if ((int64_t)p->Hin * p->Win * p->lda * 2 >= 0x7fffffffLL) return false;      // a frame must fit the descriptor's 31-bit range
+  auto fits = [&](int i) { return p->N % R3_CFG[i].bn == 0; };
+  if (p->tune > 30) {
+    if (!fits(p->tune - 31)) return false;
+    *id = p->tune - 31;
+    return true;
+  }
+  const int frames = p->M / (p->Hout * p->Wout), cus = num_cus();
+  auto tiles_of = [&](int i) { return (int64_t)frames * cdiv(p->Hout, R3_CFG[i].ty) * cdiv(p->Wout, R3_CFG[i].tx) * (p->N / R3_CFG[i].bn); };
+  // planner: filled in from measurements (tools/igemm_bench.py conv / vae); candidates by divisibility, at least ~one block per CU
+  int bid = -1;
+  const int pref[R3_NCFG] = {3, 0, 2, 1, 5, 4, 6, 7, 8};
+  for (int k = 0; k < R3_NCFG && bid < 0; ++k) {
+    const int i = pref[k];
+    if (i == 4 || i >= 6 || !fits(i)) continue;
+    const int64_t t = tiles_of(i);
+    if (4 * t >= 3 * cus) bid = i;
+  }
+  if (bid < 0 && p->tune == 30) {
+    for (int k = 0; k < R3_NCFG && bid < 0; ++k) if (fits(pref[k])) bid = pref[k];
+  }
+  if (bid < 0) return false;
+  if (p->tune == 0) {
+    static int on = -1;   // until measured against conv3q on every shape the planner takes the family only with MGLD_CONV3R_AUTO = 1
+    if (on < 0) { const char* e = getenv("MGLD_CONV3R_AUTO"); on = e ? atoi(e) : 0; }
+    if (!on) return false;
+  }
+  *id = bid;
+  return true;
+}
+
+int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id) {
+  switch (id) {
+    case 0: return launch_conv3r<8, 32, 160, 4, 2, 6>(p, s);
+    case 1: return launch_conv3r<8, 16, 320, 2, 4, 4>(p, s);
+    case 2: return launch_conv3r<8, 32, 128, 4, 2, 6>(p, s);
+    case 3: return launch_conv3r<8, 32, 256, 2, 4, 5>(p, s);
+    case 4: return launch_conv3r<16, 16, 160, 4, 2, 6>(p, s);
+    case 5: return launch_conv3r<8, 16, 160, 4, 2, 6>(p, s);
+    case 6: return launch_conv3r<16, 32, 80, 8, 1, 5>(p, s);
+    case 7: return launch_conv3r<8, 32, 80, 8, 1, 6>(p, s);
+    default: return launch_conv3r<16, 32, 128, 8, 1, 5>(p, s);
+  }
+}
+
+void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen) {
+  static const int g[R3_NCFG][6] = {{8, 32, 160, 4, 2, 6}, {8, 16, 320, 2, 4, 4}, {8, 32, 128, 4, 2, 6}, {8, 32, 256, 2, 4, 5}, {16, 16, 160, 4, 2, 6},
+                                    {8, 16, 160, 4, 2, 6}, {16, 32, 80, 8, 1, 5}, {8, 32, 80, 8, 1, 6}, {16, 32, 128, 8, 1, 5}};
+  (void)p;
+  snprintf(buf, buflen, "conv3r_kernel<%d, %d, %d, %d, %d, %d>", g[id][0], g[id][1], g[id][2], g[id][3], g[id][4], g[id][5]);
+}
+}  // namespace mgld_ig

@@ -725,6 +725,8 @@ extern "C" int mgld_set_workspace(void* ptr, int64_t bytes) {
 extern "C" int mgld_igemm_config(const MgldIGemm* p) {
   if (!p) return 0;
   int cfg, splits, kchunk;
+  if (ppgemm_plan(p, &cfg)) return 500000 + cfg;                                                            // ping-pong LINEAR
+  if (conv3r_plan(p, &cfg)) return 600000 + cfg;                                                            // ping-pong patch conv
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return 400000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // 2-D-tile patch conv
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) return 300000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // raster patch conv
   choose(p, &cfg, &splits, &kchunk);
@@ -735,6 +737,14 @@ extern "C" int mgld_igemm_config(const MgldIGemm* p) {
 extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen) {
   MGLD_REQUIRE(p && buf && buflen > 0, "igemm_kernel_name: null");
   int cfg, splits, kchunk;
+  if (ppgemm_plan(p, &cfg)) {
+    ppgemm_kernel_name(p, cfg, buf, buflen);
+    return 1;
+  }
+  if (conv3r_plan(p, &cfg)) {
+    conv3r_kernel_name(p, cfg, buf, buflen);
+    return 1;
+  }
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
     conv3q_kernel_name(p, cfg, buf, buflen);
     return splits;
@@ -796,6 +806,8 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;
+  if (ppgemm_plan(p, &cfg)) return dispatch_ppgemm(p, s, cfg);
+  if (conv3r_plan(p, &cfg)) return dispatch_conv3r(p, s, cfg);
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return dispatch_conv3q(p, s, cfg, splits, kchunk);
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) {
     MGLD_REQUIRE(!p->W2, "igemm: the raster patch kernel (MGLD_CONV3Q=0) does not take W2");

@@ -19,6 +19,14 @@ bool conv3q_plan(const MgldIGemm* p, int* id, int* splits, int* hchunk);
 int dispatch_conv3p(const MgldIGemm* p, hipStream_t s, int bn, int splits, int hchunk);
 int dispatch_conv3q(const MgldIGemm* p, hipStream_t s, int id, int splits, int hchunk);
 void conv3q_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
+// ppgemm.hip (ping-pong LINEAR kernels)
+bool ppgemm_plan(const MgldIGemm* p, int* id);
+int dispatch_ppgemm(const MgldIGemm* p, hipStream_t s, int id);
+void ppgemm_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
+// conv3r.hip (ping-pong patch convolutions)
+bool conv3r_plan(const MgldIGemm* p, int* id);
+int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id);
+void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
 }  // namespace mgld_ig
 
 namespace {

@@ -1,0 +1,147 @@
+// pp_common.h — device helpers of the ping-pong GEMM family (ppgemm.hip: LINEAR, conv3r.hip: patch-staged 3x3 convolutions).
+//
+// Structure shared by both kernels (gfx950, one 512-thread workgroup per CU):
+//   * eight waves in two GROUPS of four (group = wave >> 2: one wave of each group per SIMD).  A K slice of 32 is one PHASE; every phase is
+//     [L: ds_read_b128 the phase's fragments + issue LDS-DMA pieces of a later stage] s_barrier [M: the phase's MFMAs] s_barrier.  Group 1
+//     runs ONE barrier behind group 0, so on every SIMD one wave is in its matrix section while the other reads LDS and issues DMA: the
+//     matrix pipe alternates between the two waves instead of both waiting at the same stage barrier (the 128-class structure of
+//     igemm.hip / conv3q.hip: matrix pipe 40 % busy, waves parked 44 % on the per-stage barrier, profiles/r03_pmc_conv3q.txt).
+//   * operands reach LDS by `buffer_load_dwordx4 ... offen lds` (LDS-DMA through a buffer descriptor: one 32-bit VGPR offset per lane,
+//     everything else scalar) into a ring of stages; waits are COUNTED (`s_waitcnt vmcnt(n)`, n = the pieces of the newer stages this
+//     wave has issued) and sit one phase before the first read of the stage; barriers are raw `s_barrier` (no vmcnt drain).
+//   * v_mfma_f32_16x16x32_f16: wave tiles are any multiple of 16 (the N = 320 layers take 80-column wave tiles), one ds_read_b128 per
+//     16-row fragment and phase.  The WEIGHT fragment is the first operand: a lane ends up with 4 consecutive output channels of one
+//     output row per fragment, adjacent fragments are paired by v_permlane16_swap into 8 consecutive channels = one 16-byte store.
+//   * the epilogue runs from registers (no LDS patch, no barrier): bias / per-frame row vector / SiLU or GEGLU / alpha, beta * residual.
+#pragma once
+#include "igemm_common.h"
+
+namespace {
+
+// (hipcc parses kernel bodies in its HOST pass too; the buffer-resource builtins do not exist there, and a kernel template whose body
+// fails that way silently loses its launch stub.  The host pass therefore sees empty stand-ins — device code is unaffected.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t pp_rsrc_t;
+__device__ __forceinline__ pp_rsrc_t pp_make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+// one 1-KiB LDS-DMA piece: lane l's 16 bytes at base + voff + soff land at lds + 16 l
+__device__ __forceinline__ void pp_dma16(const pp_rsrc_t rsrc, char* lds_wave_base, const uint32_t voff, const uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, __builtin_amdgcn_readfirstlane(soff), 0, 0);
+}
+#else
+typedef const void* pp_rsrc_t;
+__device__ __forceinline__ pp_rsrc_t pp_make_rsrc(const void* base, uint32_t) { return base; }
+__device__ __forceinline__ void pp_dma16(const pp_rsrc_t, char*, const uint32_t, const uint32_t) {}
+#endif
+
+template <int N>
+__device__ __forceinline__ void pp_wait_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- epilogue from registers --------------------------------------------------------------------------------------------
+// acc[ni][mi]: fragment (weight rows n0 + 16 ni .., output rows m0 + 16 mi ..): lane l holds output row (l & 15), channels 4 (l >> 4) + r.
+// EPI: 0 = bias / rowvec / none or SiLU / alpha / residual; 1 = GEGLU (the wave's 64 weight rows are [32 value | 32 gate] of 32 outputs).
+struct PPEpi {
+  const float* bias; const float* rowvec; const f16* R; f16* C;
+  int rows_per_frame, ld_rowvec, ldr, ldc, act; float alpha, beta;
+  bool noswap;     // A/B and bring-up: every fragment by 8-byte stores (no v_permlane16_swap pairing)
+};
+
+template <int MI, int NI, bool GEGLU, typename RowFn>
+__device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const RowFn row_of) {
+  // n0: first output channel (packed weight row for GEGLU) of this wave; row_of(mi) = global output row of this lane in fragment mi, or -1
+  const int q = lane >> 4;
+  constexpr int NO = GEGLU ? NI / 2 : NI;            // output fragments
+  static_assert(!GEGLU || NI == 4, "GEGLU: 64 weight rows per wave");
+  const float alpha = e.alpha;
+  // per-lane column constants (bias, plus the per-frame row vector of the frame the rows lie in), loaded ONCE per frame: inside the row
+  // loop every fragment row paid an L2 round trip for them.  Rows of a tile are almost always one frame.
+  f32x4 cv[NI];
+  int fr_loaded = -2;
+  auto load_cv = [&](const int fr) {
+#pragma unroll
+    for (int f = 0; f < NI; ++f) {
+      cv[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e.bias) cv[f] = *(const f32x4*)(e.bias + n0 + f * 16 + 4 * q);
+    }
+    if (fr >= 0) {
+      const float* rv = e.rowvec + (int64_t)fr * e.ld_rowvec + n0 + 4 * q;
+#pragma unroll
+      for (int f = 0; f < NI; ++f) cv[f] += *(const f32x4*)(rv + f * 16);
+    }
+    fr_loaded = fr;
+  };
+  const int nb = GEGLU ? n0 / 2 : n0;                // first output column of the wave
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = row_of(mi);
+    {
+      const int fr = (!GEGLU && e.rowvec && m >= 0) ? m / e.rows_per_frame : -1;
+      if (fr != fr_loaded && (m >= 0 || fr_loaded == -2)) load_cv(fr);
+    }
+    auto out_frag = [&](const int f) -> f32x4 {      // output fragment f of this row block, epilogue arithmetic applied (not the residual)
+      if constexpr (GEGLU) {
+        const f32x4 bv = cv[f], bg = cv[2 + f];
+        const e2 v0 = pk(acc[f][mi][0] + bv[0], acc[f][mi][1] + bv[1]), v1 = pk(acc[f][mi][2] + bv[2], acc[f][mi][3] + bv[3]);
+        const e2 g0 = gelu2(pk(acc[2 + f][mi][0] + bg[0], acc[2 + f][mi][1] + bg[1])), g1 = gelu2(pk(acc[2 + f][mi][2] + bg[2], acc[2 + f][mi][3] + bg[3]));
+        const e2 r0 = v0 * g0, r1 = v1 * g1;
+        return f32x4{r0[0] * alpha, r0[1] * alpha, r1[0] * alpha, r1[1] * alpha};
+      } else {
+        f32x4 v = acc[f][mi] + cv[f];
+        if (e.act == MGLD_ACT_SILU) {
+          const e2 s0 = silu2(pk(v[0], v[1])), s1 = silu2(pk(v[2], v[3]));
+          v = f32x4{s0[0], s0[1], s1[0], s1[1]};
+        }
+        return v * alpha;
+      }
+    };
+    auto store4 = [&](const int f) {                 // fragment f by 8-byte stores of 4 channels
+      f32x4 a = out_frag(f);
+      if (m < 0) return;
+      const int n = nb + f * 16 + 4 * q;
+      if (e.R) {
+        const f16x4 rr = *(const f16x4*)(e.R + (int64_t)m * e.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += e.beta * (float)rr[r];
+      }
+      *(f16x4*)(e.C + (int64_t)m * e.ldc + n) = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+    };
+    if (e.noswap) {
+#pragma unroll
+      for (int f = 0; f < NO; ++f) store4(f);
+      continue;
+    }
+    // pairs of fragments -> 16-byte stores: after the swap, lane (row q) holds fragment 2 pr + (q & 1), channels 8 (q >> 1) .. + 8
+#pragma unroll
+    for (int pr = 0; pr < NO / 2; ++pr) {
+      f32x4 a = out_frag(2 * pr), b = out_frag(2 * pr + 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+        a[r] = __uint_as_float(s[0]); b[r] = __uint_as_float(s[1]);
+      }
+      if (m < 0) continue;
+      const int n = nb + (2 * pr + (q & 1)) * 16 + (q >> 1) * 8;
+      if (e.R) {
+        const f16x8 rr = *(const f16x8*)(e.R + (int64_t)m * e.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] += e.beta * (float)rr[r]; b[r] += e.beta * (float)rr[4 + r]; }
+      }
+      *(f16x8*)(e.C + (int64_t)m * e.ldc + n) = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
+    }
+    if constexpr (NO & 1) store4(NO - 1);            // unpaired last fragment
+  }
+}
+
+}  // namespace

@@ -205,6 +205,89 @@ def test_igemm_geglu(hip, M, dim, inner):
     assert rel_l2(out.cpu().float(), ref) < 1e-3
 
 
+# ping-pong LINEAR kernels (csrc/ppgemm.hip): tune = 21 + configuration id forces a tile configuration, tune = 12 keeps the 128-class kernel
+PP_TILES = {0: (256, 256), 1: (256, 160), 2: (128, 160), 3: (128, 256), 4: (256, 128), 5: (128, 128), 6: (256, 320)}
+
+
+@pytest.mark.parametrize("cfg", sorted(PP_TILES))
+@pytest.mark.parametrize("mt,nt,K,epi", [(1, 1, 64, 0), (2, 3, 320, 1), (8, 2, 192, 2), (3, 1, 1280, 3), (16, 8, 128, 1)])
+def test_igemm_pingpong_linear(hip, cfg, mt, nt, K, epi):
+    """every tile configuration of the ping-pong LINEAR kernel: one stage (K = 64), K shorter / longer than the ring, all three tile orders
+    (8 | tiles_m, 8 | tiles_n, neither); epilogues: bias, bias + per-frame row vector + SiLU, residual with alpha / beta into strided
+    buffers, nothing at all.  Reference: fp32 products of the same fp16 operands."""
+    bm, bn = PP_TILES[cfg]
+    M, N = mt * bm, nt * bn
+    a, w = h16(rnd(M, K, seed=51)).to(DEV), h16(rnd(N, K, seed=52, scale=K ** -0.5)).to(DEV)
+    b = rnd(N, seed=53).to(DEV)
+    pre = a.cpu().float() @ w.cpu().float().t()
+    p = hip.MgldIGemm()
+    p.M, p.N, p.K, p.batch, p.tune, p.ldc = M, N, K, 1, 21 + cfg, N
+    assert hip.igemm_config(p) == 500000 + cfg
+    if epi == 0:
+        out = torch.empty(M, N, dtype=torch.half, device=DEV)
+        hip.igemm(a, w, out, bias=b, tune=21 + cfg)
+        ref = pre + b.cpu()
+    elif epi == 1:
+        rpf = M // 4 if M % 4 == 0 else M
+        rv = rnd(M // rpf, N, seed=54).to(DEV)
+        out = torch.empty(M, N, dtype=torch.half, device=DEV)
+        hip.igemm(a, w, out, bias=b, rowvec=rv, rows_per_frame=rpf, act=hip.ACT_SILU, tune=21 + cfg)
+        ref = F.silu(pre + b.cpu() + rv.cpu().repeat_interleave(rpf, 0))
+    elif epi == 2:
+        rbig = h16(rnd(M, N + 16, seed=55)).to(DEV)
+        r = rbig[:, 8:8 + N]
+        obig = torch.zeros(M, N + 40, dtype=torch.half, device=DEV)
+        out = obig[:, 16:16 + N]
+        hip.igemm(a, w, out, bias=b, resid=r, alpha=0.6, beta=1.4, tune=21 + cfg)
+        ref = 0.6 * (pre + b.cpu()) + 1.4 * r.cpu().float()
+        assert float(obig[:, :16].abs().max()) == 0 and float(obig[:, 16 + N:].abs().max()) == 0
+    else:
+        out = torch.empty(M, N, dtype=torch.half, device=DEV)
+        hip.igemm(a, w, out, tune=21 + cfg)
+        ref = pre
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+    # same products, fp32 accumulation in another order: the 128-class kernel agrees to the fp16 output rounding
+    if epi == 3:
+        old = torch.empty(M, N, dtype=torch.half, device=DEV)
+        hip.igemm(a, w, old, tune=12)
+        assert rel_l2(out.cpu().float(), old.cpu().float()) < 5e-4
+
+
+@pytest.mark.parametrize("cfg", [0, 3, 4, 5])
+@pytest.mark.parametrize("mt,nt,dim", [(1, 1, 64), (4, 5, 320), (8, 8, 640)])
+def test_igemm_pingpong_geglu(hip, cfg, mt, nt, dim):
+    bm, bn = PP_TILES[cfg]
+    M, inner = mt * bm, nt * bn // 2
+    a = h16(rnd(M, dim, seed=56)).to(DEV)
+    w = h16(rnd(2 * inner, dim, seed=57, scale=dim ** -0.5))
+    b = rnd(2 * inner, seed=58)
+    from mgld_vsr_amd.engine import pack_geglu
+    wp, bp = pack_geglu(w, b)
+    out = torch.empty(M, inner, dtype=torch.half, device=DEV)
+    hip.igemm(a, wp.to(DEV), out, bias=bp.to(DEV), act=hip.ACT_GEGLU, tune=21 + cfg)
+    y = a.cpu().float() @ w.float().t() + b
+    ref = y[:, :inner] * F.gelu(y[:, inner:])
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+
+
+def test_igemm_pingpong_race_screen(hip):
+    """the counted waits / barrier placement of the ring: many launches of a long-K problem on every configuration must give the same
+    bits every time (a stage read before its DMA landed shows up as launch-to-launch differences)"""
+    K = 2560
+    for cfg, (bm, bn) in PP_TILES.items():
+        M, N = 16 * bm, 2 * bn
+        a, w = h16(rnd(M, K, seed=59)).to(DEV), h16(rnd(N, K, seed=60, scale=K ** -0.5)).to(DEV)
+        outs = [torch.empty(M, N, dtype=torch.half, device=DEV) for _ in range(6)]
+        for o in outs:
+            hip.igemm(a, w, o, tune=21 + cfg)
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), f"configuration {cfg}: launches differ"
+        ref = a.cpu().float() @ w.cpu().float().t()
+        assert rel_l2(outs[0].cpu().float(), ref) < 1e-3
+
+
 def _conv_ref(x_nchw, w, b, stride, pad):
     return F.conv2d(F.pad(x_nchw, pad), w, b, stride=stride)
 
@@ -341,6 +424,73 @@ def test_igemm_conv3x3_tile2d(hip, variant, n, cin, cout, h, w, epi):
               tap_inner=2, N=cout, K=9 * cin, tune=variant + 1, **kw)
     torch.cuda.synchronize()
     assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
+
+
+R3_BN = {0: 160, 1: 320, 2: 128, 3: 256, 4: 160, 5: 160, 6: 80, 7: 80, 8: 128}      # weight rows per block of the ping-pong patch conv configurations (csrc/conv3r.hip)
+
+
+@pytest.mark.parametrize("cfg", sorted(R3_BN))
+@pytest.mark.parametrize("n,cin,nt,h,w,epi", [
+    (2, 64, 1, 24, 40, 0),         # ragged in both directions for every tile shape (zero-filled halo AND ragged tiles)
+    (1, 128, 2, 72, 80, 1),        # W > 64, residual + SiLU epilogue, two column tiles
+    (3, 320, 2, 64, 64, 2),        # the UNet's dominant shape, per-frame row vector, strided (concat-slice) input
+    (1, 32, 1, 16, 16, 0),         # single slice (the ring is deeper than the problem), one tile
+    (2, 96, 1, 8, 16, 3)])         # three slices, nothing in the epilogue
+def test_igemm_conv3x3_pingpong(hip, cfg, n, cin, nt, h, w, epi):
+    """conv3r: the ping-pong patch conv, every configuration (tune = 31 + id) vs torch's conv2d on the same fp16 operands"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    cout = nt * R3_BN[cfg]
+    x = h16(rnd(n, cin, h, w, seed=270))
+    wt = h16(rnd(cout, cin, 3, 3, seed=271, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=272)
+    ref = F.conv2d(x.float(), wt.float(), b if epi != 3 else None, padding=1)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    xt = _to_tok(x).to(DEV)
+    kw = dict(bias=b.to(DEV)) if epi != 3 else {}
+    if epi == 1:
+        r = h16(rnd(n * h * w, cout, seed=273))
+        kw.update(resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+        ref = 0.5 * F.silu(ref) + 2.0 * _from_tok(r.float(), n, h, w)
+    elif epi == 2:
+        emb = rnd(n, cout, seed=274)
+        kw.update(rowvec=emb.to(DEV), rows_per_frame=h * w)
+        ref = ref + emb[:, :, None, None]
+        big = torch.zeros(n * h * w, cin + 64, dtype=torch.half, device=DEV)
+        big[:, 32:32 + cin] = xt
+        xt = big[:, 32:32 + cin]
+    p = hip.MgldIGemm()
+    p.mode, p.M, p.N, p.K, p.batch, p.tap_inner, p.tune = hip.MODE_CONV3X3, n * h * w, cout, 9 * cin, 1, 2, 31 + cfg
+    p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, 1, 1, 1, 0
+    p.lda, p.ldc = cin, cout
+    assert hip.igemm_config(p) == 600000 + cfg
+    out = torch.full((n * h * w, cout), float("nan"), dtype=torch.half, device=DEV)
+    hip.igemm(xt, tile_conv3p(wk, cin, False), out, mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0),
+              tap_inner=2, N=cout, K=9 * cin, tune=31 + cfg, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
+
+
+def test_igemm_conv3x3_pingpong_race_screen(hip):
+    """counted waits of the weight ring / patch double buffer: repeated launches of a deep-K problem give the same bits on every
+    configuration, and those bits agree with conv3q's (same products, another summation order) to the fp16 output rounding"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    n, cin, h, w = 4, 640, 32, 64
+    x = h16(rnd(n, cin, h, w, seed=280))
+    xt = _to_tok(x).to(DEV)
+    for cfg, bn in R3_BN.items():
+        cout = 2 * bn
+        wt = h16(rnd(cout, cin, 3, 3, seed=281, scale=(9 * cin) ** -0.5))
+        wk = tile_conv3p(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV), cin, False)
+        outs = [torch.empty(n * h * w, cout, dtype=torch.half, device=DEV) for _ in range(5)]
+        for o in outs:
+            hip.igemm(xt, wk, o, mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=2, N=cout, K=9 * cin, tune=31 + cfg)
+        old = torch.empty(n * h * w, cout, dtype=torch.half, device=DEV)
+        hip.igemm(xt, wk, old, mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=2, N=cout, K=9 * cin, tune=5)
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), f"configuration {cfg}: launches differ"
+        assert rel_l2(outs[0].cpu().float(), old.cpu().float()) < 5e-4
 
 
 @pytest.mark.parametrize("variant", [0, 1, 7])

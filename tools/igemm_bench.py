@@ -42,17 +42,21 @@ VAE = [
     ("vae up 256->512 256", 1, 2097152, 256, 2304, 256, 256, 256, 0, 1, 1),
 ]
 LIN = [
-    ("lin64 320->320", 0, 32768, 320, 320, 0, 0, 0, 0, 0, 1050),
-    ("lin64 320->640 qk", 0, 32768, 640, 320, 0, 0, 0, 0, 0, 250),
+    ("lin64 320->320", 0, 32768, 320, 320, 0, 0, 0, 0, 0, 1250),
+    ("lin64 320->960 qkv", 0, 32768, 960, 320, 0, 0, 0, 0, 0, 250),
     ("geglu64 320->2560", 0, 32768, 2560, 320, 0, 0, 0, 4, 0, 250),
     ("lin64 1280->320", 0, 32768, 320, 1280, 0, 0, 0, 0, 0, 250),
-    ("lin32 640->640", 0, 8192, 640, 640, 0, 0, 0, 0, 0, 1050),
+    ("lin32 640->640", 0, 8192, 640, 640, 0, 0, 0, 0, 0, 1250),
+    ("lin32 640->1920 qkv", 0, 8192, 1920, 640, 0, 0, 0, 0, 0, 250),
     ("geglu32 640->5120", 0, 8192, 5120, 640, 0, 0, 0, 4, 0, 250),
     ("lin32 2560->640", 0, 8192, 640, 2560, 0, 0, 0, 0, 0, 250),
-    ("lin16 1280->1280", 0, 2048, 1280, 1280, 0, 0, 0, 0, 0, 1050),
+    ("lin16 1280->1280", 0, 2048, 1280, 1280, 0, 0, 0, 0, 0, 1250),
+    ("lin16 1280->3840 qkv", 0, 2048, 3840, 1280, 0, 0, 0, 0, 0, 250),
     ("geglu16 1280->10240", 0, 2048, 10240, 1280, 0, 0, 0, 4, 0, 250),
     ("lin16 5120->1280", 0, 2048, 1280, 5120, 0, 0, 0, 0, 0, 250),
     ("lin8 1280->1280", 0, 512, 1280, 1280, 0, 0, 0, 0, 0, 300),
+    ("vae attn 256->768", 0, 327680, 768, 256, 0, 0, 0, 0, 0, 10),
+    ("vae attn 256->256", 0, 327680, 256, 256, 0, 0, 0, 0, 0, 10),
 ]
 
 
@@ -101,6 +105,12 @@ def main():
             else:
                 hip.igemm(a, w, o, bias=bias, act=act, tune=tune)
         best = {}
+        names = {}
+        for v in (variants if mode == 1 else nsts):      # which kernel instantiation each variant runs (the planner may refuse a forced one)
+            hip.IGEMM_LOG = []
+            launch(0, v)
+            names[v] = hip.igemm_kernel_name(hip.IGEMM_LOG[-1])[0].replace("_kernel", "").replace(" ", "")
+            hip.IGEMM_LOG = None
         for r in range(args.rounds):
             for v in (variants if mode == 1 else nsts):
                 if up2 and v > 2 and v != 8:
@@ -119,8 +129,8 @@ def main():
             if v in best:
                 tf = 2.0 * M * N * K / (best[v] * 1e-6) / 1e12
                 totals[v] += best[v] * weight / 1e3
-                line += f"| v{v}: {best[v]:8.2f} us {tf:7.1f} TF "
-                out_rows.append({"name": name, "variant": v, "us": round(best[v], 2), "tflops": round(tf, 1), "weight": weight})
+                line += f"| v{v} {names.get(v, '')[:34]}: {best[v]:8.2f} us {tf:7.1f} TF "
+                out_rows.append({"name": name, "variant": v, "kernel": names.get(v, ""), "us": round(best[v], 2), "tflops": round(tf, 1), "weight": weight})
         print(line, flush=True)
         del A, O
     print("weighted totals (ms/segment): " + "  ".join(f"v{v}: {t:.1f}" for v, t in totals.items()) +

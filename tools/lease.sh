@@ -1,0 +1,36 @@
+#!/bin/bash
+# One parametrised runner for the GPU leases of a round (replaces the one-off g<N>.sh scripts of rounds 1-3):
+#   gpurun --timeout T -- 'bash tools/lease.sh <recipe> [args...]'
+# Every recipe writes under gpurun_out/ (merged back by gpurun) and prints a short summary last.
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1
+recipe=$1; shift
+case "$recipe" in
+  pp_lin)     # bring-up of the ping-pong LINEAR kernels: lane-swap probe, unit tests, per-shape A/B against the 128-class kernels
+    ./_variants/pl16_probe 2>&1 | tail -18 | tee gpurun_out/pl16_probe.log
+    timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "pingpong" 2>&1 | tail -15 | tee gpurun_out/pp_tests.log
+    timeout 900 python tools/igemm_bench.py lin --nst ${1:-12,20,21,22,23,24,25,26,27} --rounds 2 --json gpurun_out/pp_lin.json 2>&1 | tee gpurun_out/pp_lin.log | cut -c1-400
+    ;;
+  pp_conv)    # bring-up of the ping-pong patch convolutions: unit tests, per-shape A/B against conv3q
+    timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "pingpong" 2>&1 | tail -15 | tee gpurun_out/pp_tests.log
+    timeout 900 python tools/igemm_bench.py conv --variants ${1:-0,31,32,33,34,35,36,37,38,39} --rounds 2 --json gpurun_out/pp_conv.json 2>&1 | tee gpurun_out/pp_conv.log | cut -c1-420
+    timeout 900 python tools/igemm_bench.py vae --variants ${1:-0,31,32,33,34,35,36,37,38,39} --rounds 2 --json gpurun_out/pp_vae.json 2>&1 | tee gpurun_out/pp_vae.log | cut -c1-420
+    ;;
+  ablate)     # timing of ablation builds (_variants/libmgld_<name>.so, tools/build_variant.sh): <bench group> <only> <tunes> <names...>
+    what=$1; only=$2; tunes=$3; shift; shift; shift
+    for n in base "$@"; do
+      lib=""; [ $n != base ] && lib=_variants/libmgld_$n.so
+      echo "== $n"; MGLD_HIP_LIB=$lib timeout 300 python tools/igemm_bench.py $what --only "$only" --variants $tunes --nst $tunes --rounds 2 2>&1 | grep -v amdgpu.ids | cut -c1-300
+    done | tee gpurun_out/ablate.log
+    ;;
+  tests)      # the GPU suite (optionally -k <expr>)
+    timeout 2400 python -m pytest tests -m gpu -q -x "$@" 2>&1 | tail -15 | tee gpurun_out/tests.log
+    ;;
+  bench)      # bench.py with the given flags; the JSON line goes to gpurun_out/bench_<tag>.json
+    tag=$1; shift
+    timeout 1200 python bench.py "$@" 2> gpurun_out/bench_$tag.err | tail -1 > gpurun_out/bench_$tag.json
+    cut -c1-600 gpurun_out/bench_$tag.json
+    ;;
+  *) echo "unknown recipe $recipe"; exit 2 ;;
+esac
