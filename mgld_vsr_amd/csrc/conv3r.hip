@@ -303,22 +303,25 @@ bool conv3r_plan(const MgldIGemm* p, int* id) {
   }
   const int frames = p->M / (p->Hout * p->Wout), cus = num_cus();
   auto tiles_of = [&](int i) { return (int64_t)frames * cdiv(p->Hout, R3_CFG[i].ty) * cdiv(p->Wout, R3_CFG[i].tx) * (p->N / R3_CFG[i].bn); };
-  // planner: filled in from measurements (tools/igemm_bench.py conv / vae); candidates by divisibility, at least ~one block per CU
+  // planner (measured against conv3q on MI355X, tools/igemm_bench.py conv / vae, profiles/r04_pp_conv.txt): the first configuration of the
+  // list for N's divisibility whose tile count covers most of the chip and whose tile width the image fills.  Small frames with few
+  // tiles (the 16^2 / 8^2 UNet levels) stay on conv3q and its K split.
   int bid = -1;
-  const int pref[R3_NCFG] = {3, 0, 2, 1, 5, 4, 6, 7, 8};
-  for (int k = 0; k < R3_NCFG && bid < 0; ++k) {
-    const int i = pref[k];
-    if (i == 4 || i >= 6 || !fits(i)) continue;
-    const int64_t t = tiles_of(i);
-    if (4 * t >= 3 * cus) bid = i;
-  }
+  auto take = [&](int i, int64_t min_tiles) {
+    if (bid >= 0 || !fits(i) || p->Wout < R3_CFG[i].tx || p->Hout < R3_CFG[i].ty) return;
+    if (tiles_of(i) >= min_tiles) bid = i;
+  };
+  const int64_t most = (3 * cus) / 4;
+  if (p->N % 128 == 0) { take(8, most); take(3, most); take(2, cus / 2 - cus / 8); }
+  if (p->N % 80 == 0) { take(6, most); take(0, most); take(7, most); take(5, most); }
   if (bid < 0 && p->tune == 30) {
+    const int pref[R3_NCFG] = {8, 3, 2, 6, 0, 7, 5, 1, 4};
     for (int k = 0; k < R3_NCFG && bid < 0; ++k) if (fits(pref[k])) bid = pref[k];
   }
   if (bid < 0) return false;
   if (p->tune == 0) {
-    static int on = -1;   // until measured against conv3q on every shape the planner takes the family only with MGLD_CONV3R_AUTO = 1
-    if (on < 0) { const char* e = getenv("MGLD_CONV3R_AUTO"); on = e ? atoi(e) : 0; }
+    static int on = -1;   // env MGLD_CONV3R_AUTO = 0: the planner never takes the family (A/B runs)
+    if (on < 0) { const char* e = getenv("MGLD_CONV3R_AUTO"); on = e ? atoi(e) : 1; }
     if (!on) return false;
   }
   *id = bid;

@@ -171,9 +171,9 @@ def test_igemm_epilogues_large_tiles(hip):
     r = h16(rnd(M, N, seed=42)).to(DEV)
     b, rv = rnd(N, seed=43).to(DEV), rnd(M // rpf, N, seed=44).to(DEV)
     out = torch.empty(M, N, dtype=torch.half, device=DEV)
-    hip.igemm(a, w, out, bias=b, rowvec=rv, rows_per_frame=rpf, resid=r, act=hip.ACT_SILU, alpha=0.6, beta=1.4)
+    hip.igemm(a, w, out, bias=b, rowvec=rv, rows_per_frame=rpf, resid=r, act=hip.ACT_SILU, alpha=0.6, beta=1.4, tune=12)
     p = hip.MgldIGemm()
-    p.M, p.N, p.K, p.batch = M, N, K, 1
+    p.M, p.N, p.K, p.batch, p.tune = M, N, K, 1, 12       # (tune 12: the 128-class kernels; the planner gives this shape to ppgemm)
     assert hip.igemm_config(p) == 128128
     ref = 0.6 * F.silu(a.cpu().float() @ w.cpu().float().t() + b.cpu() + rv.cpu().repeat_interleave(rpf, 0)) + 1.4 * r.cpu().float()
     assert rel_l2(out.cpu().float(), ref) < 1e-3

@@ -27,6 +27,13 @@ case "$recipe" in
   tests)      # the GPU suite (optionally -k <expr>)
     timeout 2400 python -m pytest tests -m gpu -q -x "$@" 2>&1 | tail -15 | tee gpurun_out/tests.log
     ;;
+  ab)         # end-to-end A/B: bench.py --inflight 1 (one segment at a time) under the env settings given as arguments, alternated twice
+    for rep in 1 2 3; do for envs in "$@"; do
+      tag=$(echo "$envs" | tr ' =' '__')
+      env $envs timeout 300 python bench.py --inflight 1 --steps ${AB_STEPS:-6} --warmup 2 --no-roofline --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/ab_${tag}_$rep.json
+      python -c "import json;d=json.load(open('gpurun_out/ab_${tag}_$rep.json'));print('$envs rep $rep:',d['value'],d['ms_per_step'])"
+    done; done | tee gpurun_out/ab.log
+    ;;
   bench)      # bench.py with the given flags; the JSON line goes to gpurun_out/bench_<tag>.json
     tag=$1; shift
     timeout 1200 python bench.py "$@" 2> gpurun_out/bench_$tag.err | tail -1 > gpurun_out/bench_$tag.json
