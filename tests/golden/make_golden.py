@@ -497,13 +497,21 @@ class _AD(dict):
         return _AD({k: _AD.wrap(x) for k, x in v.items()}) if isinstance(v, dict) else v
 
 
-def _harness_env(tmp, resolution):
-    """What a run of one of the reference's entry scripts needs here beyond ref_import's stubs: reduced-width configs behind
-    OmegaConf.load, synthetic checkpoints in the reference's key layout, Module.cuda as a no-op.  Returns the ddpm module."""
+def _harness_env(tmp, resolution, full=False, frames=T):
+    """What a run of one of the reference's entry scripts needs here beyond ref_import's stubs: reduced-width (or, full = True, the
+    shipped full-width) configs behind OmegaConf.load, synthetic checkpoints in the reference's key layout, Module.cuda as a no-op.
+    Returns the ddpm module."""
     ref_import.install()
     stubs = types.ModuleType("golden_stubs")
     stubs.StubCond, stubs.StubFlow = _StubCond, _StubFlow
     sys.modules["golden_stubs"] = stubs
+    if full:
+        from configs import STRUCT_FULL, UNET_FULL, VAE_DD_FULL
+        UNET_SMALL, STRUCT_SMALL, VAE_DD_SMALL = (dict(UNET_FULL, num_frames=frames), dict(STRUCT_FULL, num_frames=frames),
+                                                  dict(VAE_DD_FULL, num_frames=frames))
+    else:
+        from configs import STRUCT_SMALL, UNET_SMALL, VAE_DD_SMALL
+    T = frames
     fs_dd = dict(VAE_DD_SMALL, resolution=resolution)
     fs_dd.pop("num_frames")
     dcfg = {"target": "ldm.models.diffusion.ddpm.LatentDiffusionVSRTextWT", "params": dict(
@@ -636,6 +644,53 @@ def gen_harness():
             else:
                 out[f"p{c}_{k}_norm"] = np.array([float(v.double().norm())])
     save("g_harness", **out)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+def gen_harness_full():
+    """H4 at the PRODUCTION schedule and width (review item of round 3): the reference's README entry script
+    scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py::main(), imported from the reference tree and run unmodified, with the
+    SHIPPED full-width networks (synthetic weights), its default 5 frames per segment and 50 DDPM steps, on 5 LR frames of 136x136
+    (-> 544x544: 2x2 pixel patches of 512^2, RAFT flows, dec_w 0.5, AdaIN) — the same stubbing as gen_harness.  The fixture holds the
+    LR frames, the noise, per-patch flows / masks (norms) / x_T / x_0 and the uint8 HR frames the script wrote.  ~1 CPU-hour on 8
+    threads: `make_golden.py harness_full`."""
+    import shutil
+    import tempfile
+    import time
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="mgld_harness_full_")
+    Tn, S, LR = 5, 50, 136
+    t0 = time.time()
+    ddpm = _harness_env(tmp, 512, full=True, frames=Tn)
+    lr_u8 = _harness_frames(tmp, "harness_full/img", LR, LR, Tn)
+    script = ref_import.ref("scripts.vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile")
+    with _Instrument(ddpm, "sample_canvas") as ins:
+        sys.argv = ["x", "--seqs-path", os.path.join(tmp, "in"), "--outdir", os.path.join(tmp, "out"), "--ddpm_steps", str(S), "--n_frames",
+                    str(Tn), "--config", "diffusion.yaml", "--ckpt", os.path.join(tmp, "model.ckpt"), "--vqgan_ckpt",
+                    os.path.join(tmp, "vqgan.ckpt"), "--seed", "42", "--dec_w", "0.5", "--colorfix_type", "adain", "--vqgantile_size", "512",
+                    "--vqgantile_stride", "32", "--upscale", "4"]
+        with torch.enable_grad():
+            script.main()
+    draws, calls = ins.draws, ins.calls
+    hr = np.stack([np.asarray(Image.open(os.path.join(tmp, "out", "seq0", f"{k:04d}.png")).convert("RGB")) for k in range(Tn)])
+    per = 2 + S
+    assert len(calls) == 4 and len(draws) == 4 * per, (len(calls), len(draws))
+    for c in range(1, 4):
+        for j in range(per):
+            assert torch.equal(draws[c * per + j], draws[j])
+    out = {"lr_u8": lr_u8, "hr_u8": hr, "noise_posterior": draws[0], "noise_xT": draws[1],
+           "noise_steps_loop_order": torch.stack(draws[2:2 + S]).half(), "seconds": np.array([time.time() - t0])}
+    for c, rec in enumerate(calls):
+        for k, v in rec.items():
+            if k == "gscale":
+                continue
+            if k in ("x0", "x_T", "lat"):
+                out[f"p{c}_{k}"] = v
+            elif c == 0:
+                out[f"p{c}_{k}"] = v.half() if v.dtype == torch.float32 and k in ("ff", "fb") else v
+            else:
+                out[f"p{c}_{k}_norm"] = np.array([float(v.double().norm())])
+    save("g_harness_full", **out)
     shutil.rmtree(tmp, ignore_errors=True)
 
 
