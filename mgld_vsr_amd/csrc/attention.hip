@@ -30,11 +30,38 @@ namespace {
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) h4_t* lds_h4_ptr;
 
-template <int D, bool VRM = false>
+// DMA (round 4): K / V tiles go global -> LDS by `buffer_load ... lds` (no staging registers, no address arithmetic per tile, no
+// ds_write pass: the staging cost 61 of the kernel's 284 us on 8 x 5 heads x 4096^2, profiles/r04_attn_ablate.txt).  The K image is
+// then lane-linear: 128-byte rows, 16-byte chunk c of key r at chunk c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 fragments, the
+// swizzle applied on the DMA's source side); the V image is the row-major one above.  The transposing reads are inline asm: with the
+// builtin hipcc drains the DMA queue (s_waitcnt vmcnt(0)) in front of the first one of every tile, i.e. waits for the tile it has just
+// requested.  Covered: head_dim 64, row-major V, Nkv % 64 == 0.
+typedef __attribute__((address_space(3))) void* at_lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t at_rsrc_t;
+__device__ __forceinline__ at_rsrc_t at_make_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffffu, 0x00020000); }
+__device__ __forceinline__ void at_dma16(const at_rsrc_t r, char* lds, const uint32_t voff, const uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (at_lds_ptr_t)lds, 16, voff, __builtin_amdgcn_readfirstlane(soff), 0, 0);
+}
+#else
+typedef const void* at_rsrc_t;
+__device__ __forceinline__ at_rsrc_t at_make_rsrc(const void* base) { return base; }
+__device__ __forceinline__ void at_dma16(const at_rsrc_t, char*, const uint32_t, const uint32_t) {}
+#endif
+typedef unsigned at_u64 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ at_u64 at_tr_read(const unsigned lds_addr) {
+  at_u64 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+  return r;
+}
+
+template <int D, bool VRM = false, bool DMA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 2, D == 64 ? 3 : 2)))
 void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
+  static_assert(!DMA || (VRM && D == 64), "DMA staging: head_dim 64, row-major V");
   constexpr int KT = 64;             // keys per tile
-  constexpr int KS = D + 8;          // K LDS row stride (halves): conflict-free ds_read_b128
+  constexpr int KS = DMA ? D : D + 8;  // K LDS row stride (halves): padded rows -> conflict-free ds_read_b128; DMA: swizzled 128-byte rows
   constexpr int VS = KT + 4;         // V^T LDS row stride (halves): 34 banks -> conflict-free ds_read_b64
   constexpr int DK = D / 16;         // k-steps of the QK^T contraction
   constexpr int DT = D / 32;         // 32-row tiles of O^T
@@ -86,6 +113,33 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   const float sc = p.scale * 1.44269504088896340736f;  // fold log2(e): softmax via exp2
+
+  // ---- DMA staging: a tile is 8 K pieces (8 keys x 128 B) + 8 V pieces (16 keys x 64 B of one d half); wave w moves pieces w, w + 4
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const at_rsrc_t rsK = at_make_rsrc(Kp), rsV = at_make_rsrc(Vp);
+  const uint32_t ksi2 = (uint32_t)p.k_si * 2u, vsd2 = (uint32_t)p.vt_sd * 2u;
+  uint32_t dvK[2], dvV[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pc = wave_u + 4 * j;
+    const int row = pc * 8 + (lane >> 3);
+    dvK[j] = (uint32_t)row * ksi2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    const int key = (pc & 3) * 16 + (lane >> 2);
+    dvV[j] = (uint32_t)key * vsd2 + (pc >> 2) * 64 + (lane & 3) * 16;
+  }
+  auto dma_tile = [&](const int kbase, const int buf) __attribute__((always_inline)) {
+    char* dk = (char*)(sKb + buf * KBUF) + wave_u * 1024;
+    char* dv = (char*)(sVb + buf * VBUF) + wave_u * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      at_dma16(rsK, dk + j * 4096, dvK[j], (uint32_t)kbase * ksi2);
+      at_dma16(rsV, dv + j * 4096, dvV[j], (uint32_t)kbase * vsd2);
+    }
+  };
+  int k_rd[DK];                      // DMA image: byte offset of this lane's K fragment (key l31 of a 32-key half, k step ks)
+#pragma unroll
+  for (int ks = 0; ks < DK; ++ks) k_rd[ks] = l31 * 128 + (((ks * 2 + lhi) ^ ((l31 >> 1) & 7)) << 4);
+  const unsigned v_rd = ((((l31 & 15) >> 2) + lhi * 4) * 32 + (l31 & 16) + (l31 & 3) * 4) * 2;   // V^T fragment: the lane's part (bytes)
 
   // Staging loads are branch-free: a full tile adds a wave-uniform offset to per-thread base pointers; the (single)
   // ragged tile clamps its key indices into the valid range instead of predicating: K rows past Nkv repeat the last row
@@ -153,15 +207,23 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   };
 
   const int ntiles = (Nkv + KT - 1) / KT;
-  load_tile(0);
-  store_tile(0);
-  if (ntiles > 1) load_tile(KT);
-  __syncthreads();
+  if constexpr (DMA) {
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    load_tile(0);
+    store_tile(0);
+    if (ntiles > 1) load_tile(KT);
+    __syncthreads();
+  }
 
   for (int t = 0; t < ntiles; ++t) {
     const int kbase = t * KT;
     const int cur = t & 1;
-    if (t + 1 < ntiles) {
+    if constexpr (DMA) {
+      if (t + 1 < ntiles) dma_tile(kbase + KT, cur ^ 1);   // (that buffer was read during tile t-1: every wave has passed the barrier since)
+    } else if (t + 1 < ntiles) {
       store_tile(cur ^ 1);                            // tile t+1 (registers) -> the buffer tile t-1 was read from
       if (t + 2 < ntiles) load_tile(kbase + 2 * KT);  // in flight under this tile's MFMAs
     }
@@ -176,7 +238,8 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
       for (int r = 0; r < 16; ++r) st[k2][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
-        const f16x8 kf = *(const f16x8*)(sK + (k2 * 32 + l31) * KS + ks * 16 + lhi * 8);
+        const f16x8 kf = DMA ? *(const f16x8*)((const char*)sK + k_rd[ks] + k2 * 4096)
+                             : *(const f16x8*)(sK + (k2 * 32 + l31) * KS + ks * 16 + lhi * 8);
         st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[k2], 0, 0, 0);
       }
     }
@@ -222,6 +285,17 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
     m_run = m_new;
 
     // ---- O^T += V^T P^T : 4 chunks of 16 keys; slot jj of chunk c <-> register 8*(c&1)+jj of tile c>>1 ----
+    at_u64 vlo[4][2], vhi[4][2];
+    if constexpr (DMA) {               // all sixteen transposing reads of the tile, then one wait (inline asm: see above)
+      const unsigned va = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)((char*)sV)) + v_rd;
+#define MGLD_AT_TR(c, dt)                                                               \
+  vlo[c][dt] = at_tr_read<((dt) * KT + ((c) >> 1) * 32 + ((c) & 1) * 16) * 64>(va);     \
+  vhi[c][dt] = at_tr_read<((dt) * KT + ((c) >> 1) * 32 + ((c) & 1) * 16) * 64 + 512>(va);
+      MGLD_AT_TR(0, 0) MGLD_AT_TR(0, 1) MGLD_AT_TR(1, 0) MGLD_AT_TR(1, 1) MGLD_AT_TR(2, 0) MGLD_AT_TR(2, 1) MGLD_AT_TR(3, 0) MGLD_AT_TR(3, 1)
+#undef MGLD_AT_TR
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int k2 = c >> 1, c2 = c & 1;
@@ -231,7 +305,11 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         f16x8 vf;
-        if constexpr (VRM) {
+        if constexpr (DMA) {
+          typedef unsigned at_u128 __attribute__((ext_vector_type(4)));
+          const at_u128 w = {vlo[c][dt & 1][0], vlo[c][dt & 1][1], vhi[c][dt & 1][0], vhi[c][dt & 1][1]};
+          vf = __builtin_bit_cast(f16x8, w);
+        } else if constexpr (VRM) {
           // this lane's 16-lane group covers d = dt*32 + (l31 & 16) .. +15; it passes the address of key key0 + (l31 & 15) / 4,
           // columns 4 * (l31 & 3) .. +3 of that block and receives keys key0 .. key0+3 of ITS d (the transposing read)
           const int key0 = k2 * 32 + c2 * 16 + lhi * 4;
@@ -248,7 +326,12 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
       }
     }
-    __syncthreads();  // everyone done reading buffer `cur`; tile t+1 visible in the other one
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed ...
+      __builtin_amdgcn_s_barrier();                        // ... everyone's have, and everyone is done reading buffer `cur`
+    } else {
+      __syncthreads();  // everyone done reading buffer `cur`; tile t+1 visible in the other one
+    }
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ----
@@ -325,7 +408,11 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
       (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
       attr_done2 = true;
     }
-    if (p->head_dim == 64)
+    static int dma = -1;     // env MGLD_ATTN_DMA = 0: the register-staged form (A/B)
+    if (dma < 0) { const char* e = getenv("MGLD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
+    if (p->head_dim == 64 && dma && (p->Nkv % 64) == 0 && ((int64_t)p->Nkv * p->k_si * 2 < 0x7fffffffLL) && ((int64_t)p->Nkv * p->vt_sd * 2 < 0x7fffffffLL))
+      hipLaunchKernelGGL((flash_attn_kernel<64, true, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
+    else if (p->head_dim == 64)
       hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
     else
       hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, dim3(256), LDS128, (hipStream_t)stream, *p, order);

@@ -31,11 +31,17 @@ def main():
         q = torch.randn(B * Nq, C, device=dev).half()
         k = torch.randn(B * Nkv, C, device=dev).half()
         vt = torch.randn(B * C, Np, device=dev).half()
+        v = torch.randn(B * Nkv, C, device=dev).half()
         o = torch.empty_like(q)
+        vrm = Nkv == Nq          # self-attention: V row-major out of the fused q|k|v projection; cross-attention: cached V^T
 
         def launch():
-            hip.attention(q, k, vt, o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=(Nq * C, C, D),
-                          k_strides=(Nkv * C, C, D), vt_strides=(C * Np, D * Np, Np), o_strides=(Nq * C, C, D), scale=D ** -0.5)
+            if vrm:
+                hip.attention(q, k, v, o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=(Nq * C, C, D),
+                              k_strides=(Nkv * C, C, D), vt_strides=(Nkv * C, C, D), o_strides=(Nq * C, C, D), scale=D ** -0.5, v_rowmajor=True)
+            else:
+                hip.attention(q, k, vt, o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=(Nq * C, C, D),
+                              k_strides=(Nkv * C, C, D), vt_strides=(C * Np, D * Np, Np), o_strides=(Nq * C, C, D), scale=D ** -0.5)
         for _ in range(3):
             launch()
         e0.record()

@@ -24,6 +24,11 @@ case "$recipe" in
       echo "== $n"; MGLD_HIP_LIB=$lib timeout 300 python tools/igemm_bench.py $what --only "$only" --variants $tunes --nst $tunes --rounds 2 2>&1 | grep -v amdgpu.ids | cut -c1-300
     done | tee gpurun_out/ablate.log
     ;;
+  attn)       # attention microbench under the given env settings (one per argument), e.g. "MGLD_ATTN_DMA=0"
+    for envs in "" "$@"; do
+      echo "== ${envs:-default}"; env $envs timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids
+    done | tee gpurun_out/attn.log
+    ;;
   tests)      # the GPU suite (optionally -k <expr>)
     timeout 2400 python -m pytest tests -m gpu -q -x "$@" 2>&1 | tail -15 | tee gpurun_out/tests.log
     ;;
