@@ -109,16 +109,7 @@ def main(argv=None, w_latent=False):
     def make_pipe():
         pp = VSRPipeline(num_frames=opt.n_frames, ddpm_steps=opt.ddpm_steps, dec_w=opt.dec_w, colorfix_type=opt.colorfix_type,
                          synthetic_weights=opt.ckpt is None, configs=cfgs)
-        if opt.ckpt:
-            pp.load_checkpoint(opt.ckpt)
-        if opt.vqgan_ckpt:
-            pp.vq_model.init_from_ckpt(opt.vqgan_ckpt)
-        elif opt.ckpt:
-            # a real diffusion checkpoint with NO video-VAE checkpoint: the VAE's parameters are still the zeros _finish_init left
-            # (synthetic_weights is off) — frames would be garbage without any error.  Refuse, as load_checkpoint refuses a
-            # synthetic text context next to real weights.
-            raise SystemExit("[mgld] --ckpt was given but no --vqgan_ckpt exists: the video VAE would run with uninitialised weights; "
-                             "pass --vqgan_ckpt (or drop --ckpt to run everything on the built-in synthetic weights)")
+        pp.load_weights(opt.ckpt, opt.vqgan_ckpt)
         return pp
 
     pipe = make_pipe()
@@ -200,6 +191,8 @@ def main(argv=None, w_latent=False):
                 flush()
     flush()
     writer.close()
+    if pool is not None:
+        pool.close()
     return 0
 
 

@@ -513,7 +513,11 @@ class LatentDiffusionVSRTextWT(nn.Module):
             ctx = cond["c_crossattn"][0] if isinstance(cond, dict) else (cond[0] if isinstance(cond, list) else cond)
             ctx = ctx.to(dev, torch.float32)[:1].contiguous()
             idxs = list(reversed(range(S)))
-            if "start_T" in hooks:       # ddpm.py:4541-4550: `continue` while the step's (original) timestep is above start_T
+            if "start_T" in hooks and tile is not None:
+                # p_sample_loop_canvas has ANOTHER rule (ddpm.py:4639-4640): timesteps = min(timesteps, start_T), i.e. it walks the
+                # schedule indices start_T-1 .. 0 whatever their original timesteps are
+                idxs = list(reversed(range(min(S, int(hooks["start_T"])))))
+            elif "start_T" in hooks:     # ddpm.py:4541-4550: `continue` while the step's (original) timestep is above start_T
                 idxs = [i for i in idxs if (self.ori_timesteps[i] if use_t_replace else i) <= hooks["start_T"]]
             if "mask" in hooks:
                 assert "x0" in hooks, "mask needs x0 (ddpm.py:4522-4524)"

@@ -361,7 +361,10 @@ class Engine:
         assert wp.shape[1] == 9 * cin, (wp.shape, cin)
         tap_inner = 1 if conv_tap_inner(cin, up2) else 0          # must match pack_conv3x3(..., tap_inner) of wp
         kw = {}
-        if stride == 1 and tuple(pad) == (1, 1) and (ho, wo) == ((2 * hin, 2 * win) if up2 else (hin, win)):
+        # (MGLD_CONV3Q=0, the documented A/B switch, leaves only the raster patch kernel for tiled weights, and that one does not take
+        # the weight-residual pass: such layers keep the [N, K] layout and run on the implicit-GEMM kernel instead of failing)
+        raster_only = w2 is not None and os.environ.get("MGLD_CONV3Q", "1") == "0"
+        if not raster_only and stride == 1 and tuple(pad) == (1, 1) and (ho, wo) == ((2 * hin, 2 * win) if up2 else (hin, win)):
             wt = self._conv3p_tiled(wp, x.n, cin, cout, hin, win, tap_inner, up2)
             if wt is not None:
                 w2t = None if w2 is None else self._conv3p_tiled(w2, x.n, cin, cout, hin, win, tap_inner, up2)

@@ -94,6 +94,19 @@ class VSRPipeline:
         m.num_timesteps = 1000
         m.ori_timesteps = sorted(list(use))
 
+    def load_weights(self, ckpt=None, vqgan_ckpt=None):
+        """the checkpoint handling both entry scripts share (oldcanvas_tile.py:91-108 / old.py): diffusion checkpoint, then the video
+        VAE's.  A real diffusion checkpoint WITHOUT a video-VAE checkpoint is refused: the VAE's parameters would still be the zeros
+        _finish_init left (synthetic weights are off) and the frames garbage without any error."""
+        if ckpt:
+            self.load_checkpoint(ckpt)
+        if vqgan_ckpt:
+            self.vq_model.init_from_ckpt(vqgan_ckpt)
+        elif ckpt:
+            raise SystemExit("[mgld] --ckpt was given but no --vqgan_ckpt exists: the video VAE would run with uninitialised weights; "
+                             "pass --vqgan_ckpt (or drop --ckpt to run everything on the built-in synthetic weights)")
+        return self
+
     def load_checkpoint(self, ckpt, vqgan_ckpt=None, context=None, verbose=True):
         """Load the reference's checkpoints the way its script does (oldcanvas_tile.py:91-108, 296-329): the diffusion model's
         `state_dict` goes, strict=False, into the model WITH ITS 1000-STEP SCHEDULE (the checkpoint stores betas / alphas_cumprod /
@@ -341,8 +354,18 @@ class SegmentPool:
         # holes with; ANY offset of 2-26 ms breaks it: 670-675 -> 657 ms per segment at three in flight (profiles/r03_stagger.txt).
         self.stagger_ms = float(os.environ.get("MGLD_STAGGER_MS", "4"))
         self.last_latency_ms = {}     # slot -> GPU-side latency of that job in the last _drive call (hipEvent pair on the worker's stream)
+        self.closed = False
         for t in self._threads:
             t.start()
+
+    # the worker threads keep the pool (k pipeline instances, a 256 MB split-K scratch per thread) alive: close() it — or use it as a
+    # context manager — when the segments are done
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __len__(self):
         return len(self.pipes)
@@ -380,6 +403,9 @@ class SegmentPool:
                 self._sem.release()
 
     def close(self):
+        if self.closed:
+            return
+        self.closed = True
         for q in self._queues:
             q.put(None)
         for t in self._threads:
@@ -396,6 +422,8 @@ class SegmentPool:
     def _drive(self, plan):
         """plan[i] = list of (slot, call) for worker i, call(pipeline instance) -> result; returns {slot: result}.  The GPU-side latency
         of every job (first launch .. last kernel, measured with a hipEvent pair on the worker's stream) lands in last_latency_ms."""
+        if self.closed:
+            raise RuntimeError("SegmentPool is closed")
         out, lat, errs = {}, {}, []
         ready = torch.cuda.Event()
         ready.record()                     # whatever the caller enqueued for the jobs (inputs, pre-drawn noise) on ITS stream ...
@@ -405,7 +433,10 @@ class SegmentPool:
                 self._queues[i].put((pl, ready, out, lat, errs))
                 n += 1
         for _ in range(n):
-            self._sem.acquire()
+            while not self._sem.acquire(timeout=5.0):      # a worker that died outside its try block would never release: notice it
+                if not all(t.is_alive() for t in self._threads):
+                    self.closed = True
+                    raise RuntimeError("SegmentPool: a worker thread died" + (f": {errs[0]!r}" if errs else ""))
         self.last_latency_ms = lat
         if errs:
             raise errs[0]

@@ -36,16 +36,35 @@ def load_trusted_checkpoint(path, map_location="cpu"):
     """torch.load for the reference's checkpoint files (scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py:91-108 calls
     `torch.load(ckpt, map_location="cpu")` with the pre-2.6 default, i.e. the full unpickler).  stablevsr_025.ckpt / vqgan_cfw_00011.ckpt
     are Lightning checkpoints: next to `state_dict` they pickle callback / hyper-parameter objects, which torch >= 2.6's default
-    `weights_only=True` refuses ("Unsupported global").  Order: the safe loader first (plain state dicts need nothing else); when it
-    refuses, the full unpickler on this local, user-supplied file — with classes of modules that are not importable here
-    (pytorch_lightning is not a dependency of this path) replaced by inert placeholders, since only the tensors are read."""
+    `weights_only=True` refuses ("Unsupported global").  Order: the safe loader first (plain state dicts need nothing else; the
+    handful of harmless globals Lightning checkpoints carry are allow-listed).  When it still refuses, the file is NOT unpickled
+    unless the caller opted in — env MGLD_TRUST_CKPT=1 (or trust=True): the full unpickler executes code from the file.  With the
+    opt-in: the full unpickler on this local, user-supplied file, with a loud warning naming it; classes of modules that are not
+    importable here (pytorch_lightning is not a dependency of this path) become inert placeholders, since only the tensors are read."""
+    import collections
+    import os
     import pickle
+    import warnings
 
     import torch
+    safe = [collections.OrderedDict, collections.defaultdict, dict, list, tuple, set, int, float, str, bool, bytes, slice, complex]
     try:
-        return torch.load(path, map_location=map_location, weights_only=True)
-    except pickle.UnpicklingError:
+        import argparse
+        safe.append(argparse.Namespace)              # Lightning's hyper_parameters
+    except ImportError:
         pass
+    try:
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError as e:
+        refused = str(e).splitlines()[0] if str(e) else "unsupported global"
+    if os.environ.get("MGLD_TRUST_CKPT", "0") != "1" and not getattr(load_trusted_checkpoint, "trust", False):
+        raise RuntimeError(
+            f"{path}: the safe loader (torch.load(weights_only=True)) refuses this file ({refused}).  It is a pickle that can run code "
+            "when loaded.  If you trust where it came from (the reference's own stablevsr_025.ckpt / vqgan_cfw_00011.ckpt are Lightning "
+            "pickles of this kind), set MGLD_TRUST_CKPT=1 to load it with the full unpickler, or convert it once to a plain state dict.")
+    warnings.warn(f"[mgld] loading {path} with the FULL unpickler (MGLD_TRUST_CKPT=1): code inside the file can run. "
+                  f"The safe loader refused it: {refused}", stacklevel=2)
 
     class _Placeholder:
         def __init__(self, *a, **k):

@@ -126,10 +126,8 @@ def main(argv=None):
         cfgs = (cfgs[0], v)
     pipe = VSRPipeline(num_frames=opt.n_frames, ddpm_steps=opt.ddpm_steps, dec_w=opt.dec_w,
                        colorfix_type=opt.colorfix_type, synthetic_weights=opt.ckpt is None, configs=cfgs)
-    if opt.ckpt:
-        pipe.load_checkpoint(opt.ckpt)                # 1000-step buffers first, respacing after; text tower from the checkpoint
-    if opt.vqgan_ckpt:
-        pipe.vq_model.init_from_ckpt(opt.vqgan_ckpt)
+    pipe.load_weights(opt.ckpt, opt.vqgan_ckpt)       # 1000-step buffers first, respacing after; text tower from the checkpoint; refuses
+                                                      # a real --ckpt without a video-VAE checkpoint (the VAE would run on zeros)
     pool = None
     if opt.inflight > 1:                         # extra instances share the first one's host weights (taken before its first launch)
         from mgld_vsr_amd.pipeline import SegmentPool
