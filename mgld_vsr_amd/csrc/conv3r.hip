@@ -11,7 +11,7 @@
 //   * fragment reads are one ds_read_b128 per 16-row fragment; the four k groups of the 16x16x32 pattern read the 16-byte chunks of a row
 //     in the order {0, 3, 1, 2} and the patch image is swizzled by (row >> 2) & 1: conflict-free for every tap shift (see the kernel);
 // Out-of-image patch pixels: the DMA lane's offset is pushed past the descriptor's range and the hardware writes zeros.
-// Covered: tap_inner = 2 weights, Cin % 32 == 0, N % BN == 0, no upsample fold, no K split, no weight-residual pass, fp16 out,
+// Covered: tap_inner = 2 weights, Cin % 32 == 0, N % BN == 0, no upsample fold, no K split, fp16 out,
 // act in {none, SiLU}; everything else stays on conv3q.hip.
 #include "pp_common.h"
 
@@ -23,7 +23,10 @@ namespace {
 using namespace mgld_ig;
 constexpr int PPA = MGLD_PP_ABLATE;
 
-template <int TY, int TX, int BN, int WGM, int WGN, int NSW>
+// TWO: the instantiation that runs the weight-residual pass (MgldIGemm.W2): the slices are walked twice over the same patches — first
+// against the scaled fp16 residual of the weights (same tiled layout, its own buffer descriptor), then, after ONE multiplication of the
+// accumulators by w2_scale, against the weights themselves.  A "visit" v below is slice v % nh of pass v / nh.
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW, bool TWO = false>
 __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const int tiles_x, const int tiles_y, const int order) {
   constexpr int BM = TY * TX, WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
   // patch rows are laid out with a row stride of PW pixels, PW a multiple of 8 (TX + 2 rounded up; the pad columns are DMA'd as zeros):
@@ -73,6 +76,8 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
   const uint32_t fbytes = (uint32_t)min((int64_t)0x7fffffff, (int64_t)Hin * Win * p.lda * 2);
   const auto rsA = pp_make_rsrc((const f16*)p.A + fpix * p.lda, fbytes);
   const auto rsW = pp_make_rsrc(p.W, 0xffffffffu);
+  const auto rsW2 = pp_make_rsrc(TWO ? p.W2 : p.W, 0xffffffffu);
+  const int nv = TWO ? 2 * nh : nh;                  // visits
   uint32_t voffA[NPT];
 #pragma unroll
   for (int s = 0; s < NPT; ++s) {
@@ -90,17 +95,27 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
     const int gr = (bn0 >> 4) + k * 8 + wave;
     wbase[k] = (uint32_t)((((gr >> 2) * nh * 3) * 4 + (gr & 3)) * 3) * 1024u;
   }
-  auto issue_patch = [&](const int s, const int par, const int hh) __attribute__((always_inline)) {
+  auto issue_patch = [&](const int s, const int par, const int vv) __attribute__((always_inline)) {
+    const int hh = (TWO && vv >= nh) ? vv - nh : vv;
     pp_dma16(rsA, smem + par * A_BYTES + (s * 8 + wave) * 1024, voffA[s], (uint32_t)hh * 64u);
   };
-  auto issue_w = [&](const int slot, const int hh, const int tap) __attribute__((always_inline)) {
+  auto issue_w = [&](const int slot, const int vv, const int tap) __attribute__((always_inline)) {
+    const int hh = (TWO && vv >= nh) ? vv - nh : vv;
     const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
     const uint32_t so = (uint32_t)hh * (36u * 1024u) + (uint32_t)dy * (12u * 1024u) + (uint32_t)dx * 1024u;
     char* dst = smem + W_BASE + slot * WSLOT + wave * 1024;
+    if (TWO && vv < nh) {                          // residual pass
 #pragma unroll
-    for (int k = 0; k < CWHI; ++k) {
-      if (k >= CWLO && !hi) continue;
-      pp_dma16(rsW, dst + k * 8192, voffW, wbase[k] + so);
+      for (int k = 0; k < CWHI; ++k) {
+        if (k >= CWLO && !hi) continue;
+        pp_dma16(rsW2, dst + k * 8192, voffW, wbase[k] + so);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < CWHI; ++k) {
+        if (k >= CWLO && !hi) continue;
+        pp_dma16(rsW, dst + k * 8192, voffW, wbase[k] + so);
+      }
     }
   };
 
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
     for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: patch of slice 0, weights of phases 0 .. D-1; phase 0's operands landed and visible
-  const int F = 9 * nh;
+  const int F = 9 * nv;
 #pragma unroll
   for (int s = 0; s < NPT; ++s) issue_patch(s, 0, 0);
 #pragma unroll
@@ -213,8 +228,24 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
     phase(v, MORE_, std::integral_constant<int, 3>{}); phase(v, MORE_, std::integral_constant<int, 4>{}); phase(v, MORE_, std::integral_constant<int, 5>{});
     phase(v, MORE_, std::integral_constant<int, 6>{}); phase(v, MORE_, std::integral_constant<int, 7>{}); phase(v, MORE_, std::integral_constant<int, 8>{});
   };
-  for (int v = 0; v + 1 < nh; ++v) slice(v, std::true_type{});
-  slice(nh - 1, std::false_type{});
+  for (int v = 0; v + 1 < nv; ++v) {
+    if (TWO && v == nh) {                            // residual pass done: acc = w2_scale * (A W2^T); A W^T accumulates on top
+      const float sc2 = p.w2_scale;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] *= sc2;
+    }
+    slice(v, std::true_type{});
+  }
+  if (TWO && nh == 1) {
+    const float sc2 = p.w2_scale;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] *= sc2;
+  }
+  slice(nv - 1, std::false_type{});
   if (grp == 0) pp_barrier();
 
   if constexpr (PPA & 128) {                       // (ablation: no epilogue)
@@ -258,12 +289,12 @@ constexpr int conv3r_lds() {
   return 2 * NPT * 8 * 1024 + NSW * BN * 64;
 }
 
-template <int TY, int TX, int BN, int WGM, int WGN, int NSW>
-int launch_conv3r(const MgldIGemm* p, hipStream_t s) {
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW, bool TWO = false>
+int launch_conv3r_(const MgldIGemm* p, hipStream_t s) {
   constexpr int lds = conv3r_lds<TY, TX, BN, NSW>();
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3r_kernel<TY, TX, BN, WGM, WGN, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv3r_kernel<TY, TX, BN, WGM, WGN, NSW, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const int frames = p->M / (p->Hout * p->Wout);
@@ -274,8 +305,12 @@ int launch_conv3r(const MgldIGemm* p, hipStream_t s) {
   if (noswap < 0) { const char* e = getenv("MGLD_PP_NOSWAP"); noswap = e ? atoi(e) : 0; }
   const double wbytes = 2.0 * p->N * p->K, abytes = 2.0 * p->M * p->Cin;
   const int order = (forder >= 0 ? forder : (wbytes > 2.0 * abytes ? 1 : 0)) | (noswap ? 0x100 : 0);
-  hipLaunchKernelGGL((conv3r_kernel<TY, TX, BN, WGM, WGN, NSW>), grid, dim3(512), lds, s, *p, tiles_x, tiles_y, order);
+  hipLaunchKernelGGL((conv3r_kernel<TY, TX, BN, WGM, WGN, NSW, TWO>), grid, dim3(512), lds, s, *p, tiles_x, tiles_y, order);
   return mgld_check_launch("igemm(conv3r)");
+}
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW>
+int launch_conv3r(const MgldIGemm* p, hipStream_t s) {
+  return p->W2 ? launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, true>(p, s) : launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, false>(p, s);
 }
 
 }  // namespace
@@ -289,10 +324,11 @@ bool conv3r_plan(const MgldIGemm* p, int* id) {
   if (!knob || p->mode != MGLD_MODE_CONV3X3 || p->tap_inner != 2) return false;
   if (p->tune != 0 && (p->tune < 30 || p->tune > 30 + R3_NCFG)) return false;
   if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
-  if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->W2 || p->out_f32 || p->bias_m || (p->Cin & 31)) return false;
+  if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->out_f32 || p->bias_m || (p->Cin & 31)) return false;
   if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU)) return false;
   if (p->Hout != p->Hin || p->Wout != p->Win || p->Wout < 16 || p->Hout < 8 || (p->M % (p->Hout * p->Wout))) return false;
   if ((p->lda & 7) || (p->ldc & 7) || (((uintptr_t)p->C) & 15) || (p->R && ((p->ldr & 7) || (((uintptr_t)p->R) & 15)))) return false;
+  if (p->W2 && ((((uintptr_t)p->W2) & 15) || !(p->w2_scale > 0.f))) return false;
   if ((p->bias && (((uintptr_t)p->bias) & 15)) || (p->rowvec && ((((uintptr_t)p->rowvec) & 15) || (p->ld_rowvec & 3)))) return false;
   if ((int64_t)p->Hin * p->Win * p->lda * 2 >= 0x7fffffffLL) return false;      // a frame must fit the descriptor's 31-bit range
   auto fits = [&](int i) { return p->N % R3_CFG[i].bn == 0; };
@@ -345,7 +381,6 @@ int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id) {
 void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen) {
   static const int g[R3_NCFG][6] = {{8, 32, 160, 4, 2, 6}, {8, 16, 320, 2, 4, 4}, {8, 32, 128, 4, 2, 6}, {8, 32, 256, 2, 4, 5}, {16, 16, 160, 4, 2, 6},
                                     {8, 16, 160, 4, 2, 6}, {16, 32, 80, 8, 1, 5}, {8, 32, 80, 8, 1, 6}, {16, 32, 128, 8, 1, 5}};
-  (void)p;
-  snprintf(buf, buflen, "conv3r_kernel<%d, %d, %d, %d, %d, %d>", g[id][0], g[id][1], g[id][2], g[id][3], g[id][4], g[id][5]);
+  snprintf(buf, buflen, "conv3r_kernel<%d, %d, %d, %d, %d, %d, %s>", g[id][0], g[id][1], g[id][2], g[id][3], g[id][4], g[id][5], p->W2 ? "true" : "false");
 }
 }  // namespace mgld_ig

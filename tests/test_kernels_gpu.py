@@ -470,6 +470,31 @@ def test_igemm_conv3x3_pingpong(hip, cfg, n, cin, nt, h, w, epi):
     assert rel_l2(_from_tok(out.cpu().float(), n, h, w), ref) < 1e-3
 
 
+@pytest.mark.parametrize("cfg,n,cin,nt,h,w", [(0, 2, 64, 1, 16, 32), (8, 1, 128, 2, 32, 64), (2, 3, 32, 1, 24, 40), (6, 1, 256, 2, 16, 32)])
+def test_igemm_conv3x3_pingpong_w2(hip, cfg, n, cin, nt, h, w):
+    """conv3r with the weight-residual pass (MgldIGemm.W2: every slice visited twice, the accumulators scaled in between): against
+    fp64 on the fp32 weights it must be far closer than the one-pass product of the fp16-rounded weights, and agree with conv3q's
+    residual pass on the same operands"""
+    from mgld_vsr_amd.engine import split_residual, tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    cout = nt * R3_BN[cfg]
+    x = h16(rnd(n, cin, h, w, seed=290))
+    w32 = rnd(cout, cin, 3, 3, seed=291, scale=(9 * cin) ** -0.5)
+    ref = F.conv2d(x.double(), w32.double(), None, padding=1)
+    hi_, lo_ = split_residual(w32.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+    whi, wlo = tile_conv3p(hi_.to(DEV), cin, False), tile_conv3p(lo_.to(DEV), cin, False)
+    xt = _to_tok(x).to(DEV)
+    errs, outs = [], []
+    for tune, w2 in ((31 + cfg, None), (31 + cfg, wlo), (5, wlo)):
+        out = torch.empty(n * h * w, cout, dtype=torch.half, device=DEV)
+        hip.igemm(xt, whi, out, mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=2, N=cout, K=9 * cin, tune=tune, w2=w2)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().float())
+        errs.append(rel_l2(_from_tok(outs[-1], n, h, w), ref))
+    assert errs[1] < errs[0] and errs[1] < 4.5e-4, errs        # (fp16 output rounding alone is ~2.9e-4)
+    assert rel_l2(outs[1], outs[2]) < 2e-4
+
+
 def test_igemm_conv3x3_pingpong_race_screen(hip):
     """counted waits of the weight ring / patch double buffer: repeated launches of a deep-K problem give the same bits on every
     configuration, and those bits agree with conv3q's (same products, another summation order) to the fp16 output rounding"""
