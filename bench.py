@@ -414,6 +414,8 @@ def main():
     kw = dict(flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH)
     if shard is not None:
         kw.update(shard=shard, gather=True)
+    if world > 1 and (args.frame_shard or args.tile_shard):
+        parallel.DistComm.measure = True        # payload + device time of every exchange, reported next to comm_plan()'s prediction
     if args.tile_shard and args.tile and world > 1:
         frames, noise, flows, masks = make_inputs(pipe, args, 0)     # every rank builds the SAME clip
         h8 = args.size // 8
@@ -490,6 +492,14 @@ def main():
         dt = parallel.max_over_ranks(dt_local)
         latency = {"median_ms": round(1e3 * dt / args.steps, 1), "how": "one segment at a time: wall time of the timed region / segments"}
         one_at_a_time = None
+    comm = None
+    if world > 1 and parallel.DistComm.measure:
+        # warm-up + timed segments were logged alike: per segment = totals / (warmup + steps)
+        rep, nseg = parallel.DistComm.report(), args.warmup + args.steps
+        plan = parallel.comm_plan("tile" if args.tile_shard else "frame", T=args.frames, H=args.size, W=args.size, world=world, steps=args.ddpm_steps)
+        comm = {"plan_bytes_per_segment_per_rank": plan["bytes_per_segment"], "measured_bytes_per_segment_rank0": int(rep["bytes"] / nseg),
+                "measured_exchange_ms_per_segment_rank0": round(rep["ms"] / nseg, 3), "exchanges_per_segment": rep["calls"] // nseg,
+                "how": "device event pair around every exchange on rank 0's stream (includes waiting for the slowest neighbour)"}
     ok = bool(torch.isfinite(out).all())
     h8_ = args.size // 8
     n_unet_tiles = len(pipe.model._tile_origins(h8_, h8_, TILE[0], TILE[1])) if TILE else (args.size / 512.0) ** 2
@@ -515,7 +525,8 @@ def main():
                    "graphs_per_step": int(getattr(pipe.model, "last_graph_pieces", 0)),
                    "segments_in_flight": inflight,
                    "segment_latency_ms": latency["median_ms"], "segment_latency": latency,
-                   "world_size_seen": world, "backend": args.backend if world > 1 else None, "per_rank_ms_per_step": per_rank_ms},
+                   "world_size_seen": world, "backend": args.backend if world > 1 else None, "per_rank_ms_per_step": per_rank_ms,
+                   "comm": comm},
         # per frame: the sampler's work scales with the latent tiles it evaluates (aggregation sampling: every 64x64 tile is one 512^2
         # frame's worth of UNet + struct-cond work), the VAE's with the pixels
         "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME * n_unet_tiles + (2 * GFLOP_ENC_PER_FRAME +

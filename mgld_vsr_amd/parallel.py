@@ -105,7 +105,41 @@ def gather_frames(local_frames, segment_ids, n_segments, device=None):
 # Zero padding at the two ends of the clip (Conv3d padding, diffusionmodules/util.py:298) is kept on the first / last rank.
 # ----------------------------------------------------------------------------------------------------------------------
 class DistComm:
-    """torch.distributed transport ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+    """torch.distributed transport ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
+
+    DistComm.measure = True (bench.py's sharded modes): every exchange is bracketed by a device event pair on the current stream and its
+    payload counted; DistComm.report() returns what this rank sent / received and how long the exchanges took, so the bench line can put
+    comm_plan()'s predicted bytes next to measured bytes and time."""
+    measure = False
+    _log = []           # (bytes this rank contributes or receives, event pair or host seconds)
+
+    @classmethod
+    def _bracket(cls, nbytes, fn, device):
+        if not cls.measure:
+            return fn()
+        if device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            cls._log.append((nbytes, (e0, e1)))
+        else:
+            import time
+            t0 = time.perf_counter()
+            r = fn()
+            cls._log.append((nbytes, time.perf_counter() - t0))
+        return r
+
+    @classmethod
+    def report(cls, reset=True):
+        """{"calls", "bytes", "ms"} over the exchanges logged since the last reset (synchronises the device)"""
+        if any(not isinstance(t, float) for _, t in cls._log):
+            torch.cuda.synchronize()
+        ms = sum((1e3 * t) if isinstance(t, float) else t[0].elapsed_time(t[1]) for _, t in cls._log)
+        out = {"calls": len(cls._log), "bytes": int(sum(b for b, _ in cls._log)), "ms": round(ms, 3)}
+        if reset:
+            cls._log = []
+        return out
 
     def all_gather(self, t, shard, out=None):
         """`out`: a caller-owned buffer of the gathered shape (fixed address: what the graph pieces of a sharded step need)"""
@@ -114,10 +148,13 @@ class DistComm:
         if out is None:
             out = torch.empty((shard.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         assert out.is_contiguous() and out.shape[0] == shard.world * t.shape[0]
-        try:
-            dist.all_gather_into_tensor(out, t)
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather(list(out.chunk(shard.world, 0)), t)
+
+        def run():
+            try:
+                dist.all_gather_into_tensor(out, t)
+            except (RuntimeError, NotImplementedError):
+                dist.all_gather(list(out.chunk(shard.world, 0)), t)
+        self._bracket(t.numel() * t.element_size() * max(1, shard.world - 1), run, t.device)     # received from the other ranks
         return out
 
     def exchange(self, x, rows_per_frame, recv_left, recv_right, shard):
@@ -138,8 +175,10 @@ class DistComm:
         else:
             recv_right.zero_()
         if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            def run():
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            self._bracket(sum(k.numel() * k.element_size() for k in keep), run, x.device)               # sent to the neighbours
 
 
     def gather_tiles(self, t, shard, out=None):
