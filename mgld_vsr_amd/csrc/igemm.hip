@@ -727,6 +727,7 @@ extern "C" int mgld_igemm_config(const MgldIGemm* p) {
   int cfg, splits, kchunk;
   if (ppgemm_plan(p, &cfg)) return 500000 + cfg;                                                            // ping-pong LINEAR
   if (conv3r_plan(p, &cfg)) return 600000 + cfg;                                                            // ping-pong patch conv
+  { int lg_; if (pptconv_plan(p, &cfg, &lg_)) return 700000 + cfg; }                                        // ping-pong temporal conv
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return 400000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // 2-D-tile patch conv
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) return 300000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // raster patch conv
   choose(p, &cfg, &splits, &kchunk);
@@ -745,6 +746,7 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
     conv3r_kernel_name(p, cfg, buf, buflen);
     return 1;
   }
+  { int lg_; if (pptconv_plan(p, &cfg, &lg_)) { pptconv_kernel_name(p, cfg, buf, buflen); return 1; } }
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
     conv3q_kernel_name(p, cfg, buf, buflen);
     return splits;
@@ -808,6 +810,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   int cfg, splits, kchunk;
   if (ppgemm_plan(p, &cfg)) return dispatch_ppgemm(p, s, cfg);
   if (conv3r_plan(p, &cfg)) return dispatch_conv3r(p, s, cfg);
+  { int lg_; if (pptconv_plan(p, &cfg, &lg_)) return dispatch_pptconv(p, s, cfg, lg_); }
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return dispatch_conv3q(p, s, cfg, splits, kchunk);
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) {
     MGLD_REQUIRE(!p->W2, "igemm: the raster patch kernel (MGLD_CONV3Q=0) does not take W2");

@@ -634,6 +634,39 @@ def test_igemm_tconv_frame_interleaved_rows(hip, clips, T, c, h, w):
     assert rel_l2(_from_tok(outs[0].float(), clips * T, h, w), ref) < 1e-3
 
 
+@pytest.mark.parametrize("clips,T,c,h,w,w2", [(1, 8, 128, 8, 8, False), (2, 8, 256, 16, 8, False), (3, 4, 128, 8, 8, False), (1, 4, 512, 16, 16, True),
+                                              (2, 8, 128, 32, 32, True), (1, 8, 640, 8, 4, False)])
+def test_igemm_tconv_pingpong(hip, clips, T, c, h, w, w2):
+    """pptconv (tune = 40): the temporal Conv3d on ping-pong tiles of 256 / T pixels x all T frames — first / last frame of every clip
+    (the zero padding comes from lanes pushed out of the DMA descriptor's range), several clips, both tile widths, K order (tap, Cin),
+    the blend epilogue and the weight-residual pass; against Conv3d on the same fp16 operands (W2: on the fp32 weights)."""
+    from mgld_vsr_amd.engine import split_residual
+    x = h16(rnd(clips * T, c, h, w, seed=341))
+    w32 = rnd(c, c, 3, 1, 1, seed=342, scale=(3 * c) ** -0.5)
+    b = rnd(c, seed=343)
+    alpha = 0.6
+    wk32 = w32[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, 3 * c).contiguous()
+    hi_, lo_ = split_residual(wk32)
+    wref = w32.double() if w2 else hi_.double().reshape(c, 3, c).permute(0, 2, 1)[..., None, None]
+    x5 = x.double().reshape(clips, T, c, h, w).permute(0, 2, 1, 3, 4)
+    res = F.conv3d(x5, wref, b.double(), padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(clips * T, c, h, w)
+    ref = alpha * res + (1 - alpha) * x.double()
+    xt = _to_tok(x).to(DEV)
+    p = hip.MgldIGemm()
+    p.mode, p.M, p.N, p.K, p.batch, p.tune, p.Cin, p.T, p.HW = hip.MODE_TCONV3, clips * T * h * w, c, 3 * c, 1, 40, c, T, h * w
+    p.lda = p.ldw = p.ldc = 8
+    assert hip.igemm_config(p) // 100000 == 7
+    outs = []
+    for _ in range(3):
+        out = torch.full_like(xt, float("nan"))
+        hip.igemm(xt, hi_.to(DEV), out, mode=hip.MODE_TCONV3, bias=b.to(DEV), resid=xt, alpha=alpha, beta=1 - alpha, tconv=(c, T, h * w), tune=40,
+                  w2=lo_.to(DEV) if w2 else None)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_l2(_from_tok(outs[0].float(), clips * T, h, w), ref) < (4.5e-4 if w2 else 1e-3)
+
+
 def test_igemm_skinny_output_splits_k(hip):
     """N <= 32 over a deep K with fewer row tiles than 2 x CUs: the launcher splits K (csrc/igemm.hip choose()); result vs conv2d"""
     hip.set_workspace(hip._test_ws)

@@ -24,6 +24,10 @@ case "$recipe" in
       echo "== $n"; MGLD_HIP_LIB=$lib timeout 300 python tools/igemm_bench.py $what --only "$only" --variants $tunes --nst $tunes --rounds 2 2>&1 | grep -v amdgpu.ids | cut -c1-300
     done | tee gpurun_out/ablate.log
     ;;
+  tconv)      # the temporal Conv3d: unit tests + microbench (implicit-GEMM kernel in both row orders against the ping-pong kernel)
+    timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "tconv" 2>&1 | tail -15 | tee gpurun_out/tconv_tests.log
+    timeout 600 python tools/tconv_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/tconv.log | cut -c1-400
+    ;;
   attn)       # attention microbench under the given env settings (one per argument), e.g. "MGLD_ATTN_DMA=0"
     for envs in "" "$@"; do
       echo "== ${envs:-default}"; env $envs timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Microbench of the video VAE's temporal Conv3d (3,1,1) launches (MODE_TCONV3) at the decoder's four levels: frame-interleaved row order
-(tune 0, the launcher's default) against tiles of consecutive rows (tune 15), with and without the weight-residual pass.  Reports us per
+"""Microbench of the video VAE's temporal Conv3d (3,1,1) launches (MODE_TCONV3) at the decoder's four levels: the implicit-GEMM kernel in both row orders
+(tune 15 consecutive rows, tune 14 frame-interleaved) against the planner's choice (tune 0: the ping-pong kernel of pptconv.hip where it covers), with and without the weight-residual pass.  Reports us per
 launch and the algorithmic HBM rate (input rows once + output rows once).  Scratch tool — not product, not a test.
 
     python tools/tconv_bench.py [--iters 5] [--rounds 3]
@@ -38,7 +38,7 @@ def main():
         bias = torch.randn(C, device="cuda")
         line = f"{name:18s} M={M:8d} "
         for two in (False, True):
-            for tune in (15, 0):
+            for tune in (15, 14, 0):   # consecutive rows, frame-interleaved rows (implicit-GEMM kernel), the planner (ping-pong kernel where covered)
                 best = 1e30
                 for _ in range(args.rounds):
                     def launch(i):
@@ -52,7 +52,7 @@ def main():
                     e1.sync()
                     best = min(best, 1e3 * e0.elapsed_ms(e1) / args.iters)
                 gbs = 4.0 * M * C / (best * 1e-6) / 1e9
-                line += f"| {'w2 ' if two else ''}{'rows' if tune else 'frames'}: {best:8.1f} us {gbs:7.0f} GB/s "
+                line += f"| {'w2 ' if two else ''}{ {15: 'rows', 14: 'frames', 0: 'plan'}[tune] }: {best:8.1f} us {gbs:7.0f} GB/s "
         print(line, flush=True)
         del A, O
 
