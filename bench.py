@@ -21,6 +21,8 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the sources whose sha keys profiles/r04_pmc_traffic.json (tools/pmc_traffic.sh imports this list)
+GEMM_FAMILY_SOURCES = ("igemm_common.h", "pp_common.h", "igemm.hip", "conv3q.hip", "conv3r.hip", "ppgemm.hip", "pptconv.hip", "attention.hip")
 sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0   # dense MFMA fp16 peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -148,7 +150,7 @@ def _pmc_traffic(kernel):
     import hashlib
     try:
         src = b""
-        for f in ("igemm_common.h", "pp_common.h", "igemm.hip", "conv3q.hip", "conv3r.hip", "ppgemm.hip", "attention.hip"):
+        for f in GEMM_FAMILY_SOURCES:
             with open(os.path.join(ROOT, "mgld_vsr_amd", "csrc", f), "rb") as fh:
                 src += fh.read()
         sha = hashlib.sha256(src).hexdigest()[:16]

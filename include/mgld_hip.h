@@ -118,7 +118,17 @@ typedef struct MgldIGemm {
                              ~2^-21 instead of 2^-11, at twice the MFMA work and no extra activation traffic beyond L2.  For the layers
                              whose fp16 weight rounding dominates the output error.  Not with split-fp32 outputs of the
                              raster patch kernel (conv3p).                                                                                  */
+  float* gn_part;         /* NULL, or where the kernel ALSO writes the GroupNorm statistics of its output: per output tile and channel
+                             the (sum, sumsq) of the values it stores (taken before their rounding to fp16: the rounding noise is zero-mean and moves the
+                             moments of a frame by ~1e-7 relative), float [frames * chunks][2][N] with chunks =
+                             mgld_igemm_gn_chunks(p) tiles per frame (> 0: the kernel the launcher picks produces them — the ping-pong
+                             patch convolution today; 0: it does not, and a launch with gn_part set is refused).  The consumer passes
+                             {gn_part, MGLD_GN_CHANNEL_SUMS, chunks} to mgld_gn_apply2 / mgld_spade_apply2 instead of launching mgld_gn_stats
+                             (GroupNorm32 on a convolution's output: openaimodel.py:401-405,429-436).                                */
 } MgldIGemm;
+
+/* tiles per frame of the statistics output (see gn_part), or 0 when the kernel picked for this problem does not produce it */
+int mgld_igemm_gn_chunks(const MgldIGemm* p);
 
 int mgld_igemm(const MgldIGemm* p, void* stream);
 /* block tile the launcher selects for this problem, encoded BM*1000+BN, plus splits*1000000 when the problem is
@@ -152,6 +162,26 @@ int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, con
                      const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
                      int frames, int rows_per_frame, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
                      void* stream);
+/* Where a GroupNorm consumer finds the statistics of its input, when they were produced by the kernel that WROTE that input
+ * (no mgld_gn_stats launch): kind MGLD_GN_GROUP_SUMS = double [frames][chunks][groups][2] (mgld_gn_stats' format with any chunk
+ * count: the stats_out of mgld_gn_apply2 / mgld_spade_apply2, chunks = mgld_gn_apply_chunks(...)); kind MGLD_GN_CHANNEL_SUMS =
+ * float [frames * chunks][2][C] per-channel (sum, sumsq) of every output tile (MgldIGemm.gn_part, chunks = mgld_igemm_gn_chunks). */
+#define MGLD_GN_GROUP_SUMS 0
+#define MGLD_GN_CHANNEL_SUMS 1
+typedef struct MgldGnStats {
+  const void* sums;
+  int kind;
+  int chunks; /* per frame */
+} MgldGnStats;
+/* mgld_gn_apply / mgld_spade_apply with the statistics source spelled out and, when stats_out != NULL, the per-group sums of the
+ * OUTPUT y (the values stored, before their fp16 rounding) written as double [frames][mgld_gn_apply_chunks(frames, rows, C, groups)][groups][2]. */
+int mgld_gn_apply_chunks(int frames, int rows_per_frame, int C, int groups);
+int mgld_gn_apply2(const void* x, int ldx, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                   void* y, int ldy, int frames, int rows_per_frame, int C, int groups, int silu, double* stats_out, void* stream);
+int mgld_spade_apply2(const void* h, int ldh, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                      const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
+                      int frames, int rows_per_frame, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
+                      double* stats_out, void* stream);
 /* Statistics + apply in ONE launch for small frames (rows_per_frame <= 256: the UNet's 16x16 / 8x8 levels), plain
  * (gb == NULL: y = act(GN(x))) or SPADE (gb, skip given: the mgld_spade_apply formula).  Same arithmetic as
  * mgld_gn_stats + mgld_gn_apply / mgld_spade_apply (fp32 per-channel sums, fp64 per-group combine); mgld_gn_fused_applies

@@ -261,11 +261,22 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
   e.noswap = (order & 0x100) != 0;
   const int Hout = p.Hout, Wout = p.Wout;
   const int fbase = frame * Hout * Wout;
-  pp_epilogue<MI, NI, false>(e, acc, lane, bn0 + wn * WN, [&](const int mi) {
+  const auto row_of = [&](const int mi) {
     const int R = wm * WM + mi * 16 + l15;
     const int y = y0 + R / TX, x = x0 + (R & (TX - 1));
     return (y < Hout && x < Wout) ? fbase + y * Wout + x : -1;
-  });
+  };
+  if (p.gn_part) {
+    // GroupNorm statistics of the output (MgldIGemm.gn_part): every wave's per-channel sums of its stored rows meet in LDS (the stages
+    // are dead: both wave groups are past their last fragment read), one row of part[] per tile.  A tile lies in one frame.
+    float* table = (float*)smem;
+    pp_epilogue_stats<MI, NI>(e, acc, lane, bn0 + wn * WN, p.rowvec ? (frame * Hout * Wout) / p.rows_per_frame : -1, row_of,
+                              table + (wm * BN + wn * WN) * 2);
+    __syncthreads();
+    pp_stats_flush<WGM, BN>(table, p.gn_part, (int64_t)tile_m, p.N, bn0, tid);
+    return;
+  }
+  pp_epilogue<MI, NI, false>(e, acc, lane, bn0 + wn * WN, row_of);
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------------------------------
@@ -377,6 +388,9 @@ int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id) {
     default: return launch_conv3r<16, 32, 128, 8, 1, 5>(p, s);
   }
 }
+
+// tiles per frame of configuration id (the row count of MgldIGemm.gn_part per frame)
+int conv3r_gn_chunks(const MgldIGemm* p, int id) { return cdiv(p->Hout, R3_CFG[id].ty) * cdiv(p->Wout, R3_CFG[id].tx); }
 
 void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen) {
   static const int g[R3_NCFG][6] = {{8, 32, 160, 4, 2, 6}, {8, 16, 320, 2, 4, 4}, {8, 32, 128, 4, 2, 6}, {8, 32, 256, 2, 4, 5}, {16, 16, 160, 4, 2, 6},

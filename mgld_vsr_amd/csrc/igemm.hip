@@ -734,6 +734,15 @@ extern "C" int mgld_igemm_config(const MgldIGemm* p) {
   return cfg + (splits > 1 ? splits * 1000000 : 0);
 }
 
+// statistics output (MgldIGemm.gn_part): tiles per frame when the kernel picked for this problem writes it, else 0
+extern "C" int mgld_igemm_gn_chunks(const MgldIGemm* p) {
+  if (!p) return 0;
+  int cfg;
+  if (ppgemm_plan(p, &cfg)) return 0;
+  if (conv3r_plan(p, &cfg)) return (p->N & 7) ? 0 : conv3r_gn_chunks(p, cfg);
+  return 0;
+}
+
 // name of the kernel template instantiation the launcher runs for this problem, spelled as rocprofv3 prints it
 extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen) {
   MGLD_REQUIRE(p && buf && buflen > 0, "igemm_kernel_name: null");
@@ -808,6 +817,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;
+  if (p->gn_part) MGLD_REQUIRE(mgld_igemm_gn_chunks(p) > 0 && ((((uintptr_t)p->gn_part) & 3) == 0), "igemm: gn_part set, but the kernel picked for this problem does not write statistics (mgld_igemm_gn_chunks)");
   if (ppgemm_plan(p, &cfg)) return dispatch_ppgemm(p, s, cfg);
   if (conv3r_plan(p, &cfg)) return dispatch_conv3r(p, s, cfg);
   { int lg_; if (pptconv_plan(p, &cfg, &lg_)) return dispatch_pptconv(p, s, cfg, lg_); }

@@ -27,6 +27,7 @@ void ppgemm_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
 bool conv3r_plan(const MgldIGemm* p, int* id);
 int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id);
 void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
+int conv3r_gn_chunks(const MgldIGemm* p, int id);
 // pptconv.hip (ping-pong temporal Conv3d)
 bool pptconv_plan(const MgldIGemm* p, int* id, int* lgP);
 int dispatch_pptconv(const MgldIGemm* p, hipStream_t s, int id, int lgP);

@@ -107,33 +107,77 @@ __device__ __forceinline__ void gn_group_stats(const double* __restrict__ gs, in
   __syncthreads();
 }
 
+// ---- the same from per-CHANNEL fp32 tile sums (kind 1: written by the ping-pong GEMM family's epilogue, MgldIGemm.gn_part):
+// part[frame * chunks + chunk][2][C] floats (sum row, sumsq row).  Only the groups of the caller's channel window [c_off, c_off + Cw) are
+// computed: threads run along channels (coalesced rows of part[], the chunk loads independent), the per-channel totals meet in LDS
+// (chs[2][Cw] floats, caller-provided) and one thread per group adds its cg channels in fp64.
+__device__ __forceinline__ void gn_group_stats_pc(const float* __restrict__ part, int chunks, int C, int c_off, int Cw, int rows, int cg,
+                                                  float eps, float (*st)[2], float* __restrict__ chs) {
+  const int tid = threadIdx.x;
+  for (int c = tid; c < 2 * Cw; c += 256) {
+    const int which = c >= Cw, cc = c - which * Cw;
+    const float* src = part + (int64_t)which * C + c_off + cc;
+    float a0 = 0.f, a1 = 0.f;
+    int ch = 0;
+    for (; ch + 1 < chunks; ch += 2) { a0 += src[(int64_t)ch * 2 * C]; a1 += src[(int64_t)(ch + 1) * 2 * C]; }
+    if (ch < chunks) a0 += src[(int64_t)ch * 2 * C];
+    chs[c] = a0 + a1;
+  }
+  __syncthreads();
+  const int g0 = c_off / cg;
+  for (int g = tid; g < Cw / cg; g += 256) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < cg; ++i) { s += (double)chs[g * cg + i]; q += (double)chs[Cw + g * cg + i]; }
+    const double nn = (double)rows * cg;
+    const double mean = s / nn;
+    double var = q / nn - mean * mean;
+    if (var < 0.0) var = 0.0;
+    st[g0 + g][0] = (float)mean;
+    st[g0 + g][1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+}
+
 // ---- apply: y = [silu]((x-mean)*rstd*gamma+beta) ----------------------------------------------------------------
-template <bool SPADE>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int ldx, const double* __restrict__ gsums,
+// STATS: the block also reduces ITS OUTPUT rows (the values it stores, before their rounding to fp16) to per-group (sum, sumsq) and writes them in
+// gn_partial_kernel's format with chunks = gridDim.x: the GroupNorm that reads y next (SPADE output -> the transformer's norm)
+// needs no statistics launch of its own.
+template <bool SPADE, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void gn_apply_kernel(const f16* __restrict__ x, int ldx, const void* __restrict__ sums, int kind,
                                                        int chunks, float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const f16* __restrict__ gb, int ldgb,
                                                        const f16* __restrict__ skip, int ldskip, f16* __restrict__ y, int ldy,
                                                        int rows_per_frame, int C, int groups, int silu, int Cb,
-                                                       const int* __restrict__ step_idx, int64_t gb_step_stride) {
+                                                       const int* __restrict__ step_idx, int64_t gb_step_stride,
+                                                       double* __restrict__ gout) {
   // grid (row chunks, frames).  A thread owns ONE 8-channel vector column for all its rows, so the per-channel scale /
   // shift (rstd*gamma, beta - mean*rstd*gamma) are computed once into registers and the row loop is load-fma-store.
   __shared__ float st[GN_MAX_GROUPS][2];
+  extern __shared__ float sred[];               // STATS: [rpi][Cw][2]; statistics of kind 1: [2][Cw] in the prologue
   if (SPADE && step_idx) gb += (int64_t)step_idx[0] * gb_step_stride;   // gamma/beta table hoisted out of the step (see ddpm.py)
   const int c_off = blockIdx.z * Cb;            // this block's channel window [c_off, c_off + Cb)
-  const int NV = min(Cb, C - c_off) >> 3;
+  const int Cw = min(Cb, C - c_off);
+  const int NV = Cw >> 3;
   const int cg = C / groups;
   const int frame = blockIdx.y;
-  gn_group_stats(gsums + (int64_t)frame * chunks * groups * 2, chunks, groups, rows_per_frame, cg, eps, st);
+  if (kind == 1)
+    gn_group_stats_pc((const float*)sums + (int64_t)frame * chunks * 2 * C, chunks, C, c_off, Cw, rows_per_frame, cg, eps, st, sred);
+  else
+    gn_group_stats((const double*)sums + (int64_t)frame * chunks * groups * 2, chunks, groups, rows_per_frame, cg, eps, st);
   const int rows_per_chunk = (rows_per_frame + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(rows_per_frame, r0 + rows_per_chunk);
   const int64_t fbase = (int64_t)frame * rows_per_frame;
   const int rpi = NV >= 256 ? 1 : 256 / NV;
   const int rr = NV >= 256 ? 0 : threadIdx.x / NV;
-  if (rr >= rpi) return;
+  if (!STATS && rr >= rpi) return;
+  if (rr < rpi)
   for (int v = NV >= 256 ? threadIdx.x : threadIdx.x - rr * NV; v < NV; v += 256) {
     const int c0 = c_off + v * 8;
     float sa[8], sb[8];
+    float os[8], oq[8];                          // STATS: sums of this thread's stored values
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { os[j] = 0.f; oq[j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c0 + j;
@@ -172,12 +216,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
               f = fmaxf(f, 0.f);
             }
             o[j] = (f16)f;
+            if (STATS) { os[j] += f; oq[j] += f * f; }       // (before the fp16 rounding: see pp_epilogue_stats)
           }
           *(f16x8*)(y + row * ldy + c0) = o;
         }
       }
     }
+    if (STATS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sred[((rr * Cw) + v * 8 + j) * 2] = os[j];
+        sred[((rr * Cw) + v * 8 + j) * 2 + 1] = oq[j];
+      }
+    }
     if (NV < 256) break;
+  }
+  if (STATS) {       // per channel over the row slots (fp32), per group in fp64: exactly gn_partial_kernel's reduction of the same rows
+    __syncthreads();
+    if (rpi > 1) {
+      for (int c = threadIdx.x; c < Cw; c += 256) {
+        float ss = 0.f, qq = 0.f;
+        for (int r = 0; r < rpi; ++r) { ss += sred[(r * Cw + c) * 2]; qq += sred[(r * Cw + c) * 2 + 1]; }
+        sred[c * 2] = ss; sred[c * 2 + 1] = qq;
+      }
+      __syncthreads();
+    }
+    double* go = gout + ((int64_t)(frame * gridDim.x + blockIdx.x) * groups + c_off / cg) * 2;
+    for (int g = threadIdx.x; g < Cw / cg; g += 256) {
+      double s = 0.0, q = 0.0;
+      for (int i = 0; i < cg; ++i) { s += (double)sred[(g * cg + i) * 2]; q += (double)sred[(g * cg + i) * 2 + 1]; }
+      go[g * 2] = s; go[g * 2 + 1] = q;
+    }
   }
 }
 
@@ -399,33 +468,91 @@ static dim3 apply_grid(int frames, int rows, int C, int groups, int* Cb) {
   return dim3(chunks, frames, cdiv(C, *Cb));
 }
 
-extern "C" int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta,
-                             void* y, int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
-  MGLD_REQUIRE(x && gsums && gamma && beta && y, "gn_apply: null pointer");
+// dynamic LDS of the STATS variants: [rows per pass][channel window][2] floats
+static size_t apply_stats_lds(int Cb) {
+  const int NV = Cb >> 3;
+  const int rpi = NV >= 256 ? 1 : 256 / NV;
+  return (size_t)rpi * Cb * 2 * sizeof(float);
+}
+// + the prologue's per-channel table when the input statistics are per-channel tile sums
+static size_t apply_lds(const MgldGnStats* st, int Cb, bool stats_out) {
+  const size_t a = stats_out ? apply_stats_lds(Cb) : 0, b = st->kind == MGLD_GN_CHANNEL_SUMS ? (size_t)2 * Cb * sizeof(float) : 0;
+  return a > b ? a : b;
+}
+
+static int check_stats_in(const MgldGnStats* st, int rows, int C) {
+  MGLD_REQUIRE(st && st->sums, "gn_apply: null statistics");
+  MGLD_REQUIRE(st->kind == MGLD_GN_GROUP_SUMS || st->kind == MGLD_GN_CHANNEL_SUMS, "gn_apply: statistics kind");
+  MGLD_REQUIRE(st->chunks > 0 && st->chunks <= rows, "gn_apply: statistics chunks");
+  (void)C;
+  return 0;
+}
+
+extern "C" int mgld_gn_apply_chunks(int frames, int rows_per_frame, int C, int groups) {
+  if (frames <= 0 || rows_per_frame <= 0 || C <= 0 || groups <= 0 || C % groups) return 0;
+  int Cb;
+  return (int)apply_grid(frames, rows_per_frame, C, groups, &Cb).x;
+}
+
+extern "C" int mgld_gn_apply2(const void* x, int ldx, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                              void* y, int ldy, int frames, int rows, int C, int groups, int silu, double* stats_out, void* stream) {
+  MGLD_REQUIRE(x && gamma && beta && y, "gn_apply: null pointer");
   MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS,
                "gn_apply: alignment");
+  if (int rc = check_stats_in(st, rows, C)) return rc;
   int Cb;
   const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
-  hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, gsums,
-                     mgld_gn_chunks(rows), eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb,
-                     nullptr, (int64_t)0);
+  const size_t shm = apply_lds(st, Cb, stats_out != nullptr);
+  MGLD_REQUIRE(shm <= 48 * 1024, "gn_apply: LDS budget of the statistics tables");
+  if (stats_out) {
+    hipLaunchKernelGGL((gn_apply_kernel<false, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)x, ldx, st->sums, st->kind,
+                       st->chunks, eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb, nullptr, (int64_t)0,
+                       stats_out);
+  } else {
+    hipLaunchKernelGGL((gn_apply_kernel<false, false>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)x, ldx, st->sums, st->kind,
+                       st->chunks, eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb, nullptr, (int64_t)0,
+                       nullptr);
+  }
   return mgld_check_launch("gn_apply");
+}
+
+extern "C" int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta,
+                             void* y, int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
+  const MgldGnStats st = {gsums, MGLD_GN_GROUP_SUMS, mgld_gn_chunks(rows)};
+  return mgld_gn_apply2(x, ldx, &st, eps, gamma, beta, y, ldy, frames, rows, C, groups, silu, nullptr, stream);
+}
+
+extern "C" int mgld_spade_apply2(const void* h, int ldh, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                                 const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C,
+                                 int groups, const int32_t* gb_step_idx, int64_t gb_step_stride, double* stats_out, void* stream) {
+  MGLD_REQUIRE(h && gamma && beta && gb && skip && y, "spade_apply: null pointer");
+  MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0 &&
+                   groups <= GN_MAX_GROUPS,
+               "spade_apply: alignment");
+  if (int rc = check_stats_in(st, rows, C)) return rc;
+  int Cb;
+  const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
+  const size_t shm = apply_lds(st, Cb, stats_out != nullptr);
+  MGLD_REQUIRE(shm <= 48 * 1024, "spade_apply: LDS budget of the statistics tables");
+  if (stats_out) {
+    hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)h, ldh, st->sums, st->kind,
+                       st->chunks, eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb,
+                       gb_step_idx, gb_step_stride, stats_out);
+  } else {
+    hipLaunchKernelGGL((gn_apply_kernel<true, false>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)h, ldh, st->sums, st->kind,
+                       st->chunks, eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb,
+                       gb_step_idx, gb_step_stride, nullptr);
+  }
+  return mgld_check_launch("spade_apply");
 }
 
 extern "C" int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, const float* gamma,
                                 const float* beta, const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy,
                                 int frames, int rows, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
                                 void* stream) {
-  MGLD_REQUIRE(h && gsums && gamma && beta && gb && skip && y, "spade_apply: null pointer");
-  MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0 &&
-                   groups <= GN_MAX_GROUPS,
-               "spade_apply: alignment");
-  int Cb;
-  const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
-  hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)h, ldh, gsums,
-                     mgld_gn_chunks(rows), eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy,
-                     rows, C, groups, 0, Cb, gb_step_idx, gb_step_stride);
-  return mgld_check_launch("spade_apply");
+  const MgldGnStats st = {gsums, MGLD_GN_GROUP_SUMS, mgld_gn_chunks(rows)};
+  return mgld_spade_apply2(h, ldh, &st, eps, gamma, beta, gb, ldgb, skip, ldskip, y, ldy, frames, rows, C, groups, gb_step_idx,
+                           gb_step_stride, nullptr, stream);
 }
 
 // window of the single-launch GroupNorm: the smallest whole-group, multiple-of-8 channel window; 0 = shape not covered

@@ -144,4 +144,123 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
   }
 }
 
+// ---- the same epilogue + per-channel (sum, sumsq) of the output values (GroupNorm statistics of the output, MgldIGemm.gn_part) ----
+// For tiles whose rows lie in ONE frame (`fr`, -1 without a row vector).  Fragment pairs outermost: 16 running sums per lane and pair, reduced
+// over the 16 rows of a lane row by DPP adds (quad xor 1, xor 2, half-row mirror, row mirror), then written by lane row heads to this wave's
+// slot of the block's LDS table: wave_sums[channel of the wave tile][2].  The caller adds the wave rows up (pp_stats_flush).
+__device__ __forceinline__ float pp_row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1, 0, 3, 2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2, 3, 0, 1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+#endif
+  return v;
+}
+
+template <int MI, int NI, typename RowFn>
+__device__ __forceinline__ void pp_epilogue_stats(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const int fr,
+                                                  const RowFn row_of, float* __restrict__ wave_sums) {
+  const int q = lane >> 4, l15 = lane & 15;
+  const float alpha = e.alpha;
+  f32x4 cv[NI];
+#pragma unroll
+  for (int f = 0; f < NI; ++f) {
+    cv[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e.bias) cv[f] = *(const f32x4*)(e.bias + n0 + f * 16 + 4 * q);
+  }
+  if (fr >= 0) {
+    const float* rv = e.rowvec + (int64_t)fr * e.ld_rowvec + n0 + 4 * q;
+#pragma unroll
+    for (int f = 0; f < NI; ++f) cv[f] += *(const f32x4*)(rv + f * 16);
+  }
+  auto out_frag = [&](const int f, const int mi) -> f32x4 {
+    f32x4 v = acc[f][mi] + cv[f];
+    if (e.act == MGLD_ACT_SILU) {
+      const e2 s0 = silu2(pk(v[0], v[1])), s1 = silu2(pk(v[2], v[3]));
+      v = f32x4{s0[0], s0[1], s1[0], s1[1]};
+    }
+    return v * alpha;
+  };
+#pragma unroll
+  for (int pr = 0; pr < NI / 2; ++pr) {
+    e2 ss[4], qq[4];                                             // packed fp32 pairs: v_pk_add_f32 / v_pk_fma_f32
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ss[r] = pk(0.f, 0.f); qq[r] = pk(0.f, 0.f); }
+    const int nl = (2 * pr + (q & 1)) * 16 + (q >> 1) * 8;       // this lane's 8 channels of the wave tile after the swap
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = row_of(mi);
+      f32x4 a = out_frag(2 * pr, mi), b = out_frag(2 * pr + 1, mi);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+        a[r] = __uint_as_float(s[0]); b[r] = __uint_as_float(s[1]);
+      }
+      if (m < 0) continue;
+      if (e.R) {
+        const f16x8 rr = *(const f16x8*)(e.R + (int64_t)m * e.ldr + n0 + nl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] += e.beta * (float)rr[r]; b[r] += e.beta * (float)rr[4 + r]; }
+      }
+      const f16x8 o = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
+      *(f16x8*)(e.C + (int64_t)m * e.ldc + n0 + nl) = o;
+      // (sums of the fp32 values before their rounding to fp16: the zero-mean rounding noise moves mean and variance of >= 10^4 elements
+      //  by ~1e-7 relative — the conversions back would cost a third of this block's arithmetic)
+      const e2 v[4] = {pk(a[0], a[1]), pk(a[2], a[3]), pk(b[0], b[1]), pk(b[2], b[3])};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ss[r] += v[r]; qq[r] += v[r] * v[r]; }
+    }
+    float s1[8], q1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { s1[r] = pp_row16_sum(ss[r >> 1][r & 1]); q1[r] = pp_row16_sum(qq[r >> 1][r & 1]); }
+    if (l15 == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) *(f32x4*)(wave_sums + (nl + r) * 2) = f32x4{s1[r], q1[r], s1[r + 1], q1[r + 1]};
+    }
+  }
+  if constexpr (NI & 1) {                                      // unpaired last fragment: 4 channels per lane
+    constexpr int f = NI - 1;
+    float ss[4], qq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ss[r] = 0.f; qq[r] = 0.f; }
+    const int nl = f * 16 + 4 * q;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = row_of(mi);
+      f32x4 a = out_frag(f, mi);
+      if (m < 0) continue;
+      if (e.R) {
+        const f16x4 rr = *(const f16x4*)(e.R + (int64_t)m * e.ldr + n0 + nl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += e.beta * (float)rr[r];
+      }
+      const f16x4 o = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+      *(f16x4*)(e.C + (int64_t)m * e.ldc + n0 + nl) = o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ss[r] += a[r]; qq[r] += a[r] * a[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ss[r] = pp_row16_sum(ss[r]); qq[r] = pp_row16_sum(qq[r]); }
+    if (l15 == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { wave_sums[(nl + r) * 2] = ss[r]; wave_sums[(nl + r) * 2 + 1] = qq[r]; }
+    }
+  }
+}
+
+// block table [WGM wave rows][BN][2] in LDS -> part[tile][2][N] (after a block barrier; all 512 threads call)
+template <int WGM, int BN>
+__device__ __forceinline__ void pp_stats_flush(const float* __restrict__ table, float* __restrict__ part, const int64_t tile, const int N,
+                                               const int bn0, const int tid) {
+  for (int i = tid; i < BN; i += 512) {
+    if (bn0 + i >= N) break;
+    float s = 0.f, qv = 0.f;
+#pragma unroll
+    for (int w = 0; w < WGM; ++w) { s += table[(w * BN + i) * 2]; qv += table[(w * BN + i) * 2 + 1]; }
+    part[(tile * 2) * N + bn0 + i] = s;
+    part[(tile * 2 + 1) * N + bn0 + i] = qv;
+  }
+}
+
 }  // namespace

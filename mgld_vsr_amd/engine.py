@@ -133,11 +133,15 @@ def w2_scopes():
 # ------------------------------------------------------------------------------------------------------------------
 class Act:
     """Token-major (NHWC) activation: `v` is a 2-D fp16 view [n*h*w, C] with row stride ld >= C."""
-    __slots__ = ("v", "n", "h", "w")
+    __slots__ = ("v", "n", "h", "w", "stats")
 
     def __init__(self, v, n, h, w):
         assert v.dim() == 2 and v.shape[0] == n * h * w, (v.shape, n, h, w)
         self.v, self.n, self.h, self.w = v, n, h, w
+        # GroupNorm statistics of THIS tensor written by the kernel that produced it (Engine.conv3x3(stats=True), spade_apply(want_stats=True)):
+        # (sums tensor, hip.GN_* kind, chunks per frame, groups or None); Engine.gn_stats() then launches nothing.  Any op that writes into
+        # an existing Act (`out=`) clears it first.
+        self.stats = None
 
     @property
     def C(self):
@@ -250,6 +254,7 @@ class Engine:
 
     GROUPS = 32
     GN_FUSED = os.environ.get("MGLD_GN_FUSED", "1") != "0"    # single-launch GroupNorm for frames of <= 256 rows
+    GN_PRODUCER = os.environ.get("MGLD_GN_PRODUCER", "1") != "0"   # GroupNorm statistics written by the kernel that produces the tensor
 
     def __init__(self, device="cuda", chunk_bytes=1 << 30, workspace_bytes=256 << 20):
         hip.lib()  # fail loudly if the HIP library is missing
@@ -260,6 +265,7 @@ class Engine:
         self._wcache = {}
         self._c3p_geo, self._c3p_w = {}, {}     # patch-conv applicability per geometry / tiled weights per packed tensor
         self.launches = 0
+        self.gn_stats_saved = 0   # GroupNorm statistics launches that a producer's epilogue replaced
         self.shard = None   # parallel.FrameShard when the frames of one segment are split over ranks
         self.tile_shard = None   # parallel.TileShard when the latent tiles of aggregation sampling are split over ranks
         self.pieces = None       # GraphPieces while a sharded step is recorded / replayed as hipGraph pieces
@@ -349,7 +355,9 @@ class Engine:
 
     # ---- ops ----
     def conv3x3(self, x, wp, bias, cout, out=None, stride=1, pad=(1, 1), up2=False, hw_out=None, rowvec=None,
-                rows_per_frame=0, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, w2=None):
+                rows_per_frame=0, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, w2=None, stats=False):
+        """stats: the output feeds a GroupNorm over all of its channels — where the kernel the launcher picks can, it also writes the
+        per-tile channel sums of what it stores (MgldIGemm.gn_part) and the returned Act carries them (Act.stats)."""
         hin, win = x.h, x.w
         if hw_out is None:
             hv, wv = (2 * hin, 2 * win) if up2 else (hin, win)
@@ -370,9 +378,18 @@ class Engine:
                 w2t = None if w2 is None else self._conv3p_tiled(w2, x.n, cin, cout, hin, win, tap_inner, up2)
                 if w2 is None or w2t is not None:
                     wp, w2, tap_inner, kw = wt, w2t, 2, dict(N=cout, K=9 * cin)
+        out.stats = None
+        got = []
+        if stats and self.GN_PRODUCER and out.v.dtype == torch.float16 and not (self.GN_FUSED and hip.gn_fused_applies(ho * wo, cout, self.GROUPS)):
+            def part(chunks):
+                got.append((self.arena.alloc((x.n * chunks, 2, cout), torch.float32), hip.GN_CHANNEL_SUMS, chunks, None))
+                return got[0][0]
+            kw["gn_part"] = part
         hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec, w2=w2,
                   rows_per_frame=rows_per_frame or ho * wo, resid=None if resid is None else resid.v, act=act, alpha=alpha,
                   beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0), tap_inner=tap_inner, **kw)
+        if got:
+            out.stats = got[0]
         self.launches += 1
         return out
 
@@ -403,6 +420,7 @@ class Engine:
         if out is None:
             out = Act(self.arena.alloc((x.n * ho * wo, cout), out_dtype), x.n, ho, wo)
         cin = x.C
+        out.stats = None
         assert wp.shape[1] == kh * kw * cin, (wp.shape, kh, kw, cin)
         hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, act=act, alpha=alpha, N=cout,
                   conv=(cin, x.h, x.w, ho, wo, stride, pad[0], pad[1], 0), ksize=(kh, kw))
@@ -418,6 +436,8 @@ class Engine:
             ov = self.arena.alloc((xv.shape[0], N), out_dtype)
             out = Act(ov, x.n, x.h, x.w) if isinstance(x, Act) else ov
         ov = out.v if isinstance(out, Act) else out
+        if isinstance(out, Act):
+            out.stats = None
         rv = resid.v if isinstance(resid, Act) else resid
         hip.igemm(xv, w, ov, bias=bias, resid=rv, act=act, alpha=alpha, beta=beta, M=xv.shape[0], N=w.shape[0], K=w.shape[1], w2=w2)
         self.launches += 1
@@ -427,6 +447,7 @@ class Engine:
         """SpatialTemporalConv: out = a*(conv3d_t(x)+b) + (1-a)*x."""
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C)
+        out.stats = None
         sh = self.shard
         if sh is None:
             hip.igemm(x.v, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
@@ -454,36 +475,51 @@ class Engine:
         as ONE launch (mgld_gn_fused), so nothing is computed here."""
         g = groups or self.GROUPS
         if self.GN_FUSED and hip.gn_fused_applies(x.hw, x.C, g):
-            return None, float(eps)
+            return None, float(eps), 0, 0
+        st = x.stats
+        if st is not None and (st[3] is None or st[3] == g):       # written by the producer of x: nothing to launch
+            self.gn_stats_saved += 1
+            return st[0], float(eps), st[1], st[2]
         gsums = self.arena.alloc((x.n, hip.gn_chunks(x.hw), g, 2), torch.float64)
         hip.gn_stats(x.v, x.n, x.hw, g, gsums)
         self.launches += 1
-        return gsums, float(eps)
+        return gsums, float(eps), hip.GN_GROUP_SUMS, 0
 
     def gn_apply(self, x, stats, gamma, beta, silu, out=None, groups=None):
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C)
-        gsums, eps = stats
+        out.stats = None
+        gsums, eps, kind, chunks = stats
         if gsums is None:
             hip.gn_fused(x.v, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
         else:
-            hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
+            hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, kind=kind, chunks=chunks)
         self.launches += 1
         return out
 
     def groupnorm(self, x, gamma, beta, eps, silu, out=None):
         return self.gn_apply(x, self.gn_stats(x, eps), gamma, beta, silu, out)
 
-    def spade_apply(self, h, stats, gamma, beta, gb, skip, out=None, step_idx=None, step_stride=0):
+    def spade_apply(self, h, stats, gamma, beta, gb, skip, out=None, step_idx=None, step_stride=0, want_stats=False):
+        """want_stats: the output feeds a GroupNorm (the transformer's norm after a ResBlockDual): the apply kernel also reduces what it
+        stores, and the returned Act carries the sums (Act.stats)"""
         if out is None:
             out = self.act(h.n, h.h, h.w, h.C)
-        gsums, eps = stats
+        out.stats = None
+        gsums, eps, kind, chunks = stats
         gbv = gb.v if isinstance(gb, Act) else gb
         if gsums is None:
             hip.gn_fused(h.v, eps, gamma, beta, out.v, h.n, h.hw, self.GROUPS, 0, gb=gbv, skip=skip.v, step_idx=step_idx,
                          step_stride=step_stride)
         else:
-            hip.spade_apply(h.v, gsums, eps, gamma, beta, gbv, skip.v, out.v, h.n, h.hw, self.GROUPS, step_idx, step_stride)
+            so = None
+            if want_stats and self.GN_PRODUCER:
+                oc = hip.gn_apply_chunks(h.n, h.hw, h.C, self.GROUPS)
+                so = self.arena.alloc((h.n, oc, self.GROUPS, 2), torch.float64)
+            hip.spade_apply(h.v, gsums, eps, gamma, beta, gbv, skip.v, out.v, h.n, h.hw, self.GROUPS, step_idx, step_stride, kind=kind,
+                            chunks=chunks, stats_out=so)
+            if so is not None:
+                out.stats = (so, hip.GN_GROUP_SUMS, oc, self.GROUPS)
         self.launches += 1
         return out
 

@@ -33,7 +33,7 @@ class MgldIGemm(C.Structure):
         ("batch", C.c_int32), ("tap_inner", C.c_int32),
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
         ("t_off", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("tune", C.c_int32),
-        ("w2_scale", C.c_float), ("W2", C.c_void_p),
+        ("w2_scale", C.c_float), ("W2", C.c_void_p), ("gn_part", C.c_void_p),
     ]
 
 
@@ -54,7 +54,8 @@ EXPORTS = [
     "mgld_version", "mgld_last_error", "mgld_device_info",
     "mgld_graph_begin", "mgld_graph_end", "mgld_graph_launch", "mgld_graph_destroy",
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
-    "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply", "mgld_gn_fused_applies", "mgld_gn_fused", "mgld_layernorm",
+    "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_igemm_gn_chunks", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply",
+    "mgld_gn_apply_chunks", "mgld_gn_apply2", "mgld_spade_apply2", "mgld_gn_fused_applies", "mgld_gn_fused", "mgld_layernorm",
     "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
     "mgld_linear_small", "mgld_timestep_embedding",
     "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
@@ -120,7 +121,7 @@ W2_SCALE = 2.0 ** -11     # scale of the weight-residual matrices (MgldIGemm.W2)
 
 def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None,
           act=ACT_NONE, alpha=1.0, beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0,
-          M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0, w2=None, w2_scale=W2_SCALE):
+          M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0, w2=None, w2_scale=W2_SCALE, gn_part=None):
     """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h).
     w2: the scaled fp16 rounding residual of the weights (same layout as w; engine.split_residual): the product then uses weights
     exact to ~2^-21 at twice the MFMA work."""
@@ -158,6 +159,14 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
         p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = conv
     elif mode == MODE_TCONV3:
         p.Cin, p.T, p.HW = tconv
+    if gn_part is not None:
+        # gn_part(chunks) -> float32 device tensor [frames * chunks, 2, N] (called only when the kernel picked for this problem writes
+        # the statistics of its output: chunks = mgld_igemm_gn_chunks > 0); the caller keeps what it returned
+        chunks = lib().mgld_igemm_gn_chunks(C.byref(p))
+        if chunks > 0:
+            t = gn_part(chunks)
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+            p.gn_part = t.data_ptr()
     if IGEMM_LOG is not None:
         IGEMM_LOG.append(MgldIGemm.from_buffer_copy(p))
     if TIMED is not None:
@@ -258,22 +267,46 @@ def gn_stats(x, frames, rows, groups, gsums):
     return gsums
 
 
-def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu):
+class MgldGnStats(C.Structure):
+    """include/mgld_hip.h: where a GroupNorm consumer finds the statistics of its input"""
+    _fields_ = [("sums", C.c_void_p), ("kind", C.c_int), ("chunks", C.c_int)]
+
+
+GN_GROUP_SUMS, GN_CHANNEL_SUMS = 0, 1
+
+
+def _gn_src(sums, kind, chunks, rows):
+    st = MgldGnStats()
+    st.sums, st.kind, st.chunks = sums.data_ptr(), int(kind), int(chunks if chunks else gn_chunks(rows))
+    return st
+
+
+def gn_apply_chunks(frames, rows, channels, groups):
+    """row chunks per frame of the apply kernels' grid = the chunk count of their stats_out"""
+    return lib().mgld_gn_apply_chunks(int(frames), int(rows), int(channels), int(groups))
+
+
+def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu, kind=GN_GROUP_SUMS, chunks=0, stats_out=None):
+    """kind / chunks: format of `gsums` (default: mgld_gn_stats' output); stats_out: float64 [frames, gn_apply_chunks, groups, 2] that
+    receives the per-group sums of y"""
     _req_cuda(x, gsums, gamma, beta, y)
+    st = _gn_src(gsums, kind, chunks, rows)
     with timed("gn_apply", {"bytes": 4.0 * frames * rows * x.shape[1]}):
-        _chk(lib().mgld_gn_apply(_p(x), _ld(x), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), _p(y), _ld(y), frames, rows,
-                                 x.shape[1], groups, int(silu), stream_ptr()), "gn_apply")
+        _chk(lib().mgld_gn_apply2(_p(x), _ld(x), C.byref(st), C.c_float(eps), _p(gamma), _p(beta), _p(y), _ld(y), frames, rows,
+                                  x.shape[1], groups, int(silu), _p(stats_out), stream_ptr()), "gn_apply")
     return y
 
 
-def spade_apply(h, gsums, eps, gamma, beta, gb, skip, y, frames, rows, groups, step_idx=None, step_stride=0):
+def spade_apply(h, gsums, eps, gamma, beta, gb, skip, y, frames, rows, groups, step_idx=None, step_stride=0, kind=GN_GROUP_SUMS, chunks=0,
+                stats_out=None):
     """gb: [frames*rows, 2C] modulation, or (step_idx given) the first slice of a per-step table with `step_stride` elements
-    between consecutive steps"""
+    between consecutive steps.  kind / chunks / stats_out as in gn_apply."""
     _req_cuda(h, gsums, gamma, beta, gb, skip, y)
+    st = _gn_src(gsums, kind, chunks, rows)
     with timed("spade_apply", {"bytes": 10.0 * frames * rows * h.shape[1]}):
-        _chk(lib().mgld_spade_apply(_p(h), _ld(h), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip),
-                                    _ld(skip), _p(y), _ld(y), frames, rows, h.shape[1], groups, _p(step_idx), C.c_int64(step_stride),
-                                    stream_ptr()), "spade_apply")
+        _chk(lib().mgld_spade_apply2(_p(h), _ld(h), C.byref(st), C.c_float(eps), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip),
+                                     _ld(skip), _p(y), _ld(y), frames, rows, h.shape[1], groups, _p(step_idx), C.c_int64(step_stride),
+                                     _p(stats_out), stream_ptr()), "spade_apply")
     return y
 
 

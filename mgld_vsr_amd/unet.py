@@ -110,7 +110,7 @@ class ResBlock(nn.Module):
         t = eng.groupnorm(x, eng.f32("g", gn1.weight), eng.f32("b", gn1.bias), gn1.eps, True)
         rv = emb_all[:, self.emb_slot:self.emb_slot + self.out_channels]
         h = eng.conv3x3(t, eng.weight("c3", (conv1.weight,), pack_conv3x3), eng.f32("b", conv1.bias), self.out_channels,
-                        rowvec=rv, rows_per_frame=emb_rpf)
+                        rowvec=rv, rows_per_frame=emb_rpf, stats=True)      # feeds gn2: statistics from the convolution's epilogue
         gn2 = self.out_layers[0]
         return eng.groupnorm(h, eng.f32("g", gn2.weight), eng.f32("b", gn2.bias), gn2.eps, True)
 
@@ -132,7 +132,7 @@ class ResBlockDual(ResBlock):
     def run(self, eng, x, emb_all, emb_rpf, struct_cond, out=None):
         t = self._trunk(eng, x, emb_all, emb_rpf)
         conv2 = self.out_layers[3]
-        h = eng.conv3x3(t, eng.weight("c3", (conv2.weight,), pack_conv3x3), eng.f32("b", conv2.bias), self.out_channels)
+        h = eng.conv3x3(t, eng.weight("c3", (conv2.weight,), pack_conv3x3), eng.f32("b", conv2.bias), self.out_channels, stats=True)
         sp = self.spade
         self._sc_key = str(h.w)                      # which struct-cond scale this block reads (recorded for the hoisting pass)
         stats = eng.gn_stats(h, sp.param_free_norm.eps)
@@ -141,9 +141,9 @@ class ResBlockDual(ResBlock):
         hoisted = struct_cond.get("__spade__", {}).get(id(self)) if isinstance(struct_cond, dict) else None
         if hoisted is not None:                       # gamma/beta of every step precomputed (ddpm._precompute_spade)
             table, stride, step_idx = hoisted
-            return eng.spade_apply(h, stats, g, b, table[0], skip, out=out, step_idx=step_idx, step_stride=stride)
+            return eng.spade_apply(h, stats, g, b, table[0], skip, out=out, step_idx=step_idx, step_stride=stride, want_stats=True)
         gb = self.spade_modulation(eng, struct_cond[self._sc_key])
-        return eng.spade_apply(h, stats, g, b, gb, skip, out=out)
+        return eng.spade_apply(h, stats, g, b, gb, skip, out=out, want_stats=True)   # the transformer's norm reads this next
 
     def spade_modulation(self, eng, seg):
         """[gamma | beta] = conv(relu(conv(seg))) (spade.py:93-104): a function of the struct-cond features only"""

@@ -74,9 +74,9 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
 
     def run(self, eng, x, out=None):
-        h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True))
+        h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True), stats=True)          # norm2 reads the epilogue's statistics
         skip = x if self.in_channels == self.out_channels else _conv1(eng, self.nin_shortcut, x)
-        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip)
+        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip, stats=True)   # the next block's norm likewise
 
 
 class AttnBlock(nn.Module):
@@ -232,9 +232,9 @@ class ResBlock(nn.Module):
             self.conv_out = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
 
     def run(self, eng, x, out=None, resid_extra=None):
-        h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True))
+        h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True), stats=True)          # norm2 reads the epilogue's statistics
         skip = x if self.in_channels == self.out_channels else _conv1(eng, self.conv_out, x)
-        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip)
+        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip, stats=True)   # the next block's norm likewise
 
 
 class ResidualDenseBlock(nn.Module):

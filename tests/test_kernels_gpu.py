@@ -495,6 +495,54 @@ def test_igemm_conv3x3_pingpong_w2(hip, cfg, n, cin, nt, h, w):
     assert rel_l2(outs[1], outs[2]) < 2e-4
 
 
+@pytest.mark.parametrize("cfg,n,cin,nt,h,w,epi", [(0, 2, 64, 2, 16, 32, 2), (8, 2, 128, 5, 32, 64, 1), (2, 3, 32, 1, 24, 40, 0), (6, 2, 64, 4, 20, 36, 2),
+                                                  (3, 1, 64, 1, 16, 64, 0), (5, 2, 32, 2, 8, 16, 1), (7, 2, 32, 4, 16, 40, 2), (1, 2, 32, 1, 16, 24, 0)])
+def test_igemm_conv3x3_pingpong_gn_stats(hip, cfg, n, cin, nt, h, w, epi):
+    """conv3r with MgldIGemm.gn_part: same output bits as without; the per-tile channel sums add up to the moments of the stored
+    output (ragged tiles included; sums are taken before the fp16 rounding); GroupNorm fed by them (mgld_gn_apply2, MGLD_GN_CHANNEL_SUMS) agrees with the mgld_gn_stats path"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    cout = nt * R3_BN[cfg]
+    x = h16(rnd(n, cin, h, w, seed=300))
+    wt = h16(rnd(cout, cin, 3, 3, seed=301, scale=(9 * cin) ** -0.5))
+    wk = tile_conv3p(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV), cin, False)
+    xt = _to_tok(x).to(DEV)
+    kw = dict(bias=(rnd(cout, seed=302) + 0.5).to(DEV))
+    if epi == 1:
+        kw.update(resid=h16(rnd(n * h * w, cout, seed=303)).to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+    elif epi == 2:
+        kw.update(rowvec=rnd(n, cout, seed=304).to(DEV), rows_per_frame=h * w)
+    common = dict(mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=2, N=cout, K=9 * cin, tune=31 + cfg, **kw)
+    plain = torch.empty(n * h * w, cout, dtype=torch.half, device=DEV)
+    hip.igemm(xt, wk, plain, **common)
+    got = []
+
+    def part(chunks):
+        got.append((torch.full((n * chunks, 2, cout), float("nan"), dtype=torch.float32, device=DEV), chunks))
+        return got[0][0]
+    out = torch.empty_like(plain)
+    hip.igemm(xt, wk, out, gn_part=part, **common)
+    torch.cuda.synchronize()
+    assert got, "the ping-pong patch convolution must offer the statistics output"
+    pt, chunks = got[0]
+    assert torch.equal(out, plain)
+    o = out.double().reshape(n, h * w, cout)
+    tot = pt.double().reshape(n, chunks, 2, cout).sum(1)
+    assert torch.isfinite(pt).all()
+    # (sums are taken before the fp16 rounding: the first moment is compared on the scale of the rms, not of the — possibly ~0 — mean)
+    rms = ((o * o).sum(1) / (h * w)).sqrt()
+    assert (((tot[:, 0] - o.sum(1)) / (h * w)).abs() / rms).max() < 1e-4 and rel_l2(tot[:, 1], (o * o).sum(1)) < 1e-4
+    if cout % 32 == 0:
+        rows = h * w
+        gamma, beta = (1 + 0.1 * rnd(cout, seed=305)).to(DEV), (0.1 * rnd(cout, seed=306)).to(DEV)
+        gs = torch.empty(n, hip.gn_chunks(rows), 32, 2, dtype=torch.float64, device=DEV)
+        hip.gn_stats(out, n, rows, 32, gs)
+        y0, y1 = torch.empty_like(out), torch.empty_like(out)
+        hip.gn_apply(out, gs, 1e-5, gamma, beta, y0, n, rows, 32, True)
+        hip.gn_apply(out, pt, 1e-5, gamma, beta, y1, n, rows, 32, True, kind=hip.GN_CHANNEL_SUMS, chunks=chunks)
+        torch.cuda.synchronize()
+        assert rel_l2(y1.float(), y0.float()) < 1e-4
+
+
 def test_igemm_conv3x3_pingpong_race_screen(hip):
     """counted waits of the weight ring / patch double buffer: repeated launches of a deep-K problem give the same bits on every
     configuration, and those bits agree with conv3q's (same products, another summation order) to the fp16 output rounding"""
@@ -801,6 +849,45 @@ def test_spade_apply(hip):
     ref = _from_tok(skip.float(), frames, h, w) + hn * (1 + _from_tok(gb.float()[:, :C], frames, h, w)) + _from_tok(
         gb.float()[:, C:], frames, h, w)
     assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
+
+
+@pytest.mark.parametrize("frames,C,h,w", [(2, 320, 64, 64), (3, 640, 32, 32), (1, 2560, 20, 24), (2, 128, 48, 40), (2, 960, 17, 23)])
+def test_groupnorm_stats_of_output(hip, frames, C, h, w):
+    """mgld_spade_apply2 / mgld_gn_apply2 with stats_out: the output bits do not change, the per-group chunk sums add up to the moments of
+    the stored output, and a GroupNorm fed by them agrees with one fed by mgld_gn_stats on that output"""
+    rows = h * w
+    hh, skip = h16(rnd(frames * rows, C, seed=310) + 0.2).to(DEV), h16(rnd(frames * rows, C, seed=311)).to(DEV)
+    gb = h16(rnd(frames * rows, 2 * C, seed=312, scale=0.5)).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd(C, seed=313)).to(DEV), (0.1 * rnd(C, seed=314)).to(DEV)
+    gs = torch.empty(frames, hip.gn_chunks(rows), 32, 2, dtype=torch.float64, device=DEV)
+    hip.gn_stats(hh, frames, rows, 32, gs)
+    oc = hip.gn_apply_chunks(frames, rows, C, 32)
+    assert oc > 0
+    for spade in (True, False):
+        y0, y1 = torch.empty_like(hh), torch.empty_like(hh)
+        so = torch.full((frames, oc, 32, 2), float("nan"), dtype=torch.float64, device=DEV)
+        if spade:
+            hip.spade_apply(hh, gs, 1e-5, gamma, beta, gb, skip, y0, frames, rows, 32)
+            hip.spade_apply(hh, gs, 1e-5, gamma, beta, gb, skip, y1, frames, rows, 32, stats_out=so)
+        else:
+            hip.gn_apply(hh, gs, 1e-5, gamma, beta, y0, frames, rows, 32, True)
+            hip.gn_apply(hh, gs, 1e-5, gamma, beta, y1, frames, rows, 32, True, stats_out=so)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+        yg = y1.double().reshape(frames, rows, 32, C // 32)
+        tot = so.sum(1)
+        assert torch.isfinite(so).all()
+        # (sums are taken before the fp16 rounding: the first moment is compared on the scale of the rms, not of the — possibly ~0 — mean)
+        nel = rows * (C // 32)
+        rms = ((yg * yg).sum((1, 3)) / nel).sqrt()
+        assert (((tot[:, :, 0] - yg.sum((1, 3))) / nel).abs() / rms).max() < 2e-5 and rel_l2(tot[:, :, 1], (yg * yg).sum((1, 3))) < 1e-4
+        gs2 = torch.empty_like(gs)
+        hip.gn_stats(y1, frames, rows, 32, gs2)
+        z0, z1 = torch.empty_like(hh), torch.empty_like(hh)
+        hip.gn_apply(y1, gs2, 1e-5, gamma, beta, z0, frames, rows, 32, False)
+        hip.gn_apply(y1, so, 1e-5, gamma, beta, z1, frames, rows, 32, False, kind=hip.GN_GROUP_SUMS, chunks=oc)
+        torch.cuda.synchronize()
+        assert rel_l2(z1.float(), z0.float()) < 1e-4
 
 
 @pytest.mark.parametrize("frames,C,h,w,silu", [(2, 1280, 16, 16, 1), (3, 1920, 8, 8, 1), (2, 2560, 16, 16, 1), (1, 320, 16, 16, 0),

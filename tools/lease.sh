@@ -48,5 +48,11 @@ case "$recipe" in
     timeout 1200 python bench.py "$@" 2> gpurun_out/bench_$tag.err | tail -1 > gpurun_out/bench_$tag.json
     cut -c1-600 gpurun_out/bench_$tag.json
     ;;
+  prof)       # rocprofv3 --kernel-trace --stats of the default bench workload -> gpurun_out/kernel_stats.txt (+ .json)
+    bash tools/prof_run.sh
+    ;;
+  pmc)        # HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes) -> gpurun_out/pmc_traffic.json
+    bash tools/pmc_traffic.sh
+    ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac

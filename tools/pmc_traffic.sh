@@ -1,8 +1,8 @@
 # HBM traffic per launch of every GEMM-family / attention kernel (roofline.traffic): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
 # SEPARATE passes (counter collection only, no trace domains) over one eager segment of the default bench workload.
 # Writes gpurun_out/pmc_traffic.json keyed by the exact kernel instantiation name + the sha256 of the GEMM family's sources
-# (csrc/igemm_common.h + igemm.hip + conv3q.hip + attention.hip) it was taken on (bench.py uses an entry only when both match the running build);
-# copy it to profiles/r03_pmc_traffic.json.
+# (bench.py: GEMM_FAMILY_SOURCES) it was taken on (bench.py uses an entry only when both match the running build);
+# copy it to profiles/r04_pmc_traffic.json.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export MGLD_SC_PRECOMPUTE=0   # rocprofv3 --pmc segfaults inside its launch hook on the batched struct-cond passes (round 1); per-launch
@@ -20,7 +20,7 @@ def per_kernel(counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"((?:igemm|conv3p|conv3q|flash_attn|splitk_reduce|gn_\w+|layernorm)_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
+            m = re.search(r"((?:igemm|conv3p|conv3q|conv3r|ppgemm|pptconv|flash_attn|splitk_reduce|gn_\w+|layernorm)_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
             if not m:
                 continue
             tot[m.group(1)][0] += 1
@@ -32,7 +32,9 @@ for k, (n, f) in fe.items():
     w = wr.get(k, [0, 0.0])[1]
     kern[k] = {"launches": n, "fetch_size_kb_per_launch": f / n, "write_size_kb_per_launch": w / n,
                "hbm_bytes_per_launch": (2.0 * f + w) / n * 1024.0}
-sha = hashlib.sha256(b"".join(open("mgld_vsr_amd/csrc/" + f, "rb").read() for f in ("igemm_common.h", "igemm.hip", "conv3q.hip", "attention.hip"))).hexdigest()[:16]
+import sys; sys.path.insert(0, ".")
+from bench import GEMM_FAMILY_SOURCES
+sha = hashlib.sha256(b"".join(open("mgld_vsr_amd/csrc/" + f, "rb").read() for f in GEMM_FAMILY_SOURCES)).hexdigest()[:16]
 res = {"gemm_src_sha16": sha, "kernels": kern,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `MGLD_SC_PRECOMPUTE=0 bench.py --steps 1 --warmup 0 --no-graph` "
                "(one 8x512^2 50-step segment, eager launches); counters in KB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "

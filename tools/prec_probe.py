@@ -57,7 +57,8 @@ def main():
         torch.cuda.synchronize()
         r = {"latent": rel_l2(lat, g["x0"]), "frames": rel_l2(out[:, :, ::st, ::st], g["out_s"]),
              "frames_w05": rel_l2(out05[:, :, ::st, ::st], g["out_w05_s"]), "decoder_only": rel_l2(dec[:, :, ::st, ::st], g["dec_s"]),
-             "segment_ms": ev[0].elapsed_time(ev[1]), "encode_ms": ev[1].elapsed_time(ev[2]), "decode_ms": ev[2].elapsed_time(ev[3])}
+             "segment_ms": ev[0].elapsed_time(ev[1]), "encode_ms": ev[1].elapsed_time(ev[2]), "decode_ms": ev[2].elapsed_time(ev[3]),
+             "launches_per_step": getattr(m, "last_launches_per_step", None), "gn_stats_saved": m.engine().gn_stats_saved}
         res[setting] = r
         print(setting, json.dumps(r), flush=True)
         del pipe, vq, m, out, lat, dec, dec05, out05, fea
