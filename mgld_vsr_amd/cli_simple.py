@@ -29,6 +29,7 @@ REF_VQGAN_CKPT = "models/ldm/stable-diffusion-v1/epoch=000011.ckpt"
 
 NOISE_HOOK = None     # tests: NOISE_HOOK(T, h, w, steps) -> {"posterior", "x_T", "steps"}
 CAPTURE = None        # tests: list receiving {"flows", "masks", "x0"} per segment
+FLOW_HOOK = None      # tests: FLOW_HOOK(flows, masks) -> (flows, masks) the sampler gets instead (CAPTURE keeps this build's as own_*)
 
 
 def load_img(path):
@@ -135,8 +136,11 @@ def main(argv=None, w_latent=False):
         fwd, bwd = (f1, f0) if w_latent else (f0, f1)                                  # (:354) vs w_latent (:360)
         fo, bo = forward_backward_consistency_check(fwd, bwd)
         flows, masks = (f0[None], f1[None]), (fo[None, :, None], bo[None, :, None])
+        own = (flows, masks)
+        if FLOW_HOOK is not None:
+            flows, masks = FLOW_HOOK(flows, masks)
         out, lat = pp.run_segment(x, flows=flows, masks=masks, guidance_scale=gscale, noise=nz, return_latents=True, init_from_vq=True)
-        cap = {"flows": flows, "masks": masks, "x0": lat, "frames": x} if CAPTURE is not None else None
+        cap = {"flows": flows, "masks": masks, "x0": lat, "frames": x, "own_flows": own[0], "own_masks": own[1]} if CAPTURE is not None else None
         arrs = preproc.to_png_payload(out, opt.input_size, opt.input_size)
         return arrs, (lat.cpu().numpy() if w_latent else None), cap
 

@@ -106,9 +106,12 @@ def parse(argv=None):
 
 
 # test hooks (tests/test_cli_gpu.py): NOISE_HOOK(T, h, w, steps) -> the noise dict run_segment takes (the parity test replays the
-# draws of a captured reference run); CAPTURE: a list that receives, per sampled patch, its flows / masks / sampled latents
+# draws of a captured reference run); CAPTURE: a list that receives, per sampled patch, its flows / masks / sampled latents;
+# FLOW_HOOK(patch index, flows, masks) -> (flows, masks) the sampler gets instead (the production-schedule parity test hands one patch
+# the reference run's flows, to separate the sampler's deviation from what RAFT's fp16 flows add)
 NOISE_HOOK = None
 CAPTURE = None
+FLOW_HOOK = None
 
 
 def main(argv=None):
@@ -170,7 +173,13 @@ def main(argv=None):
                 flows, masks = pipe.estimate_flows(seg)
             latents = []
 
+            npatch = [0]
+
             def one(frames, fl, mk, reseed=False):
+                if FLOW_HOOK is not None:
+                    own = (fl, mk)
+                    fl, mk = FLOW_HOOK(npatch[0], fl, mk)
+                npatch[0] += 1
                 if reseed:
                     torch.manual_seed(opt.seed)                  # seed_everything(opt.seed) per pixel patch (:428)
                 h8_, w8_ = frames.shape[-2] // 8, frames.shape[-1] // 8
@@ -181,6 +190,8 @@ def main(argv=None):
                 latents.append(lat_)
                 if CAPTURE is not None:
                     CAPTURE.append({"flows": fl, "masks": mk, "x0": lat_})
+                    if FLOW_HOOK is not None:
+                        CAPTURE[-1]["own_flows"], CAPTURE[-1]["own_masks"] = own
                 return out_
 
             if seg.shape[-2] > opt.vqgantile_size or seg.shape[-1] > opt.vqgantile_size:
@@ -201,7 +212,10 @@ def main(argv=None):
                         torch.manual_seed(opt.seed)
                         h8_, w8_ = pch.shape[-2] // 8, pch.shape[-1] // 8
                         nz = NOISE_HOOK(pch.shape[0], h8_, w8_, opt.ddpm_steps) if NOISE_HOOK is not None else pipe.draw_noise(pch.shape[0], h8_, w8_)
-                        jobs.append((pch, (ff_[None], fb_[None]), (fo_[None], bo_[None]), nz, idx))
+                        fl_, mk_ = (ff_[None], fb_[None]), (fo_[None], bo_[None])
+                        if FLOW_HOOK is not None:
+                            fl_, mk_ = FLOW_HOOK(len(jobs), fl_, mk_)
+                        jobs.append((pch, fl_, mk_, nz, idx))
 
                     def patch(pipe_i, job):
                         pch, fl, mk, nz, _ = job

@@ -581,8 +581,9 @@ class _Instrument:
             return t
 
         def entry(obj, **kw):
+            rng = torch.get_rng_state().clone()          # CPU generator at entry: the per-step draws follow from it
             out = o_entry(obj, **kw)
-            self.calls.append({"x_T": kw["x_T"].clone(), "ff": kw["flows"][0].clone(), "fb": kw["flows"][1].clone(),
+            self.calls.append({"rng": rng, "x_T": kw["x_T"].clone(), "ff": kw["flows"][0].clone(), "fb": kw["flows"][1].clone(),
                                "fo": kw["masks"][0].clone(), "bo": kw["masks"][1].clone(), "lat": kw["struct_cond"].clone(),
                                "x0": out[0].clone(), "gscale": float(kw["guidance_scale"])})
             return out
@@ -596,6 +597,20 @@ class _Instrument:
         setattr(self.ddpm.LatentDiffusionVSRTextWT, self.entry, self.o[2])
         torch.nn.Module.cuda, sys.argv = self.o[3], self.o[4]
         return False
+
+
+def _steps_digest(state, draws):
+    """the per-step noise draws of a sampler call as (CPU generator state at its entry, sha256 of the fp32 draws, a few head values):
+    50 x [T,4,64,64] floats are 16 MiB a call; they are torch.randn calls on the global generator, so the state reproduces them (checked
+    here) on the torch build that made the fixture, and the tests check the digest before they trust the replay"""
+    import hashlib
+    steps = torch.stack(draws)
+    keep = torch.get_rng_state()
+    torch.set_rng_state(state)
+    rep = torch.stack([torch.randn(tuple(steps.shape[1:])) for _ in range(steps.shape[0])])
+    torch.set_rng_state(keep)
+    assert torch.equal(rep, steps), "the generator state at the sampler's entry does not reproduce its per-step draws"
+    return state, np.frombuffer(hashlib.sha256(steps.numpy().tobytes()).digest(), dtype=np.uint8), steps[:, 0, 0, 0, :4]
 
 
 def gen_harness():
@@ -637,7 +652,7 @@ def gen_harness():
            "noise_steps_loop_order": torch.stack(draws[2:2 + S])}
     for c, rec in enumerate(calls):
         for k, v in rec.items():
-            if k == "gscale":
+            if k in ("gscale", "rng"):
                 continue
             if c == 0 or k in ("x0",):
                 out[f"p{c}_{k}"] = v
@@ -652,8 +667,10 @@ def gen_harness_full():
     scripts/vsr_val_ddpm_text_T_vqganfin_oldcanvas_tile.py::main(), imported from the reference tree and run unmodified, with the
     SHIPPED full-width networks (synthetic weights), its default 5 frames per segment and 50 DDPM steps, on 5 LR frames of 136x136
     (-> 544x544: 2x2 pixel patches of 512^2, RAFT flows, dec_w 0.5, AdaIN) — the same stubbing as gen_harness.  The fixture holds the
-    LR frames, the noise, per-patch flows / masks (norms) / x_T / x_0 and the uint8 HR frames the script wrote.  ~1 CPU-hour on 8
-    threads: `make_golden.py harness_full`."""
+    LR frames, the noise (the per-step draws as generator state + digest, _steps_digest), per-patch flows / masks (norms) / x_T / x_0 and the
+    uint8 HR frames the script wrote.  ~80 CPU-minutes on 8 threads: `make_golden.py harness_full`.  (The committed file came from a run
+    that stored the step draws rounded to fp16; the generator state was recovered by re-running the script up to the first sampler call
+    and checked against those — this function now records it directly.)"""
     import shutil
     import tempfile
     import time
@@ -678,11 +695,12 @@ def gen_harness_full():
     for c in range(1, 4):
         for j in range(per):
             assert torch.equal(draws[c * per + j], draws[j])
+    st, sha, head = _steps_digest(calls[0]["rng"], draws[2:2 + S])
     out = {"lr_u8": lr_u8, "hr_u8": hr, "noise_posterior": draws[0], "noise_xT": draws[1],
-           "noise_steps_loop_order": torch.stack(draws[2:2 + S]).half(), "seconds": np.array([time.time() - t0])}
+           "rng_state_steps": st, "noise_steps_sha256": sha, "noise_steps_head": head, "seconds": np.array([time.time() - t0])}
     for c, rec in enumerate(calls):
         for k, v in rec.items():
-            if k == "gscale":
+            if k in ("gscale", "rng"):
                 continue
             if k in ("x0", "x_T", "lat"):
                 out[f"p{c}_{k}"] = v
@@ -694,7 +712,14 @@ def gen_harness_full():
     shutil.rmtree(tmp, ignore_errors=True)
 
 
-def gen_harness_old():
+def gen_harness_old_full():
+    """gen_harness_old at the PRODUCTION width and schedule: scripts/vsr_val_ddpm_text_T_vqganfin_old.py::main() with the shipped
+    full-width networks (synthetic weights), one 5-frame segment, 50 DDPM steps (-> g_harness_old_full.npz; the per-step draws as
+    generator state + digest, _steps_digest).  ~20 CPU-minutes: `make_golden.py harness_old_full`."""
+    gen_harness_old(full=True)
+
+
+def gen_harness_old(full=False):
     """H4, the two fixed-size entry scripts: scripts/vsr_val_ddpm_text_T_vqganfin_old.py::main() and ..._w_latent.py::main() of the
     reference, run unmodified (same stubbing as gen_harness; torchvision's Resize / CenterCrop — a third-party dependency absent
     here — stand in as the tensor code path of torchvision 0.13/0.14, the reference's pin: bilinear, align_corners=False, no
@@ -708,7 +733,7 @@ def gen_harness_old():
     from PIL import Image
     ref_import.install()
     torchvision = sys.modules["torchvision"]          # ref_import's stand-in module
-    Tn, S, NF = T, 2, 7
+    Tn, S, NF = (5, 50, 5) if full else (T, 2, 7)
     out = {}
 
     class Resize:
@@ -755,8 +780,10 @@ def gen_harness_old():
     torch.cuda.Event, torch.cuda.synchronize = _Ev, (lambda *a, **k: None)
     try:
         for tag, modname in (("old", "scripts.vsr_val_ddpm_text_T_vqganfin_old"), ("wlat", "scripts.vsr_val_ddpm_text_T_vqganfin_w_latent")):
+            if full and tag != "old":
+                continue
             tmp = tempfile.mkdtemp(prefix="mgld_harness_old_")
-            ddpm = _harness_env(tmp, 128)
+            ddpm = _harness_env(tmp, 128, full=full, frames=Tn)
             lr_u8 = _harness_frames(tmp, "harness_old/img", 160, 224, NF)
             script = ref_import.ref(modname)
             with _Instrument(ddpm, "sample") as ins:
@@ -768,10 +795,11 @@ def gen_harness_old():
                 with torch.enable_grad():
                     script.main()
             names = sorted(os.listdir(os.path.join(tmp, "out", "seq0")))
-            assert names == [f"{k:04d}.png" for k in range(6)] and len(ins.calls) == 2, (names, len(ins.calls))
+            nseg = NF // Tn
+            assert names == [f"{k:04d}.png" for k in range(nseg * Tn)] and len(ins.calls) == nseg, (names, len(ins.calls))
             hr = np.stack([np.asarray(Image.open(os.path.join(tmp, "out", "seq0", f)).convert("RGB")) for f in names])
             per = 2 + S                                  # posterior noise, x_T noise, one draw per step; seeded once: segments differ
-            assert len(ins.draws) == 2 * per
+            assert len(ins.draws) == nseg * per
             out["lr_u8"] = lr_u8
             assert bool(torch.isfinite(ins.calls[0]["ff"]).all())
             out[f"{tag}_hr_u8"] = hr
@@ -779,15 +807,19 @@ def gen_harness_old():
             for sgi, rec in enumerate(ins.calls):
                 d = ins.draws[sgi * per:(sgi + 1) * per]
                 out[f"{tag}_s{sgi}_noise_posterior"], out[f"{tag}_s{sgi}_noise_xT"] = d[0], d[1]
-                out[f"{tag}_s{sgi}_noise_steps_loop_order"] = torch.stack(d[2:])
+                if full:
+                    (out[f"{tag}_s{sgi}_rng_state_steps"], out[f"{tag}_s{sgi}_noise_steps_sha256"],
+                     out[f"{tag}_s{sgi}_noise_steps_head"]) = _steps_digest(rec["rng"], d[2:])
+                else:
+                    out[f"{tag}_s{sgi}_noise_steps_loop_order"] = torch.stack(d[2:])
                 for k in ("x_T", "ff", "fb", "fo", "bo", "lat", "x0"):
-                    out[f"{tag}_s{sgi}_{k}"] = rec[k]
+                    out[f"{tag}_s{sgi}_{k}"] = rec[k].half() if full and k in ("ff", "fb") else rec[k]
             if tag == "wlat":
                 out["wlat_npy"] = np.stack([np.load(os.path.join(tmp, "lat", "seq0", f"{k:04d}.npy")) for k in range(6)])
             shutil.rmtree(tmp, ignore_errors=True)
     finally:
         torch.cuda.Event, torch.cuda.synchronize = o_ev, o_sync
-    save("g_harness_old", **out)
+    save("g_harness_old_full" if full else "g_harness_old", **out)
 
 
 def gen_raft():
