@@ -241,7 +241,7 @@ def roofline(pipe, args, frames, noise, flows, masks):
                 h["ms"] += ms
                 h["launches"] += 1
         elif kind == "attention":
-            name = f"flash_attn_kernel<{info['d']}, {'true' if info.get('vrm') else 'false'}>"      # as rocprofv3 prints it
+            name = info["kernel"]      # as rocprofv3 prints it (mgld_attention_kernel_name)
             k = kern.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "splitk_launches": 0})
             k["flops"] += info["flops"]
             k["bytes"] += info["bytes"]
@@ -272,6 +272,9 @@ def roofline(pipe, args, frames, noise, flows, masks):
         tr = _pmc_traffic(n)          # HBM-side bytes per launch from the committed PMC pass, when it was taken on this build
         if tr:
             e["traffic"], e["traffic_over_algorithmic"] = tr, round(tr / max(1.0, v["bytes"] / v["launches"]), 2)
+        rk = _rocprof_avg(n)          # the same kernel's average launch in the committed rocprofv3 --kernel-trace summary
+        if rk:
+            e["frac_rocprof_avg"] = round(v["flops"] / v["launches"] / (rk["avg_us"] * 1e-6) / 1e12 / PEAK_FP16_TFLOPS, 4)
         return e
     by_kernel = [_entry(n, v) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:10]]
     traffic = _pmc_traffic(dom)

@@ -219,6 +219,9 @@ typedef struct MgldAttn {
   int32_t v_rowmajor;
 } MgldAttn;
 int mgld_attention(const MgldAttn* p, void* stream);
+/* name of the kernel instantiation mgld_attention launches for this problem, spelled as rocprofv3 --kernel-trace prints it (bench.py groups
+ * its in-sequence timings by it, like mgld_igemm_kernel_name) */
+int mgld_attention_kernel_name(const MgldAttn* p, char* buf, int buflen);
 /* TemporalAttention core (attention.py:124-143 -> 262-308): per pixel and head, softmax over the T frames.
  * q,k,v,o: frame-major token matrices [T*HW, ld] fp16 (row = t*HW + pixel), head h at columns h*head_dim.. ;
  * T <= 16, head_dim in {64,128}. One wave per (pixel, head). */

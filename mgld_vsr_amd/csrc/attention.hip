@@ -380,6 +380,23 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
+// does the launcher stage K / V by LDS-DMA for this problem (flash_attn_kernel<64, true, true>)?  env MGLD_ATTN_DMA = 0: never (A/B)
+static bool attn_takes_dma(const MgldAttn* p) {
+  static int dma = -1;
+  if (dma < 0) { const char* e = getenv("MGLD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
+  return p->v_rowmajor && p->head_dim == 64 && dma && (p->Nkv % 64) == 0 && ((int64_t)p->Nkv * p->k_si * 2 < 0x7fffffffLL) &&
+         ((int64_t)p->Nkv * p->vt_sd * 2 < 0x7fffffffLL);
+}
+
+// name of the kernel instantiation mgld_attention launches for this problem, as rocprofv3 --kernel-trace prints it
+extern "C" int mgld_attention_kernel_name(const MgldAttn* p, char* buf, int buflen) {
+  MGLD_REQUIRE(p && buf && buflen > 0, "attention_kernel_name: null");
+  MGLD_REQUIRE(p->head_dim == 64 || p->head_dim == 128, "attention: head_dim must be 64 or 128");
+  if (p->v_rowmajor) snprintf(buf, buflen, "flash_attn_kernel<%d, true, %s>", p->head_dim, attn_takes_dma(p) ? "true" : "false");
+  else snprintf(buf, buflen, "flash_attn_kernel<%d, false, false>", p->head_dim);
+  return 0;
+}
+
 extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
   MGLD_REQUIRE(p && p->Q && p->K && p->Vt && p->O, "attention: null pointer");
   MGLD_REQUIRE(p->batch > 0 && p->heads > 0 && p->Nq > 0 && p->Nkv > 0, "attention: empty");
@@ -408,9 +425,7 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
       (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
       attr_done2 = true;
     }
-    static int dma = -1;     // env MGLD_ATTN_DMA = 0: the register-staged form (A/B)
-    if (dma < 0) { const char* e = getenv("MGLD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
-    if (p->head_dim == 64 && dma && (p->Nkv % 64) == 0 && ((int64_t)p->Nkv * p->k_si * 2 < 0x7fffffffLL) && ((int64_t)p->Nkv * p->vt_sd * 2 < 0x7fffffffLL))
+    if (attn_takes_dma(p))
       hipLaunchKernelGGL((flash_attn_kernel<64, true, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
     else if (p->head_dim == 64)
       hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);

@@ -56,7 +56,7 @@ EXPORTS = [
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
     "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_igemm_gn_chunks", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply",
     "mgld_gn_apply_chunks", "mgld_gn_apply2", "mgld_spade_apply2", "mgld_gn_fused_applies", "mgld_gn_fused", "mgld_layernorm",
-    "mgld_attention", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
+    "mgld_attention", "mgld_attention_kernel_name", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
     "mgld_linear_small", "mgld_timestep_embedding",
     "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
     "mgld_ddpm_step", "mgld_flow_warp", "mgld_guidance", "mgld_guidance_loss", "mgld_step_advance",
@@ -352,8 +352,13 @@ def attention(q, k, vt, o, *, batch, heads, Nq, Nkv, head_dim, q_strides, k_stri
         p.vt_sb, p.vt_sh, p.vt_sd = vt_strides
     p.o_sb, p.o_si, p.o_sh = o_strides
     p.scale = scale
-    with timed("attention", {"flops": 4.0 * batch * heads * Nq * Nkv * head_dim, "bytes": 2.0 * batch * heads * head_dim * (2 * Nq + 2 * Nkv), "d": head_dim,
-                             "vrm": bool(v_rowmajor)}):
+    info = None
+    if TIMED is not None:
+        buf = C.create_string_buffer(96)
+        _chk(lib().mgld_attention_kernel_name(C.byref(p), buf, 96), "attention_kernel_name")
+        info = {"flops": 4.0 * batch * heads * Nq * Nkv * head_dim, "bytes": 2.0 * batch * heads * head_dim * (2 * Nq + 2 * Nkv), "d": head_dim,
+                "vrm": bool(v_rowmajor), "kernel": buf.value.decode()}
+    with timed("attention", info):
         _chk(lib().mgld_attention(C.byref(p), stream_ptr()), "attention")
     return o
 
