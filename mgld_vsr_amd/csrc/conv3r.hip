@@ -26,8 +26,9 @@ constexpr int PPA = MGLD_PP_ABLATE;
 // TWO: the instantiation that runs the weight-residual pass (MgldIGemm.W2): the slices are walked twice over the same patches — first
 // against the scaled fp16 residual of the weights (same tiled layout, its own buffer descriptor), then, after ONE multiplication of the
 // accumulators by w2_scale, against the weights themselves.  A "visit" v below is slice v % nh of pass v / nh.
-template <int TY, int TX, int BN, int WGM, int WGN, int NSW, bool TWO = false>
-__global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const int tiles_x, const int tiles_y, const int order) {
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW, bool TWO, bool SPLIT>
+__global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const int tiles_x, const int tiles_y, const int order, float* __restrict__ ws,
+                                                     const int hsplit) {
   constexpr int BM = TY * TX, WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
   // patch rows are laid out with a row stride of PW pixels, PW a multiple of 8 (TX + 2 rounded up; the pad columns are DMA'd as zeros):
   // the chunk swizzle bit (row >> 2) & 1 of a fragment row is then the same for every tile row, i.e. the nine taps of every fragment are
@@ -69,7 +70,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
   const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
   const int y0 = tyi * TY, x0 = txi * TX;
   const int bn0 = tile_n * BN;
-  const int Hin = p.Hin, Win = p.Win, nh = p.Cin >> 5;
+  // SPLIT (the 16^2 level: too few tiles for the chip): blockIdx.z owns the channel slices [h0, h0 + nh) and writes raw fp32 sums into its
+  // slab of the K-split workspace; splitk_reduce_kernel adds the slabs and runs the epilogue
+  const int Hin = p.Hin, Win = p.Win, nh_all = p.Cin >> 5;
+  const int h0 = SPLIT ? (int)blockIdx.z * hsplit : 0;
+  const int nh = SPLIT ? min(hsplit, nh_all - h0) : nh_all;
 
   // ---- DMA sources
   const int64_t fpix = (int64_t)frame * Hin * Win;
@@ -93,14 +98,14 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
 #pragma unroll
   for (int k = 0; k < CWHI; ++k) {
     const int gr = (bn0 >> 4) + k * 8 + wave;
-    wbase[k] = (uint32_t)((((gr >> 2) * nh * 3) * 4 + (gr & 3)) * 3) * 1024u;
+    wbase[k] = (uint32_t)((((gr >> 2) * nh_all * 3) * 4 + (gr & 3)) * 3) * 1024u;
   }
   auto issue_patch = [&](const int s, const int par, const int vv) __attribute__((always_inline)) {
-    const int hh = (TWO && vv >= nh) ? vv - nh : vv;
+    const int hh = h0 + ((TWO && vv >= nh) ? vv - nh : vv);
     pp_dma16(rsA, smem + par * A_BYTES + (s * 8 + wave) * 1024, voffA[s], (uint32_t)hh * 64u);
   };
   auto issue_w = [&](const int slot, const int vv, const int tap) __attribute__((always_inline)) {
-    const int hh = (TWO && vv >= nh) ? vv - nh : vv;
+    const int hh = h0 + ((TWO && vv >= nh) ? vv - nh : vv);
     const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
     const uint32_t so = (uint32_t)hh * (36u * 1024u) + (uint32_t)dy * (12u * 1024u) + (uint32_t)dx * 1024u;
     char* dst = smem + W_BASE + slot * WSLOT + wave * 1024;
@@ -266,6 +271,18 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
     const int y = y0 + R / TX, x = x0 + (R & (TX - 1));
     return (y < Hout && x < Wout) ? fbase + y * Wout + x : -1;
   };
+  if constexpr (SPLIT) {                           // raw sums: lane = one output row, 4 consecutive channels per fragment
+    float* slab = ws + (int64_t)blockIdx.z * p.M * p.N;
+    const int nb = bn0 + wn * WN + 4 * g;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = row_of(mi);
+      if (m < 0) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) *(f32x4*)(slab + (int64_t)m * p.N + nb + ni * 16) = acc[ni][mi];
+    }
+    return;
+  }
   if (p.gn_part) {
     // GroupNorm statistics of the output (MgldIGemm.gn_part): every wave's per-channel sums of its stored rows meet in LDS (the stages
     // are dead: both wave groups are past their last fragment read), one row of part[] per tile.  A tile lies in one frame.
@@ -300,40 +317,49 @@ constexpr int conv3r_lds() {
   return 2 * NPT * 8 * 1024 + NSW * BN * 64;
 }
 
-template <int TY, int TX, int BN, int WGM, int WGN, int NSW, bool TWO = false>
-int launch_conv3r_(const MgldIGemm* p, hipStream_t s) {
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW, bool TWO, bool SPLIT>
+int launch_conv3r_(const MgldIGemm* p, hipStream_t s, int splits) {
   constexpr int lds = conv3r_lds<TY, TX, BN, NSW>();
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3r_kernel<TY, TX, BN, WGM, WGN, NSW, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv3r_kernel<TY, TX, BN, WGM, WGN, NSW, TWO, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const int frames = p->M / (p->Hout * p->Wout);
   const int tiles_x = cdiv(p->Wout, TX), tiles_y = cdiv(p->Hout, TY);
-  dim3 grid(frames * tiles_x * tiles_y, p->N / BN, 1);
+  const int nh = p->Cin >> 5, hsplit = cdiv(nh, splits);
+  dim3 grid(frames * tiles_x * tiles_y, p->N / BN, SPLIT ? cdiv(nh, hsplit) : 1);
   static int forder = -2, noswap = -1;
   if (forder == -2) { const char* e = getenv("MGLD_CONV3R_ORDER"); forder = e ? atoi(e) : -1; }
   if (noswap < 0) { const char* e = getenv("MGLD_PP_NOSWAP"); noswap = e ? atoi(e) : 0; }
   const double wbytes = 2.0 * p->N * p->K, abytes = 2.0 * p->M * p->Cin;
   const int order = (forder >= 0 ? forder : (wbytes > 2.0 * abytes ? 1 : 0)) | (noswap ? 0x100 : 0);
-  hipLaunchKernelGGL((conv3r_kernel<TY, TX, BN, WGM, WGN, NSW, TWO>), grid, dim3(512), lds, s, *p, tiles_x, tiles_y, order);
+  hipLaunchKernelGGL((conv3r_kernel<TY, TX, BN, WGM, WGN, NSW, TWO, SPLIT>), grid, dim3(512), lds, s, *p, tiles_x, tiles_y, order,
+                     SPLIT ? g_ws : nullptr, hsplit);
+  if (SPLIT) launch_splitk_reduce(p, s, (int)grid.z);
   return mgld_check_launch("igemm(conv3r)");
 }
-template <int TY, int TX, int BN, int WGM, int WGN, int NSW>
-int launch_conv3r(const MgldIGemm* p, hipStream_t s) {
-  return p->W2 ? launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, true>(p, s) : launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, false>(p, s);
+template <int TY, int TX, int BN, int WGM, int WGN, int NSW, bool SPLITTABLE = false>
+int launch_conv3r(const MgldIGemm* p, hipStream_t s, int splits) {
+  if constexpr (SPLITTABLE) {
+    if (splits > 1)
+      return p->W2 ? launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, true, true>(p, s, splits) : launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, false, true>(p, s, splits);
+  }
+  return p->W2 ? launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, true, false>(p, s, 1) : launch_conv3r_<TY, TX, BN, WGM, WGN, NSW, false, false>(p, s, 1);
 }
 
 }  // namespace
 
 namespace mgld_ig {
 // does the ping-pong patch convolution take this problem?  p->tune: 30 = yes wherever it is covered, 31 + id = that configuration,
-// 0 = the planner decides; other values: no.  env MGLD_CONV3R = 0 switches the family off.
-bool conv3r_plan(const MgldIGemm* p, int* id) {
+// 50 + id = that configuration with the channel slices split over grid.z where its tiles do not fill the chip (configurations 4, 5, 8),
+// 0 = the planner decides; other values: no.  env MGLD_CONV3R = 0 switches the family off, MGLD_CONV3R_SPLIT = 0 the K split.
+bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
+  *splits = 1;
   static int knob = -1;
   if (knob < 0) { const char* e = getenv("MGLD_CONV3R"); knob = e ? atoi(e) : 1; }
   if (!knob || p->mode != MGLD_MODE_CONV3X3 || p->tap_inner != 2) return false;
-  if (p->tune != 0 && (p->tune < 30 || p->tune > 30 + R3_NCFG)) return false;
+  if (p->tune != 0 && (p->tune < 30 || p->tune > 30 + R3_NCFG) && (p->tune < 50 || p->tune >= 50 + R3_NCFG)) return false;
   if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
   if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->out_f32 || p->bias_m || (p->Cin & 31)) return false;
   if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU)) return false;
@@ -343,13 +369,31 @@ bool conv3r_plan(const MgldIGemm* p, int* id) {
   if ((p->bias && (((uintptr_t)p->bias) & 15)) || (p->rowvec && ((((uintptr_t)p->rowvec) & 15) || (p->ld_rowvec & 3)))) return false;
   if ((int64_t)p->Hin * p->Win * p->lda * 2 >= 0x7fffffffLL) return false;      // a frame must fit the descriptor's 31-bit range
   auto fits = [&](int i) { return p->N % R3_CFG[i].bn == 0; };
+  const int frames = p->M / (p->Hout * p->Wout), cus = num_cus();
+  auto tiles_of = [&](int i) { return (int64_t)frames * cdiv(p->Hout, R3_CFG[i].ty) * cdiv(p->Wout, R3_CFG[i].tx) * (p->N / R3_CFG[i].bn); };
+  // K split of configuration i: as many slabs as keep tiles x slabs within the chip (>= 2, at most one per two channel slices), workspace permitting
+  auto splits_of = [&](int i) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MGLD_CONV3R_SPLIT"); on = e ? atoi(e) : 1; }
+    if (!on || !(i == 4 || i == 5 || i == 8) || p->gn_part) return 1;
+    const int nh = p->Cin >> 5;
+    int sp = (int)(cus / tiles_of(i));
+    if (sp > nh / 2) sp = nh / 2;
+    if (sp < 2 || g_ws == nullptr || (size_t)sp * p->M * p->N * sizeof(float) > g_ws_bytes || (p->N & 3)) return 1;
+    return cdiv(nh, cdiv(nh, sp));            // slabs actually launched
+  };
+  if (p->tune >= 50) {
+    const int i = p->tune - 50;
+    if (!fits(i)) return false;
+    *id = i;
+    *splits = splits_of(i);
+    return true;
+  }
   if (p->tune > 30) {
     if (!fits(p->tune - 31)) return false;
     *id = p->tune - 31;
     return true;
   }
-  const int frames = p->M / (p->Hout * p->Wout), cus = num_cus();
-  auto tiles_of = [&](int i) { return (int64_t)frames * cdiv(p->Hout, R3_CFG[i].ty) * cdiv(p->Wout, R3_CFG[i].tx) * (p->N / R3_CFG[i].bn); };
   // planner (measured against conv3q on MI355X, tools/igemm_bench.py conv / vae, profiles/r04_pp_conv.txt): the first configuration of the
   // list for N's divisibility whose tile count covers most of the chip and whose tile width the image fills.  Small frames with few
   // tiles (the 16^2 / 8^2 UNet levels) stay on conv3q and its K split.
@@ -361,6 +405,17 @@ bool conv3r_plan(const MgldIGemm* p, int* id) {
   const int64_t most = (3 * cus) / 4;
   if (p->N % 128 == 0) { take(8, most); take(3, most); take(2, cus / 2 - cus / 8); }
   if (p->N % 80 == 0) { take(6, most); take(0, most); take(7, most); take(5, most); }
+  // few tiles, deep K (the 16^2 UNet level: 8 frames x 256 pixels x 1280 channels, K = 11520 .. 23040): the channel slices split over
+  // grid.z so that tiles x slabs fill the chip once (profiles/r04_conv3r_split.txt)
+  if (bid < 0 && p->tune == 0 && p->Wout >= 16 && p->Hout >= 8 && (p->Cin >> 5) >= 8) {
+    const int cand[3] = {4, 5, 8};                 // 256-pixel tiles x 160 channels x 4 slabs measured best at 8 frames x 16^2 x 1280
+    for (int k = 0; k < 3 && bid < 0; ++k) {
+      const int i = cand[k];
+      if (!fits(i) || p->Wout < R3_CFG[i].tx || p->Hout < R3_CFG[i].ty) continue;
+      const int sp = splits_of(i);
+      if (sp >= 2 && tiles_of(i) * sp >= most) { bid = i; *splits = sp; }
+    }
+  }
   if (bid < 0 && p->tune == 30) {
     const int pref[R3_NCFG] = {8, 3, 2, 6, 0, 7, 5, 1, 4};
     for (int k = 0; k < R3_NCFG && bid < 0; ++k) if (fits(pref[k])) bid = pref[k];
@@ -375,17 +430,17 @@ bool conv3r_plan(const MgldIGemm* p, int* id) {
   return true;
 }
 
-int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id) {
+int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id, int splits) {
   switch (id) {
-    case 0: return launch_conv3r<8, 32, 160, 4, 2, 6>(p, s);
-    case 1: return launch_conv3r<8, 16, 320, 2, 4, 4>(p, s);
-    case 2: return launch_conv3r<8, 32, 128, 4, 2, 6>(p, s);
-    case 3: return launch_conv3r<8, 32, 256, 2, 4, 5>(p, s);
-    case 4: return launch_conv3r<16, 16, 160, 4, 2, 6>(p, s);
-    case 5: return launch_conv3r<8, 16, 160, 4, 2, 6>(p, s);
-    case 6: return launch_conv3r<16, 32, 80, 8, 1, 5>(p, s);
-    case 7: return launch_conv3r<8, 32, 80, 8, 1, 6>(p, s);
-    default: return launch_conv3r<16, 32, 128, 8, 1, 5>(p, s);
+    case 0: return launch_conv3r<8, 32, 160, 4, 2, 6>(p, s, 1);
+    case 1: return launch_conv3r<8, 16, 320, 2, 4, 4>(p, s, 1);
+    case 2: return launch_conv3r<8, 32, 128, 4, 2, 6>(p, s, 1);
+    case 3: return launch_conv3r<8, 32, 256, 2, 4, 5>(p, s, 1);
+    case 4: return launch_conv3r<16, 16, 160, 4, 2, 6, true>(p, s, splits);
+    case 5: return launch_conv3r<8, 16, 160, 4, 2, 6, true>(p, s, splits);
+    case 6: return launch_conv3r<16, 32, 80, 8, 1, 5>(p, s, 1);
+    case 7: return launch_conv3r<8, 32, 80, 8, 1, 6>(p, s, 1);
+    default: return launch_conv3r<16, 32, 128, 8, 1, 5, true>(p, s, splits);
   }
 }
 
@@ -395,6 +450,9 @@ int conv3r_gn_chunks(const MgldIGemm* p, int id) { return cdiv(p->Hout, R3_CFG[i
 void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen) {
   static const int g[R3_NCFG][6] = {{8, 32, 160, 4, 2, 6}, {8, 16, 320, 2, 4, 4}, {8, 32, 128, 4, 2, 6}, {8, 32, 256, 2, 4, 5}, {16, 16, 160, 4, 2, 6},
                                     {8, 16, 160, 4, 2, 6}, {16, 32, 80, 8, 1, 5}, {8, 32, 80, 8, 1, 6}, {16, 32, 128, 8, 1, 5}};
-  snprintf(buf, buflen, "conv3r_kernel<%d, %d, %d, %d, %d, %d, %s>", g[id][0], g[id][1], g[id][2], g[id][3], g[id][4], g[id][5], p->W2 ? "true" : "false");
+  int id_, splits = 1;
+  (void)conv3r_plan(p, &id_, &splits);
+  snprintf(buf, buflen, "conv3r_kernel<%d, %d, %d, %d, %d, %d, %s, %s>", g[id][0], g[id][1], g[id][2], g[id][3], g[id][4], g[id][5], p->W2 ? "true" : "false",
+           splits > 1 ? "true" : "false");
 }
 }  // namespace mgld_ig

@@ -726,7 +726,7 @@ extern "C" int mgld_igemm_config(const MgldIGemm* p) {
   if (!p) return 0;
   int cfg, splits, kchunk;
   if (ppgemm_plan(p, &cfg)) return 500000 + cfg;                                                            // ping-pong LINEAR
-  if (conv3r_plan(p, &cfg)) return 600000 + cfg;                                                            // ping-pong patch conv
+  if (conv3r_plan(p, &cfg, &splits)) return 600000 + cfg + (splits > 1 ? splits * 1000000 : 0);          // ping-pong patch conv
   { int lg_; if (pptconv_plan(p, &cfg, &lg_)) return 700000 + cfg; }                                        // ping-pong temporal conv
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return 400000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // 2-D-tile patch conv
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) return 300000 + cfg + (splits > 1 ? splits * 1000000 : 0);   // raster patch conv
@@ -739,7 +739,8 @@ extern "C" int mgld_igemm_gn_chunks(const MgldIGemm* p) {
   if (!p) return 0;
   int cfg;
   if (ppgemm_plan(p, &cfg)) return 0;
-  if (conv3r_plan(p, &cfg)) return (p->N & 7) ? 0 : conv3r_gn_chunks(p, cfg);
+  int sp;
+  if (conv3r_plan(p, &cfg, &sp)) return ((p->N & 7) || sp > 1) ? 0 : conv3r_gn_chunks(p, cfg);
   return 0;
 }
 
@@ -751,9 +752,9 @@ extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen)
     ppgemm_kernel_name(p, cfg, buf, buflen);
     return 1;
   }
-  if (conv3r_plan(p, &cfg)) {
+  if (conv3r_plan(p, &cfg, &splits)) {
     conv3r_kernel_name(p, cfg, buf, buflen);
-    return 1;
+    return splits;
   }
   { int lg_; if (pptconv_plan(p, &cfg, &lg_)) { pptconv_kernel_name(p, cfg, buf, buflen); return 1; } }
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) {
@@ -819,7 +820,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   int cfg, splits, kchunk;
   if (p->gn_part) MGLD_REQUIRE(mgld_igemm_gn_chunks(p) > 0 && ((((uintptr_t)p->gn_part) & 3) == 0), "igemm: gn_part set, but the kernel picked for this problem does not write statistics (mgld_igemm_gn_chunks)");
   if (ppgemm_plan(p, &cfg)) return dispatch_ppgemm(p, s, cfg);
-  if (conv3r_plan(p, &cfg)) return dispatch_conv3r(p, s, cfg);
+  if (conv3r_plan(p, &cfg, &splits)) return dispatch_conv3r(p, s, cfg, splits);
   { int lg_; if (pptconv_plan(p, &cfg, &lg_)) return dispatch_pptconv(p, s, cfg, lg_); }
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return dispatch_conv3q(p, s, cfg, splits, kchunk);
   if (conv3p_plan(p, &cfg, &splits, &kchunk)) {

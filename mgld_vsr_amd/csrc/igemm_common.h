@@ -24,8 +24,8 @@ bool ppgemm_plan(const MgldIGemm* p, int* id);
 int dispatch_ppgemm(const MgldIGemm* p, hipStream_t s, int id);
 void ppgemm_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
 // conv3r.hip (ping-pong patch convolutions)
-bool conv3r_plan(const MgldIGemm* p, int* id);
-int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id);
+bool conv3r_plan(const MgldIGemm* p, int* id, int* splits);
+int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id, int splits);
 void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
 int conv3r_gn_chunks(const MgldIGemm* p, int id);
 // pptconv.hip (ping-pong temporal Conv3d)

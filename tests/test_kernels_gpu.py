@@ -543,6 +543,52 @@ def test_igemm_conv3x3_pingpong_gn_stats(hip, cfg, n, cin, nt, h, w, epi):
         assert rel_l2(y1.float(), y0.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cfg,n,cin,nt,h,w,epi,two", [(5, 8, 1280, 8, 16, 16, 2, False), (8, 8, 640, 10, 16, 16, 1, False), (4, 3, 320, 2, 16, 16, 0, False),
+                                                      (5, 2, 256, 1, 16, 24, 1, True), (8, 5, 2560, 10, 16, 16, 0, False)])
+def test_igemm_conv3x3_pingpong_ksplit(hip, cfg, n, cin, nt, h, w, epi, two):
+    """conv3r with the channel slices split over grid.z (tune = 50 + id: the 16^2 UNet level, too few tiles for the chip): raw fp32 slabs +
+    splitk_reduce == the unsplit kernel to the summation order, against conv2d on the same fp16 operands; with the weight-residual pass too"""
+    from mgld_vsr_amd.engine import split_residual, tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    cout = nt * R3_BN[cfg]
+    x = h16(rnd(n, cin, h, w, seed=320))
+    w32 = rnd(cout, cin, 3, 3, seed=321, scale=(9 * cin) ** -0.5)
+    hi_, lo_ = split_residual(w32.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+    wk = tile_conv3p(hi_.to(DEV), cin, False)
+    w2 = tile_conv3p(lo_.to(DEV), cin, False) if two else None
+    b = rnd(cout, seed=322)
+    wref = (w32 if two else hi_.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)).double()
+    ref = F.conv2d(x.double(), wref, b.double(), padding=1)
+    xt = _to_tok(x).to(DEV)
+    kw = dict(bias=b.to(DEV), w2=w2)
+    if epi == 1:
+        r = h16(rnd(n * h * w, cout, seed=323))
+        kw.update(resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+        ref = 0.5 * F.silu(ref) + 2.0 * _from_tok(r.double(), n, h, w)
+    elif epi == 2:
+        emb = rnd(n, cout, seed=324)
+        kw.update(rowvec=emb.to(DEV), rows_per_frame=h * w)
+        ref = ref + emb.double()[:, :, None, None]
+    p = hip.MgldIGemm()
+    p.mode, p.M, p.N, p.K, p.batch, p.tap_inner, p.tune = hip.MODE_CONV3X3, n * h * w, cout, 9 * cin, 1, 2, 50 + cfg
+    p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, 1, 1, 1, 0
+    p.lda, p.ldc = cin, cout
+    code = hip.igemm_config(p)
+    assert code % 1000000 == 600000 + cfg and code // 1000000 >= 2, code       # split taken
+    name, splits = hip.igemm_kernel_name(p)
+    assert name.endswith("true>") and splits == code // 1000000, (name, splits)
+    common = dict(mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=2, N=cout, K=9 * cin, **kw)
+    outs = [torch.full((n * h * w, cout), float("nan"), dtype=torch.half, device=DEV) for _ in range(3)]
+    for o in outs:
+        hip.igemm(xt, wk, o, tune=50 + cfg, **common)
+    one = torch.empty_like(outs[0])
+    hip.igemm(xt, wk, one, tune=31 + cfg, **common)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_l2(_from_tok(outs[0].cpu().double(), n, h, w), ref) < (4.5e-4 if two else 1e-3)
+    assert rel_l2(outs[0].float(), one.float()) < 3e-4
+
+
 def test_igemm_conv3x3_pingpong_race_screen(hip):
     """counted waits of the weight ring / patch double buffer: repeated launches of a deep-K problem give the same bits on every
     configuration, and those bits agree with conv3q's (same products, another summation order) to the fp16 output rounding"""
