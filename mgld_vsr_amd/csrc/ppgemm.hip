@@ -15,6 +15,13 @@
 namespace {
 using namespace mgld_ig;
 
+// ablation builds (tools/build_variant.sh <name> ppgemm -DMGLD_PPG_ABLATE=<bits>; timing only, results are wrong): 1 = no epilogue, 2 = the
+// K loop runs ONE stage whatever K is (what launch + prologue + epilogue cost), 4 = epilogue without the GEGLU / activation arithmetic
+#ifndef MGLD_PPG_ABLATE
+#define MGLD_PPG_ABLATE 0
+#endif
+constexpr int PPG = MGLD_PPG_ABLATE;
+
 template <int BM, int BN, int WGM, int WGN, int NST, bool GEGLU>
 __global__ __launch_bounds__(512) void ppgemm_kernel(const MgldIGemm p, const int tiles_m, const int tiles_n, const int order) {
   constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(512) void ppgemm_kernel(const MgldIGemm p, const in
   const uint32_t prow = wave * 8 + (lane >> 3);
   const uint32_t clog = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
   const uint32_t voffA = prow * lda2 + clog * 16, voffW = prow * ldw2 + clog * 16;
-  const int nk = p.K >> 6;
+  const int nk = (PPG & 2) ? 1 : p.K >> 6;
 
   // (slot range [j0, j1) is a compile-time constant at every call site; a generic lambda with integral_constant parameters made the host
   // pass of hipcc drop the kernel stubs of all but one instantiation)
@@ -132,11 +139,28 @@ __global__ __launch_bounds__(512) void ppgemm_kernel(const MgldIGemm p, const in
   }
   if (grp == 0) pp_barrier();                      // (same barrier count for both groups)
 
+  if constexpr (PPG & 1) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
+    return;
+  }
   PPEpi e;
   e.bias = p.bias; e.rowvec = p.rowvec; e.R = (const f16*)p.R; e.C = (f16*)p.C;
   e.rows_per_frame = p.rows_per_frame; e.ld_rowvec = p.ld_rowvec; e.ldr = p.ldr; e.ldc = p.ldc; e.act = p.act; e.alpha = p.alpha; e.beta = p.beta;
   e.noswap = (order & 0x100) != 0;
   const int mrow = bm0 + wm * WM + l15;
+  if constexpr ((PPG & 4) && GEGLU) {             // (the GEGLU tile written as a plain tile of half the width: store pattern kept, arithmetic dropped)
+    e.act = MGLD_ACT_NONE;
+    f32x4 half_acc[NI / 2][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI / 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) half_acc[ni][mi] = acc[ni][mi] + acc[ni + NI / 2][mi];
+    pp_epilogue<MI, NI / 2, false>(e, half_acc, lane, (bn0 + wn * WN) / 2, [&](const int mi) { return mrow + mi * 16; });
+    return;
+  }
   pp_epilogue<MI, NI, GEGLU>(e, acc, lane, bn0 + wn * WN, [&](const int mi) { return mrow + mi * 16; });
 }
 

@@ -453,6 +453,30 @@ def gen_sample_opts(model=None, ddpm=None):
     save("g_sample_opts", **out)
 
 
+def gen_sample_opts_canvas():
+    """start_T on the CANVAS loop (advisor item of round 3): p_sample_loop_canvas has another rule than p_sample_loop — `timesteps =
+    min(timesteps, start_T)` (ddpm.py:4639-4640), i.e. it walks the schedule indices start_T-1 .. 0 whatever their original timesteps
+    are.  Reduced model, 4-step schedule, 24x24 latent with 16/8 tiles, start_T = 3 -> indices 2, 1, 0.  -> g_sample_opts_canvas.npz"""
+    model, ddpm = build_ref_model()
+    S, h, w, st = 4, 24, 24, 3
+    respace(model, S)
+    ctx = model.cond_stage_model([""])
+    lat = synth.synth_tensor("optsc/lat", (T, 4, h, w), 0.5)
+    xT = synth.synth_tensor("optsc/xT", (T, 4, h, w))
+    noises = [synth.synth_tensor(f"optsc/noise{i}", (T, 4, h, w)) for i in range(S)]          # indexed by schedule index i
+    queue = [noises[i] for i in reversed(range(min(S, st)))]
+    orig = ddpm.noise_like
+    ddpm.noise_like = lambda shape, device, repeat=False: queue.pop(0)
+    try:
+        x = model.p_sample_loop_canvas(ctx, lat, (T, 4, h, w), guidance_scale=-10.0, x_T=xT, verbose=False, timesteps=S, time_replace=S,
+                                       start_T=st, tile_size=16, tile_overlap=8, batch_size=1)
+    finally:
+        ddpm.noise_like = orig
+    assert not queue
+    save("g_sample_opts_canvas", lat=lat, xT=xT, noise=torch.stack(noises), ctx=ctx, x_start_T=x, start_T=np.array([st]),
+         ori_timesteps=np.array(model.ori_timesteps, dtype=np.int64))
+
+
 def gen_ckpt_keys():
     """The key / shape list of the checkpoints the scripts load (oldcanvas_tile.py:91-108, :296-306): `state_dict` of the FULL-width
     LatentDiffusionVSRTextWT exactly as the shipped YAML builds it (mgldvsr_512_realbasicvsr_deg.yaml: UNet, struct-cond encoder,

@@ -193,6 +193,25 @@ def test_sample_loop_options_vs_golden(hip):
         model.sample(cond=g["ctx"], struct_cond=g["lat"], timesteps=S, time_replace=S, x_T=g["xT"], interfea_path="/tmp/x")
 
 
+def test_canvas_loop_start_T_vs_golden(hip):
+    """start_T on the canvas loop: p_sample_loop_canvas walks the schedule indices start_T-1 .. 0 (`timesteps = min(timesteps, start_T)`,
+    ddpm.py:4639-4640) — not p_sample_loop's "skip while the original timestep is above start_T" — against a run of the reference's own
+    loop (g_sample_opts_canvas.npz: 24x24 latent, 16/8 tiles, 4-step schedule, start_T = 3)"""
+    g = G("g_sample_opts_canvas")
+    model = _small_model()
+    S = 4
+    _respace(model, S)
+    assert list(model.ori_timesteps) == g["ori_timesteps"].tolist()
+    shape = tuple(g["xT"].shape)
+    st = int(g["start_T"][0])
+    x = model._sample_loop(g["ctx"], g["lat"], shape, -10.0, None, None, g["xT"], S, S, False, None, g["noise"], (16, 8), True,
+                           hooks={"start_T": st})
+    assert record("opts_canvas_start_T", rel_l2(x, g["x_start_T"])) < 1.4e-3
+    # the plain loop's rule on the same inputs gives ANOTHER result (ori_timesteps[i] <= 3 keeps index 0 only): the two rules are distinct
+    y = model._sample_loop(g["ctx"], g["lat"], shape, -10.0, None, None, g["xT"], S, S, False, None, g["noise"], None, True, hooks={"start_T": st})
+    assert rel_l2(y, g["x_start_T"]) > 1e-2
+
+
 def test_single_step_api_and_decode_first_stage_vs_golden(hip):
     """p_mean_variance / p_sample / p_mean_variance_canvas / p_sample_canvas (ddpm.py:4157-4442) as eager single steps and
     decode_first_stage (ddpm.py:3786 -> AutoencoderKL.decode) against the reference's outputs (g_pstep.npz)"""
