@@ -1050,6 +1050,45 @@ def test_flash_attention_rowmajor_v(hip, B, H, Nq, Nkv, D):
     assert torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nkv,D,rowmajor", [(8, 5, 4096, 4096, 64, True), (8, 5, 4096, 77, 64, False), (8, 10, 1024, 1024, 64, True)])
+def test_flash_attention_production_shapes(hip, B, H, Nq, Nkv, D, rowmajor):
+    """the attention launches of the 8 x 512^2 segment as they are launched there: 64^2 self-attention (40 (frame, head) pairs x 4096
+    tokens, q | k | v of one fused projection, row-major V: the LDS-DMA kernel), its cross-attention against the 77 context tokens
+    (V^T form), the 32^2 self-attention — against fp32 torch on the device, frame by frame"""
+    C_ = H * D
+    scale = D ** -0.5
+    g = torch.Generator().manual_seed(77)
+    if rowmajor:
+        qkv = (torch.randn(B * Nq, 3 * C_, generator=g) * 0.8).half().to(DEV)
+        q2, k2, v2 = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
+        st = (Nq * 3 * C_, 3 * C_, D)
+        o = torch.empty(B * Nq, C_, dtype=torch.half, device=DEV)
+        hip.attention(qkv, k2, v2, o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=st, k_strides=st, vt_strides=st,
+                      o_strides=(Nq * C_, C_, D), scale=scale, v_rowmajor=True)
+        kq = lambda t, n: t.float().reshape(B, n, H, D).permute(0, 2, 1, 3)
+        qf, kf, vf = kq(q2, Nq), kq(k2, Nkv), kq(v2, Nkv)
+    else:
+        qt = (torch.randn(B * Nq, C_, generator=g) * 0.8).half().to(DEV)
+        kt = (torch.randn(B * Nkv, C_, generator=g) * 0.8).half().to(DEV)
+        v = (torch.randn(B, H, Nkv, D, generator=g) * 0.8).half()
+        nkp = (Nkv + 7) // 8 * 8
+        vt = torch.zeros(B, H, D, nkp, dtype=torch.half)
+        vt[..., :Nkv] = v.permute(0, 1, 3, 2)
+        o = torch.empty(B * Nq, C_, dtype=torch.half, device=DEV)
+        hip.attention(qt, kt, vt.to(DEV), o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=(Nq * C_, C_, D),
+                      k_strides=(Nkv * C_, C_, D), vt_strides=(H * D * nkp, D * nkp, nkp), o_strides=(Nq * C_, C_, D), scale=scale)
+        qf = qt.float().reshape(B, Nq, H, D).permute(0, 2, 1, 3)
+        kf = kt.float().reshape(B, Nkv, H, D).permute(0, 2, 1, 3)
+        vf = v.float().to(DEV)
+    got = o.float().reshape(B, Nq, H, D).permute(0, 2, 1, 3)
+    num = den = 0.0
+    for b in range(B):                      # fp32 reference on the device, one frame at a time (the 64^2 logits are 335 MB per frame)
+        ref = torch.softmax(qf[b] @ kf[b].transpose(-1, -2) * scale, dim=-1) @ vf[b]
+        num += float(((got[b] - ref).double() ** 2).sum())
+        den += float((ref.double() ** 2).sum())
+    assert torch.isfinite(o).all() and (num / den) ** 0.5 < 1e-3
+
+
 def test_flash_attention_spike(hip):
     # force a large running-max jump in a late key tile (online-softmax rescale path)
     B, H, N, D = 1, 1, 192, 64
