@@ -721,7 +721,8 @@ def gen_harness_full():
             assert torch.equal(draws[c * per + j], draws[j])
     st, sha, head = _steps_digest(calls[0]["rng"], draws[2:2 + S])
     out = {"lr_u8": lr_u8, "hr_u8": hr, "noise_posterior": draws[0], "noise_xT": draws[1],
-           "rng_state_steps": st, "noise_steps_sha256": sha, "noise_steps_head": head, "seconds": np.array([time.time() - t0])}
+           "rng_state_steps": st, "noise_steps_sha256": sha, "noise_steps_head": head}
+    print(f"gen_harness_full: {time.time() - t0:.0f} s")
     for c, rec in enumerate(calls):
         for k, v in rec.items():
             if k in ("gscale", "rng"):

@@ -375,6 +375,7 @@ def _regen_and_compare(tmp_path, what, names, timeout):
     (["text_hf"], ["g_text_hf.npz"], 1200),                                     # text tower vs transformers' CLIPTextModel
     (["sample_opts_canvas"], ["g_sample_opts_canvas.npz"], 1200),               # start_T on the canvas loop
     (["harness_old_full"], ["g_harness_old_full.npz"], 7200),                   # old.py::main() at production width / schedule
+    (["harness_full"], ["g_harness_full.npz"], 21600),                          # oldcanvas_tile.py::main() at production width / schedule (80 CPU-minutes)
     (["workload:c2:4"], ["g_work_c2_S4.npz"], 3600),                            # BASELINE configs[1] / [4] workload, 4 steps
     (["workload:c2g:4"], ["g_work_c2g_S4.npz"], 3600),                          # configs[2] share
     (["workload:c4:4"], ["g_work_c4_S4.npz"], 7200),                            # configs[3]: 1024^2 aggregation sampling

@@ -54,7 +54,6 @@ def main():
         t1 = timeit(lambda: hip.igemm(x, wt, out, gn_part=part, **kw))
         gs = torch.empty(n, hip.gn_chunks(h * w), 32, 2, dtype=torch.float64, device="cuda")
         t2 = timeit(lambda: hip.gn_stats(out, n, h * w, 32, gs))
-        p = hip.MgldIGemm()
         print(f"{name:18s} conv {t0:8.1f} us   conv + statistics {t1:8.1f} us (+{t1 - t0:6.1f})   mgld_gn_stats {t2:7.1f} us   chunks {holder[0].shape[0] // n if holder else 0}", flush=True)
 
 
