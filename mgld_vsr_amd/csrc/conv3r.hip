@@ -33,14 +33,19 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
   // patch rows are laid out with a row stride of PW pixels, PW a multiple of 8 (TX + 2 rounded up; the pad columns are DMA'd as zeros):
   // the chunk swizzle bit (row >> 2) & 1 of a fragment row is then the same for every tile row, i.e. the nine taps of every fragment are
   // THREE per-lane offsets (dx) plus immediates — no address arithmetic in the loop
-  constexpr int PW = (TX + 2 + 7) & ~7, PH = TY + 2, PR = PW * PH;
+  // TX == 8 ("frame-stacked" tiles, the 8^2 UNet level): the tile is TY / 8 whole 8 x 8 frames, its patch their (8 + 2) x PW patches one
+  // below the other; a 16-row fragment is two image rows of 8 pixels (two runs of 8 patch rows 16 apart), for which the conflict-free
+  // chunk swizzle is ((row >> 2) & 1) << 1 (same k-group order; enumeration over the ds_read_b128 lane groups as for the wide tiles)
+  constexpr bool W8 = (TX == 8);
+  constexpr int FT = W8 ? TY / 8 : 1;
+  constexpr int PW = (TX + 2 + 7) & ~7, PH = W8 ? FT * 10 : TY + 2, PR = PW * PH;
   constexpr int NPA = (PR + 15) / 16, NPT = (NPA + 7) / 8;      // 1-KiB patch pieces; pieces per wave (taps 0 .. NPT-1 of the previous slice)
   constexpr int A_BYTES = NPT * 8 * 1024;
   constexpr int WSLOT = BN * 64, NPW = BN / 16;                 // one tap of one slice: BN rows x 64 B = NPW pieces
   constexpr int CWLO = NPW / 8, CWHI = (NPW + 7) / 8;
   constexpr int D = NSW - 1;                                    // weights are issued D phases ahead
   constexpr int W_BASE = 2 * A_BYTES;
-  static_assert(WGM * WGN == 8 && TX % 16 == 0 && WM % 16 == 0 && WN % 16 == 0 && BN % 16 == 0, "tile shape");
+  static_assert(WGM * WGN == 8 && (TX % 16 == 0 || (W8 && TY % 8 == 0 && WM <= 64)) && WM % 16 == 0 && WN % 16 == 0 && BN % 16 == 0, "tile shape");
   static_assert(WM % TX == 0, "a wave tile is whole tile rows");
   static_assert(NPT <= 10 - D && D >= 2 && D <= 7 && W_BASE + NSW * WSLOT <= 160 * 1024, "ring");
 
@@ -64,11 +69,12 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
       tile_n = j % (int)gridDim.y;
     }
   }
-  const int tpf = tiles_x * tiles_y;
-  const int frame = tile_m / tpf;
-  const int trem = tile_m - frame * tpf;
-  const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+  const int tpf = W8 ? 1 : tiles_x * tiles_y;
+  const int frame = W8 ? tile_m * FT : tile_m / tpf;          // W8: first frame of the tile (tiles_x carries the frame count)
+  const int trem = W8 ? 0 : tile_m - frame * tpf;
+  const int tyi = W8 ? 0 : trem / tiles_x, txi = W8 ? 0 : trem - tyi * tiles_x;
   const int y0 = tyi * TY, x0 = txi * TX;
+  const int nfr = W8 ? min(FT, tiles_x - frame) : 1;        // frames of this tile that exist
   const int bn0 = tile_n * BN;
   // SPLIT (the 16^2 level: too few tiles for the chip): blockIdx.z owns the channel slices [h0, h0 + nh) and writes raw fp32 sums into its
   // slab of the K-split workspace; splitk_reduce_kernel adds the slabs and runs the epilogue
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
 
   // ---- DMA sources
   const int64_t fpix = (int64_t)frame * Hin * Win;
-  const uint32_t fbytes = (uint32_t)min((int64_t)0x7fffffff, (int64_t)Hin * Win * p.lda * 2);
+  const uint32_t fbytes = (uint32_t)min((int64_t)0x7fffffff, (int64_t)nfr * Hin * Win * p.lda * 2);
   const auto rsA = pp_make_rsrc((const f16*)p.A + fpix * p.lda, fbytes);
   const auto rsW = pp_make_rsrc(p.W, 0xffffffffu);
   const auto rsW2 = pp_make_rsrc(TWO ? p.W2 : p.W, 0xffffffffu);
@@ -88,10 +94,17 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
   for (int s = 0; s < NPT; ++s) {
     const int j = (s * 8 + wave) * 16 + (lane >> 2);
     const int pr = j / PW, pc = j - pr * PW;
+    if constexpr (W8) {
+      const int fr = pr / 10, y = pr - fr * 10 - 1, x = pc - 1;
+      const bool ok = (j < PR) && (fr < nfr) && ((unsigned)y < 8u) && ((unsigned)x < 8u);
+      const int cl = (lane & 3) ^ (((j >> 2) & 1) << 1);
+      voffA[s] = ok ? (uint32_t)((((fr * 8 + y) * 8 + x) * p.lda + cl * 8) * 2) : 0x80000000u;
+    } else {
     const int y = y0 - 1 + pr, x = x0 - 1 + pc;
     const bool ok = (j < PR) && (pc < TX + 2) && ((unsigned)y < (unsigned)Hin) && ((unsigned)x < (unsigned)Win);
     const int cl = (lane & 3) ^ ((j >> 2) & 1);       // patch image: chunk c of row j sits at c ^ ((j >> 2) & 1)
     voffA[s] = ok ? (uint32_t)(((y * Win + x) * p.lda + cl * 8) * 2) : 0x80000000u;   // past num_records: the DMA writes zeros
+    }
   }
   const uint32_t voffW = lane * 16;
   uint32_t wbase[CWHI];        // byte offset of this wave's weight pieces at (slice 0, tap 0)
@@ -133,14 +146,17 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
   const int w_rd = W_BASE + (wn * WN + l15) * 64 + (((pg ^ (l15 >> 2)) & 3) << 4);
   // patch row of this lane's pixel in fragment 0 at tap (0, 0); fragment mi / tap (dy, dx) add compile-time rows (multiples of 8, or 16)
   const int R0 = wm * WM;
-  const int jb0 = (R0 / TX) * PW + (R0 & (TX - 1)) + l15;
+  const int ir0 = (R0 >> 3) + (l15 >> 3);              // W8: image row of this lane's pixel, counted over the stacked frames
+  const int jb0 = W8 ? (ir0 + 2 * (ir0 >> 3)) * PW + (l15 & 7) : (R0 / TX) * PW + (R0 & (TX - 1)) + l15;
   int a_off[3];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
     const int jj = jb0 + dx;
-    a_off[dx] = jj * 64 + ((((jj >> 2) & 1) ^ pg) << 4);
+    a_off[dx] = jj * 64 + (((W8 ? ((jj >> 2) & 1) << 1 : (jj >> 2) & 1) ^ pg) << 4);
   }
-  auto frag_rows = [](const int mi) { return ((mi * 16) / TX) * PW + ((mi * 16) & (TX - 1)); };   // rows of fragment mi below fragment 0
+  // rows of fragment mi below fragment 0 (W8: two image rows per fragment, + the two halo rows of every frame boundary crossed; a wave tile
+  // starts at a multiple of 32 rows and is at most one frame, so the crossing count is mi >> 2)
+  auto frag_rows = [](const int mi) { return W8 ? (2 * mi + 2 * (mi >> 2)) * PW : ((mi * 16) / TX) * PW + ((mi * 16) & (TX - 1)); };
 
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -268,6 +284,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
   const int fbase = frame * Hout * Wout;
   const auto row_of = [&](const int mi) {
     const int R = wm * WM + mi * 16 + l15;
+    if constexpr (W8) return ((R >> 6) < nfr) ? fbase + R : -1;
     const int y = y0 + R / TX, x = x0 + (R & (TX - 1));
     return (y < Hout && x < Wout) ? fbase + y * Wout + x : -1;
   };
@@ -307,13 +324,16 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
 //    6 : 16 x 32, 80, 8 x 1,  64 x 80, 5 slots of  5 KiB       512-pixel tiles: half the weight bytes per FLOP of configuration 0
 //    7 : 8 x 32, 80, 8 x 1,   32 x 80, 6 slots of  5 KiB       256-pixel tiles x 80 channels (32^2 level: one block per CU)
 //    8 : 16 x 32, 128, 8 x 1, 64 x 128, 5 slots of 8 KiB       512-pixel tiles for N = 128 k
+//    9 : 4 frames of 8 x 8, 160, 4 x 2, 64 x 80, 5 slots       frame-stacked tiles (ty = 8 x frames, tx = 8): the 8^2 UNet level, K split
+//   10 : 2 frames of 8 x 8, 160, 4 x 2, 32 x 80, 6 slots
 struct R3Cfg { int ty, tx, bn; };
-constexpr int R3_NCFG = 9;
-const R3Cfg R3_CFG[R3_NCFG] = {{8, 32, 160}, {8, 16, 320}, {8, 32, 128}, {8, 32, 256}, {16, 16, 160}, {8, 16, 160}, {16, 32, 80}, {8, 32, 80}, {16, 32, 128}};
+constexpr int R3_NCFG = 11;
+const R3Cfg R3_CFG[R3_NCFG] = {{8, 32, 160}, {8, 16, 320}, {8, 32, 128}, {8, 32, 256}, {16, 16, 160}, {8, 16, 160}, {16, 32, 80}, {8, 32, 80}, {16, 32, 128},
+                               {32, 8, 160}, {16, 8, 160}};
 
 template <int TY, int TX, int BN, int NSW>
 constexpr int conv3r_lds() {
-  constexpr int PW = (TX + 2 + 7) & ~7, NPA = (PW * (TY + 2) + 15) / 16, NPT = (NPA + 7) / 8;
+  constexpr int PW = (TX + 2 + 7) & ~7, PH = TX == 8 ? (TY / 8) * 10 : TY + 2, NPA = (PW * PH + 15) / 16, NPT = (NPA + 7) / 8;
   return 2 * NPT * 8 * 1024 + NSW * BN * 64;
 }
 
@@ -326,9 +346,10 @@ int launch_conv3r_(const MgldIGemm* p, hipStream_t s, int splits) {
     attr_done = true;
   }
   const int frames = p->M / (p->Hout * p->Wout);
-  const int tiles_x = cdiv(p->Wout, TX), tiles_y = cdiv(p->Hout, TY);
+  constexpr bool W8 = (TX == 8);                   // frame-stacked tiles: TY / 8 frames per tile, tiles_x carries the frame count
+  const int tiles_x = W8 ? frames : cdiv(p->Wout, TX), tiles_y = W8 ? 1 : cdiv(p->Hout, TY);
   const int nh = p->Cin >> 5, hsplit = cdiv(nh, splits);
-  dim3 grid(frames * tiles_x * tiles_y, p->N / BN, SPLIT ? cdiv(nh, hsplit) : 1);
+  dim3 grid(W8 ? cdiv(frames, TY / 8) : frames * tiles_x * tiles_y, p->N / BN, SPLIT ? cdiv(nh, hsplit) : 1);
   static int forder = -2, noswap = -1;
   if (forder == -2) { const char* e = getenv("MGLD_CONV3R_ORDER"); forder = e ? atoi(e) : -1; }
   if (noswap < 0) { const char* e = getenv("MGLD_PP_NOSWAP"); noswap = e ? atoi(e) : 0; }
@@ -363,19 +384,24 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
   if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
   if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->out_f32 || p->bias_m || (p->Cin & 31)) return false;
   if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU)) return false;
-  if (p->Hout != p->Hin || p->Wout != p->Win || p->Wout < 16 || p->Hout < 8 || (p->M % (p->Hout * p->Wout))) return false;
+  const bool w8 = (p->Hout == 8 && p->Wout == 8);     // the 8^2 level: frame-stacked tiles (configurations 9, 10), K split only
+  if (p->Hout != p->Hin || p->Wout != p->Win || (!w8 && (p->Wout < 16 || p->Hout < 8)) || (p->M % (p->Hout * p->Wout))) return false;
+  if (w8 && p->W2) return false;
   if ((p->lda & 7) || (p->ldc & 7) || (((uintptr_t)p->C) & 15) || (p->R && ((p->ldr & 7) || (((uintptr_t)p->R) & 15)))) return false;
   if (p->W2 && ((((uintptr_t)p->W2) & 15) || !(p->w2_scale > 0.f))) return false;
   if ((p->bias && (((uintptr_t)p->bias) & 15)) || (p->rowvec && ((((uintptr_t)p->rowvec) & 15) || (p->ld_rowvec & 3)))) return false;
   if ((int64_t)p->Hin * p->Win * p->lda * 2 >= 0x7fffffffLL) return false;      // a frame must fit the descriptor's 31-bit range
-  auto fits = [&](int i) { return p->N % R3_CFG[i].bn == 0; };
+  auto fits = [&](int i) { return p->N % R3_CFG[i].bn == 0 && (R3_CFG[i].tx == 8) == w8; };
   const int frames = p->M / (p->Hout * p->Wout), cus = num_cus();
-  auto tiles_of = [&](int i) { return (int64_t)frames * cdiv(p->Hout, R3_CFG[i].ty) * cdiv(p->Wout, R3_CFG[i].tx) * (p->N / R3_CFG[i].bn); };
+  auto tiles_of = [&](int i) {
+    if (R3_CFG[i].tx == 8) return (int64_t)cdiv(frames, R3_CFG[i].ty / 8) * (p->N / R3_CFG[i].bn);
+    return (int64_t)frames * cdiv(p->Hout, R3_CFG[i].ty) * cdiv(p->Wout, R3_CFG[i].tx) * (p->N / R3_CFG[i].bn);
+  };
   // K split of configuration i: as many slabs as keep tiles x slabs within the chip (>= 2, at most one per two channel slices), workspace permitting
   auto splits_of = [&](int i) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("MGLD_CONV3R_SPLIT"); on = e ? atoi(e) : 1; }
-    if (!on || !(i == 4 || i == 5 || i == 8) || p->gn_part) return 1;
+    if (!on || !(i == 4 || i == 5 || i == 8 || i == 9 || i == 10) || p->gn_part) return 1;
     const int nh = p->Cin >> 5;
     int sp = (int)(cus / tiles_of(i));
     if (sp > nh / 2) sp = nh / 2;
@@ -407,7 +433,22 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
   if (p->N % 80 == 0) { take(6, most); take(0, most); take(7, most); take(5, most); }
   // few tiles, deep K (the 16^2 UNet level: 8 frames x 256 pixels x 1280 channels, K = 11520 .. 23040): the channel slices split over
   // grid.z so that tiles x slabs fill the chip once (profiles/r04_conv3r_split.txt)
-  if (bid < 0 && p->tune == 0 && p->Wout >= 16 && p->Hout >= 8 && (p->Cin >> 5) >= 8) {
+  if (bid < 0 && p->tune == 0 && w8 && (p->Cin >> 5) >= 8) {      // the 8^2 level (profiles/r04_conv3r_split.txt)
+    // env MGLD_CONV3R_W8 = 1: the planner takes them.  Default off: -10 % / -24 % per launch in isolation (34.4 -> 30.6 us at K = 11520,
+    // 54.4 -> 41.4 us at K = 23040), but no measurable change of the segment (708.9 vs 709.7 ms, A/B on one box): eight fp32 slabs + the
+    // reduction launch eat what the 256-class tiles gain.  tune = 40 / 41 / 59 / 60 select them per launch (tests, tools/igemm_bench.py)
+    static int on8 = -1;
+    if (on8 < 0) { const char* e = getenv("MGLD_CONV3R_W8"); on8 = e ? atoi(e) : 0; }
+    const bool deep = (p->Cin >> 5) >= 64;          // measured: 4-frame tiles win from Cin = 2048 up (46.5 -> 41.4 us at 2560), 2-frame tiles below
+    const int cand[2] = {deep ? 9 : 10, deep ? 10 : 9};
+    for (int k = 0; k < 2 && bid < 0 && on8; ++k) {
+      const int i = cand[k];
+      if (!fits(i)) continue;
+      const int sp = splits_of(i);
+      if (sp >= 2 && tiles_of(i) * sp >= most) { bid = i; *splits = sp; }
+    }
+  }
+  if (bid < 0 && p->tune == 0 && !w8 && p->Wout >= 16 && p->Hout >= 8 && (p->Cin >> 5) >= 8) {
     const int cand[3] = {4, 5, 8};                 // 256-pixel tiles x 160 channels x 4 slabs measured best at 8 frames x 16^2 x 1280
     for (int k = 0; k < 3 && bid < 0; ++k) {
       const int i = cand[k];
@@ -417,7 +458,7 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
     }
   }
   if (bid < 0 && p->tune == 30) {
-    const int pref[R3_NCFG] = {8, 3, 2, 6, 0, 7, 5, 1, 4};
+    const int pref[R3_NCFG] = {8, 3, 2, 6, 0, 7, 5, 1, 4, 9, 10};
     for (int k = 0; k < R3_NCFG && bid < 0; ++k) if (fits(pref[k])) bid = pref[k];
   }
   if (bid < 0) return false;
@@ -440,16 +481,19 @@ int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id, int splits) {
     case 5: return launch_conv3r<8, 16, 160, 4, 2, 6, true>(p, s, splits);
     case 6: return launch_conv3r<16, 32, 80, 8, 1, 5>(p, s, 1);
     case 7: return launch_conv3r<8, 32, 80, 8, 1, 6>(p, s, 1);
-    default: return launch_conv3r<16, 32, 128, 8, 1, 5, true>(p, s, splits);
+    case 8: return launch_conv3r<16, 32, 128, 8, 1, 5, true>(p, s, splits);
+    case 9: return launch_conv3r<32, 8, 160, 4, 2, 5, true>(p, s, splits);
+    default: return launch_conv3r<16, 8, 160, 4, 2, 6, true>(p, s, splits);
   }
 }
 
 // tiles per frame of configuration id (the row count of MgldIGemm.gn_part per frame)
-int conv3r_gn_chunks(const MgldIGemm* p, int id) { return cdiv(p->Hout, R3_CFG[id].ty) * cdiv(p->Wout, R3_CFG[id].tx); }
+int conv3r_gn_chunks(const MgldIGemm* p, int id) { return R3_CFG[id].tx == 8 ? 0 : cdiv(p->Hout, R3_CFG[id].ty) * cdiv(p->Wout, R3_CFG[id].tx); }
 
 void conv3r_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen) {
   static const int g[R3_NCFG][6] = {{8, 32, 160, 4, 2, 6}, {8, 16, 320, 2, 4, 4}, {8, 32, 128, 4, 2, 6}, {8, 32, 256, 2, 4, 5}, {16, 16, 160, 4, 2, 6},
-                                    {8, 16, 160, 4, 2, 6}, {16, 32, 80, 8, 1, 5}, {8, 32, 80, 8, 1, 6}, {16, 32, 128, 8, 1, 5}};
+                                    {8, 16, 160, 4, 2, 6}, {16, 32, 80, 8, 1, 5}, {8, 32, 80, 8, 1, 6}, {16, 32, 128, 8, 1, 5}, {32, 8, 160, 4, 2, 5},
+                                    {16, 8, 160, 4, 2, 6}};
   int id_, splits = 1;
   (void)conv3r_plan(p, &id_, &splits);
   snprintf(buf, buflen, "conv3r_kernel<%d, %d, %d, %d, %d, %d, %s, %s>", g[id][0], g[id][1], g[id][2], g[id][3], g[id][4], g[id][5], p->W2 ? "true" : "false",

@@ -589,6 +589,49 @@ def test_igemm_conv3x3_pingpong_ksplit(hip, cfg, n, cin, nt, h, w, epi, two):
     assert rel_l2(outs[0].float(), one.float()) < 3e-4
 
 
+@pytest.mark.parametrize("cfg,n,cin,nt,epi,split", [(9, 8, 1280, 8, 2, True), (10, 8, 1280, 8, 1, True), (9, 5, 320, 2, 0, True), (10, 3, 640, 1, 2, True),
+                                                    (9, 8, 64, 2, 1, False), (10, 2, 32, 1, 0, False), (10, 1, 2560, 8, 0, True)])
+def test_igemm_conv3x3_pingpong_frame_stacked(hip, cfg, n, cin, nt, epi, split):
+    """conv3r on the 8 x 8 level: tiles of 4 (configuration 9) or 2 (10) whole frames stacked (two image rows per fragment, frames that do
+    not exist masked), with and without the K split, against conv2d on the same fp16 operands and against conv3q; bit-repeatable"""
+    from mgld_vsr_amd.engine import tile_conv3p
+    hip.set_workspace(hip._test_ws)
+    h = w = 8
+    cout = nt * 160
+    x = h16(rnd(n, cin, h, w, seed=330))
+    wt = h16(rnd(cout, cin, 3, 3, seed=331, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=332)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    wk = tile_conv3p(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV), cin, False)
+    xt = _to_tok(x).to(DEV)
+    kw = dict(bias=b.to(DEV))
+    if epi == 1:
+        r = h16(rnd(n * h * w, cout, seed=333))
+        kw.update(resid=r.to(DEV), act=hip.ACT_SILU, alpha=0.5, beta=2.0)
+        ref = 0.5 * F.silu(ref) + 2.0 * _from_tok(r.double(), n, h, w)
+    elif epi == 2:
+        emb = rnd(n, cout, seed=334)
+        kw.update(rowvec=emb.to(DEV), rows_per_frame=h * w)
+        ref = ref + emb.double()[:, :, None, None]
+    tune = (50 if split else 31) + cfg
+    p = hip.MgldIGemm()
+    p.mode, p.M, p.N, p.K, p.batch, p.tap_inner, p.tune = hip.MODE_CONV3X3, n * h * w, cout, 9 * cin, 1, 2, tune
+    p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, 1, 1, 1, 0
+    p.lda, p.ldc = cin, cout
+    code = hip.igemm_config(p)
+    assert code % 1000000 == 600000 + cfg and (code // 1000000 >= 2) == (split and cin >= 128), code
+    common = dict(mode=hip.MODE_CONV3X3, conv=(cin, h, w, h, w, 1, 1, 1, 0), tap_inner=2, N=cout, K=9 * cin, **kw)
+    outs = [torch.full((n * h * w, cout), float("nan"), dtype=torch.half, device=DEV) for _ in range(3)]
+    for o in outs:
+        hip.igemm(xt, wk, o, tune=tune, **common)
+    old = torch.empty_like(outs[0])
+    hip.igemm(xt, wk, old, tune=5, **common)           # conv3q
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_l2(_from_tok(outs[0].cpu().double(), n, h, w), ref) < 1e-3
+    assert rel_l2(outs[0].float(), old.float()) < 5e-4
+
+
 def test_igemm_conv3x3_pingpong_race_screen(hip):
     """counted waits of the weight ring / patch double buffer: repeated launches of a deep-K problem give the same bits on every
     configuration, and those bits agree with conv3q's (same products, another summation order) to the fp16 output rounding"""

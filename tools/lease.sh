@@ -25,8 +25,10 @@ case "$recipe" in
     done | tee gpurun_out/ablate.log
     ;;
   c3split)    # conv3r K split on the 16^2 level: unit tests + A/B against conv3q's split (tune 0 = planner, 5 = conv3q variant, 54/55/58 = conv3r cfg 4/5/8 split)
-    timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "ksplit or conv3x3_pingpong" 2>&1 | tail -6 | tee gpurun_out/c3split_tests.log
+    timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "ksplit or frame_stacked or conv3x3_pingpong" 2>&1 | tail -6 | tee gpurun_out/c3split_tests.log
     timeout 600 python tools/igemm_bench.py conv --only conv16 --variants ${1:-0,5,54,55,58,35,39} --rounds 3 2>&1 | grep -v amdgpu.ids | tee gpurun_out/c3split.log | cut -c1-900
+    MGLD_CONV3R_W8=0 timeout 600 python tools/igemm_bench.py conv --only conv8 --variants 0 --rounds 3 2>&1 | grep -v amdgpu.ids | grep conv8 | sed "s/^/conv3q planner: /" | tee gpurun_out/c3w8.log | cut -c1-400
+    timeout 600 python tools/igemm_bench.py conv --only conv8 --variants 0,59,60,40,41 --rounds 3 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/c3w8.log | cut -c1-900
     ;;
   tconv)      # the temporal Conv3d: unit tests + microbench (implicit-GEMM kernel in both row orders against the ping-pong kernel)
     timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "tconv" 2>&1 | tail -15 | tee gpurun_out/tconv_tests.log
