@@ -335,6 +335,25 @@ def test_conv3p_planner_routes_the_unet_convolutions():
     assert hip.conv3p_applies(8, 256, 256, 128, 128) and hip.conv3p_applies(5, 512, 512, 90, 120) and hip.conv3p_applies(8, 512, 512, 64, 64, True)
     assert qcode(8, 1280, 1280, 8, 8) == 400006         # 8x8 level: one 8x8 tile per frame (split along the channel slices on a GPU)
     assert qcode(8, 320, 4, 64, 64) < 300000 and qcode(8, 64, 64, 8, 12) < 300000
+    # frame-stacked conv3r tiles of the 8 x 8 level: configurations 9 / 10 by tune only (the planner leaves the level to conv3q by default)
+    assert qcode(8, 1280, 1280, 8, 8, tune=40) == 600009 and qcode(8, 1280, 1280, 8, 8, tune=41) == 600010
+    assert qcode(8, 1280, 1280, 16, 16, tune=40) < 600000      # they take 8 x 8 frames only
+
+    # statistics output of the producer (MgldIGemm.gn_part): tiles per frame where the picked kernel writes it, 0 where it does not
+    def chunks(frames, cin, cout, h, w, tune=0, mode=hip.MODE_CONV3X3):
+        p = hip.MgldIGemm()
+        p.mode, p.M, p.N, p.K, p.batch, p.tap_inner, p.tune = mode, frames * h * w, cout, (9 if mode == hip.MODE_CONV3X3 else 1) * cin, 1, 2 if mode == hip.MODE_CONV3X3 else 0, tune
+        if mode == hip.MODE_CONV3X3:
+            p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, 1, 1, 1, 0
+        p.lda, p.ldc, p.ldw = cin, cout, p.K
+        return hip.lib().mgld_igemm_gn_chunks(C.byref(p))
+    import ctypes as C
+    assert chunks(8, 320, 320, 64, 64) == 8                    # 16 x 32-pixel tiles: 2 x 4 per 64 x 64 frame
+    assert chunks(8, 640, 640, 32, 32) == 4                    # 8 x 32-pixel tiles
+    assert chunks(8, 1280, 1280, 16, 16) == 0                  # conv3q level
+    assert chunks(8, 1280, 1280, 8, 8, tune=40) == 0           # frame-stacked tiles span frames
+    assert chunks(8, 320, 320, 64, 64, mode=hip.MODE_LINEAR) == 0
+    assert hip.gn_apply_chunks(8, 4096, 320, 32) > 0 and hip.gn_apply_chunks(0, 4096, 320, 32) == 0
 
 
 def _spliter_case(ImageSpliterTh, g, sf, to_dev=lambda t: t):
