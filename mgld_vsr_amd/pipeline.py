@@ -352,7 +352,8 @@ class SegmentPool:
         # Entry offset between the workers.  Identical segments entered at the same instant run their launch sequences in lock-step — all in
         # the 64x64-level convolutions together, all in the latency-bound 8x8 level together — and there is nothing left to fill the
         # holes with; ANY offset of 2-26 ms breaks it: 670-675 -> 657 ms per segment at three in flight (profiles/r03_stagger.txt).
-        self.stagger_ms = float(os.environ.get("MGLD_STAGGER_MS", "4"))
+        # Round 4 (faster kernels): 20 ms is the best offset on two boxes, -0.5 .. -1.5 % against 4 ms (profiles/r04_stagger.txt).
+        self.stagger_ms = float(os.environ.get("MGLD_STAGGER_MS", "20"))
         self.last_latency_ms = {}     # slot -> GPU-side latency of that job in the last _drive call (hipEvent pair on the worker's stream)
         self.closed = False
         for t in self._threads:
