@@ -41,7 +41,7 @@ def _keys(module):
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
     """include/mgld_hip.h is a plain-C header: compile a probe with gcc that prints sizeof / offsetof of every field of the
-    two argument structs and compare with the ctypes mirror in mgld_vsr_amd/hip.py (the binding a maintainer would write)."""
+    argument structs and compare with the ctypes mirror in mgld_vsr_amd/hip.py (the binding a maintainer would write)."""
     import ctypes
     import shutil
     import subprocess
@@ -50,7 +50,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     if gcc is None:
         pytest.skip("no C compiler on this box")
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "mgld_hip.h"', "int main(void) {"]
-    for name, cls in (("MgldIGemm", hip.MgldIGemm), ("MgldAttn", hip.MgldAttn)):
+    structs = (("MgldIGemm", hip.MgldIGemm), ("MgldAttn", hip.MgldAttn), ("MgldGnStats", hip.MgldGnStats))
+    for name, cls in structs:
         lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
         for f, _ in cls._fields_:
             lines.append(f'  printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
@@ -60,7 +61,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     exe = tmp_path / "probe"
     subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
-    for name, cls in (("MgldIGemm", hip.MgldIGemm), ("MgldAttn", hip.MgldAttn)):
+    for name, cls in structs:
         assert int(got[name]) == ctypes.sizeof(cls)
         for f, _ in cls._fields_:
             assert int(got[f"{name}.{f}"]) == getattr(cls, f).offset, (name, f)
