@@ -285,6 +285,7 @@ class VSRPipeline:
             n0 = torch.randn_like(init_latent) if n0 is None else n0.to(eng.device)
             t = torch.full((T,), 999, dtype=torch.long, device=eng.device)
             x_T = m.q_sample_respace(init_latent, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, n0)
+        self.last_init_latent = init_latent     # (tests: the struct-cond latent the sampler was handed, next to its output)
         kw = dict(cond=ctx, struct_cond=init_latent, guidance_scale=guidance_scale, flows=flows, masks=masks, batch_size=1,
                   timesteps=self.ddpm_steps, time_replace=self.ddpm_steps, x_T=x_T, noise=noise.get("steps"), use_graph=use_graph)
         if tile is None:

@@ -189,7 +189,7 @@ def main(argv=None):
                                               return_latents=True, noise=nz)
                 latents.append(lat_)
                 if CAPTURE is not None:
-                    CAPTURE.append({"flows": fl, "masks": mk, "x0": lat_})
+                    CAPTURE.append({"flows": fl, "masks": mk, "x0": lat_, "lat": getattr(pipe, "last_init_latent", None)})
                     if FLOW_HOOK is not None:
                         CAPTURE[-1]["own_flows"], CAPTURE[-1]["own_masks"] = own
                 return out_

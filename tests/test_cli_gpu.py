@@ -161,6 +161,7 @@ def test_cli_reproduces_the_reference_script_at_the_production_schedule(tmp_path
          "mask_flips": float(np.mean(c0["own_masks"][0].cpu().numpy() != g["p0_fo"]) + np.mean(c0["own_masks"][1].cpu().numpy() != g["p0_bo"]))}
     for c in range(4):
         m[f"x0_patch{c}"] = rel(cli.CAPTURE[c]["x0"].cpu().numpy(), g[f"p{c}_x0"])
+        m[f"lat_patch{c}"] = rel(cli.CAPTURE[c]["lat"].cpu().numpy(), g[f"p{c}_lat"])      # the struct-cond latent (first-stage encode of the patch)
     hr = np.stack([np.asarray(Image.open(tmp_path / "out" / "seq0" / f"{k:04d}.png").convert("RGB")) for k in range(Tn)])
     assert hr.shape == g["hr_u8"].shape and hr.dtype == np.uint8
     d = hr.astype(np.int32) - g["hr_u8"].astype(np.int32)
@@ -175,6 +176,7 @@ def test_cli_reproduces_the_reference_script_at_the_production_schedule(tmp_path
     # frames — what the script writes — to 1e-3 and one level; the sampled latents of these smooth frames to ~1.8e-3 (measured 1.03e-3 ..
     # 1.80e-3 over the four patches, with the reference's own flows on patch 0 as well as with this build's: it is the sampler's fp16
     # arithmetic, not RAFT's; the random-texture workload fixtures sit at 5.5e-4 on the same schedule, test_nets_gpu work_*_S50)
+    assert max(m[f"lat_patch{c}"] for c in range(4)) < 1.2e-3, m        # struct-cond latent (first-stage encode): 9.7e-4 on every patch
     assert max(m[f"x0_patch{c}"] for c in range(4)) < 2.2e-3, m
     assert m["hr_rel_l2"] < 1e-3 and m["hr_max_abs_lsb"] <= 1, m
 
