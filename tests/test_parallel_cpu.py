@@ -83,6 +83,8 @@ def _shard_worker(rank, world, port, ret):
     x = torch.randn(T, hw, C, generator=g)
     w = torch.randn(3, C, C, generator=g)
     sh = parallel.FrameShard(T, rank, world)
+    parallel.DistComm.measure = True          # exchange accounting (bytes + time per call: what bench.py prints beside comm_plan)
+    parallel.DistComm.report()
     xl = sh.local(x).reshape(sh.F * hw, C).contiguous()
     # temporal conv on a halo-extended copy, exactly as Engine.tconv3 lays it out
     ext = torch.empty((sh.F + 2) * hw, C)
@@ -96,7 +98,9 @@ def _shard_worker(rank, world, port, ret):
     buf = torch.full((T, 1), -1.0)     # caller-owned destination (what the graph pieces of a sharded step use): filled in place
     ids = sh.all_gather(torch.arange(sh.f0, sh.f1, dtype=torch.float32).reshape(sh.F, 1), out=buf)
     ok_order = ids is buf and ids.flatten().tolist() == list(range(T))
-    ret[rank] = (bool(ok_conv), bool(ok_order), float(ext[:hw].abs().sum()), float(ext[(sh.F + 1) * hw:].abs().sum()))
+    rep = parallel.DistComm.report()
+    parallel.DistComm.measure = False
+    ret[rank] = (bool(ok_conv), bool(ok_order), float(ext[:hw].abs().sum()), float(ext[(sh.F + 1) * hw:].abs().sum()), rep)
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
@@ -109,8 +113,9 @@ def test_frame_shard_halo_and_gather(world):
     ret = mgr.dict()
     mp.spawn(_shard_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
-        ok_conv, ok_order, left, right = ret[r]
+        ok_conv, ok_order, left, right, rep = ret[r]
         assert ok_conv and ok_order
+        assert rep["calls"] == 3 and rep["bytes"] > 0 and rep["ms"] >= 0.0, rep      # one halo exchange + two all-gathers were logged
         assert (left == 0.0) == (r == 0)              # zero padding only at the two ends of the clip
         assert (right == 0.0) == (r == world - 1)
 
