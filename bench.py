@@ -56,6 +56,11 @@ def parse():
                          "latency-bound stretches of the others: same result per segment (tested bit for bit), higher frames/s, "
                          "proportionally longer per-segment latency.  0 (default) = 3 up to 8 x 512^2 frames per segment, 2 up to twice "
                          "that, else 1 (arena memory)")
+    ap.add_argument("--clips", type=int, default=1,
+                    help="independent segments batched as CLIPS of one pass (round 5): a step runs `clips` segments of --frames frames through "
+                         "ONE encode / sampling / decode pass (the UNet sees clips x frames frames per launch, each clip with its own temporal "
+                         "windows, flows and noise), so the low-resolution levels and the projections get clips x the rows per launch.  The "
+                         "result of every clip is what it produces alone (tested).  Default scheduling: see --inflight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-one-at-a-time", action="store_true", help="skip the second scheduling leg (profiling runs of the segments in flight)")
@@ -108,6 +113,18 @@ def build_pipeline(args):
 
 
 def make_inputs(pipe, args, rank):
+    """inputs of one step: `clips` independent segments (own frames / noise / flows each) concatenated along the frame axis"""
+    if args.clips > 1:
+        one = argparse.Namespace(**dict(vars(args), clips=1))
+        parts = [make_inputs(pipe, one, rank + 100003 * i) for i in range(args.clips)]
+        frames = torch.cat([p[0] for p in parts])
+        noise = {"posterior": torch.cat([p[1]["posterior"] for p in parts]), "x_T": torch.cat([p[1]["x_T"] for p in parts]),
+                 "steps": torch.cat([p[1]["steps"] for p in parts], 1)}
+        flows = masks = None
+        if parts[0][2] is not None:
+            flows = tuple(torch.cat([p[2][j] for p in parts]) for j in range(2))
+            masks = tuple(torch.cat([p[3][j] for p in parts]) for j in range(2))
+        return frames, noise, flows, masks
     from mgld_vsr_amd import synth
     T, S, H = args.frames, args.ddpm_steps, args.size
     dev = pipe.engine().device
@@ -428,15 +445,19 @@ def main():
         shard = parallel.TileShard(n_tiles, rank, world)
         kw = dict(flows=flows, masks=masks, noise=noise, tile=TILE, use_graph=GRAPH, tile_shard=shard)
 
+    def own_flows(p, fr):        # --raft: the flows of every clip from its own frames (one RAFT batch per clip, as the script does per segment)
+        est = [p.estimate_flows(fr[i * args.frames:(i + 1) * args.frames]) for i in range(args.clips)]
+        return tuple(torch.cat([e[0][j] for e in est]) for j in range(2)), tuple(torch.cat([e[1][j] for e in est]) for j in range(2))
+
     def step():
         if args.raft and args.guidance:
-            kw["flows"], kw["masks"] = pipe.estimate_flows(frames)
+            kw["flows"], kw["masks"] = own_flows(pipe, frames)
         return pipe.run_segment(frames, **kw)
 
     if args.inflight > 0:
         inflight = args.inflight
     else:
-        px = args.frames * args.size * args.size
+        px = args.clips * args.frames * args.size * args.size
         inflight = 3 if px <= 8 * 512 * 512 else (2 if px <= 16 * 512 * 512 else 1)
     if shard is not None:
         inflight = 1                          # the sharded modes spread ONE segment over the ranks
@@ -453,7 +474,7 @@ def main():
         def seg(pipe_i, j):                        # segment j on the instance that owns its inputs (j % inflight); --raft: the flows
             fr, nz, fl, mk = ins[j % inflight]     # are estimated inside the segment, as in step()
             if args.raft and args.guidance:
-                fl, mk = pipe_i.estimate_flows(fr)
+                fl, mk = own_flows(pipe_i, fr)
             return pipe_i.run_segment(fr, flows=fl, masks=mk, noise=nz, tile=TILE, use_graph=GRAPH)
         for i in range(inflight):                 # warm-up one instance at a time, on ITS inputs
             pool.map_on(i, seg, [i] * args.warmup)
@@ -483,7 +504,7 @@ def main():
         dt1 = parallel.max_over_ranks(time.perf_counter() - t1)
         l1 = sorted(a.elapsed_time(b) for a, b in e_lat)
         pool.close()
-        one_at_a_time = None if args.no_one_at_a_time else {"value": round((1 if shard is not None else world) * args.frames * args.steps / dt1, 4), "ms_per_step": round(1e3 * dt1 / args.steps, 2),
+        one_at_a_time = None if args.no_one_at_a_time else {"value": round((1 if shard is not None else world) * args.clips * args.frames * args.steps / dt1, 4), "ms_per_step": round(1e3 * dt1 / args.steps, 2),
                          "segment_latency_ms": round(l1[len(l1) // 2], 1), "steps": args.steps}
     else:
         for _ in range(args.warmup):
@@ -511,7 +532,7 @@ def main():
     per_rank_ms = parallel.gather_floats(1e3 * dt_local / args.steps) if world > 1 else [round(1e3 * dt_local / args.steps, 2)]
     ms_per_step = 1e3 * dt / args.steps
     segs = 1 if shard is not None else world
-    fps = segs * args.frames * args.steps / dt
+    fps = segs * args.clips * args.frames * args.steps / dt
     res = {
         "metric": "HR frames/sec at 512^2, 50 DDPM steps", "value": round(fps, 4), "unit": "HR frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
@@ -520,8 +541,9 @@ def main():
                                f"{args.ddpm_steps} DDPM steps, random-init SD-2.1 UNet + struct-cond encoder + KL-VAE encode x2 "
                                f"+ temporal video decoder + AdaIN, flow-guided warp {'on' if args.guidance else 'off'}{', aggregation sampling 64/32' if args.tile else ''}; "
                                + ("one segment, frames sharded over the GPUs" if shard is not None else
-                                  ("one segment per GPU at a time" if inflight == 1 else f"independent segments, {inflight} in flight per GPU")),
-                   "frames_per_segment": args.frames,
+                                  ("one segment per GPU at a time" if inflight == 1 else f"independent segments, {inflight} in flight per GPU")
+                                  + (f", {args.clips} segments batched as clips of each pass" if args.clips > 1 else "")),
+                   "frames_per_segment": args.frames, "clips_per_pass": args.clips, "frames_per_step": args.clips * args.frames,
                    "parallelism": (f"tile-sharded x{world}" if args.tile_shard and shard is not None else f"frame-sharded x{world}")
                    if shard is not None else f"segment-parallel x{world}" + (f", {inflight} segments in flight per GPU" if inflight > 1 else ""),
                    "finite": ok,
@@ -534,7 +556,7 @@ def main():
                    "comm": comm},
         # per frame: the sampler's work scales with the latent tiles it evaluates (aggregation sampling: every 64x64 tile is one 512^2
         # frame's worth of UNet + struct-cond work), the VAE's with the pixels
-        "sustained_tflops": round(segs * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME * n_unet_tiles + (2 * GFLOP_ENC_PER_FRAME +
+        "sustained_tflops": round(segs * args.clips * args.frames * (args.ddpm_steps * GFLOP_STEP_PER_FRAME * n_unet_tiles + (2 * GFLOP_ENC_PER_FRAME +
                                                           GFLOP_DEC_PER_FRAME) * (args.size / 512.0) ** 2) / 1e3 / (dt / args.steps), 1),
     }
     # whole-segment algorithmic FLOP rate against the dense fp16 MFMA peak of the GPUs in use (the path is compute-bound:

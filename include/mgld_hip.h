@@ -338,27 +338,55 @@ int mgld_replicate_pad(const float* x, float* y, int planes, int h, int w, int o
 int mgld_to_uint8_hwc(const float* x, void* y, int n, int c, int H, int W, int h, int w, void* stream);
 
 
-/* ---- RAFT flow estimator pieces (basicsr/archs/raft_arch.py) ---------------------------------------
- * The encoders / update block run on mgld_igemm (general kh x kw taps) and the norm kernels; these are the rest. */
+/* ---- RAFT_SR flow estimator (basicsr/archs/raft_arch.py:668-807, called from ddpm.py:3404-3429) ------------
+ * Entirely fp32 (round 5): the flows feed a thresholded forward/backward consistency check (util_flow.py:114-136) and sub-pixel
+ * warps of the latents, and RAFT is < 0.1 % of a segment's arithmetic.  Activations are fp32 NHWC matrices [n*h*w, ld]. */
+/* Every nn.Conv2d of RAFT_SR (7x7 s2, 3x3 s1/s2, 1x1 s1/s2, 1x5, 5x1; raft_arch.py:95-97,216,246,383-389,430-434,354-355,471-473)
+ * and the all-pairs correlation matmul (:82-85, batched LINEAR form) as an implicit GEMM on the f32-input MFMA:
+ *   C[m][n] = post_relu( act( alpha * (sum_k A[m][k] * W[n][k] + bias[n]) ) + R[m][n] )
+ * m = (image, oy, ox) over n_img*Hout*Wout = M rows, k = (tap, channel); A is gathered from the NHWC input with zero padding.
+ * W: fp32 [N][kh*kw][Cin4], Cin4 = Cin rounded up to 4 (zero filled).  act: MGLD_ACT_NONE / RELU / SIGMOID / TANH.
+ * R (optional, leading dimension ldr) is added AFTER the activation; post_relu then clamps (ResidualBlock tail, :138).
+ * batch > 1 (kh = kw = 1 only): operand b starts at A + b*strideA, W + b*strideW, C (and R) + b*strideC (floats). */
+typedef struct MgldConvF32 {
+  const float* A;
+  const float* W;
+  const float* bias; /* [N] or NULL */
+  const float* R;    /* [M, ldr] or NULL */
+  float* C;
+  int64_t M;
+  int32_t N, Cin, lda, ldc, ldr;
+  int32_t Hin, Win, Hout, Wout, kh, kw, stride, pad_t, pad_l;
+  int32_t act, post_relu;
+  float alpha;
+  int32_t batch;
+  int64_t strideA, strideW, strideC;
+} MgldConvF32;
+int mgld_conv_f32(const MgldConvF32* p, void* stream);
+/* nn.InstanceNorm2d (no affine, eps 1e-5; raft_arch.py:115-119,211) on fp32 NHWC [n*hw, ldx] -> y, optional ReLU, optional
+ * ResidualBlock tail y = relu(skip + y) (:138).  fp64 statistics; `part` is scratch of n * mgld_instnorm_chunks(hw) * C * 2 doubles. */
+int mgld_instnorm_chunks(int hw);
+int mgld_instnorm_f32(const float* x, int ldx, double* part, const float* skip, int lds, float* y, int ldy, int n, int hw, int C,
+                      float eps, int relu, void* stream);
+/* [n,c,h,w] fp32 -> fp32 NHWC [n*hw, ld >= c], pad columns zeroed (the encoders' RGB input, :248-250) */
+int mgld_nchw_to_nhwc_f32(const float* x, float* y, int n, int c, int hw, int ld, void* stream);
 /* F.avg_pool2d(x, 2, stride=2) on fp32 planes [planes, h, w] -> [planes, h/2, w/2]  (correlation pyramid, :47-49) */
 int mgld_avgpool2(const float* x, float* y, int64_t planes, int h, int w, void* stream);
 /* CorrBlock.__call__ (:54-75): windowed bilinear lookup of the pyramid at coords [B,2,H,W] (pixel units, x then y);
- * levels[l] = fp32 [B*H*W, hs[l], ws[l]]; out fp16 [B*H*W, ldo], column l*(2r+1)^2 + i*(2r+1) + j samples
+ * levels[l] = fp32 [B*H*W, hs[l], ws[l]]; out fp32 [B*H*W, ldo], column l*(2r+1)^2 + i*(2r+1) + j samples
  * (cx/2^l + i - r, cy/2^l + j - r) with zeros outside (grid_sample, align_corners=True). */
 int mgld_corr_lookup(const float* const* levels, const int* hs, const int* ws, int nlev, const float* coords, int B, int H, int W,
-                     int radius, void* out, int ldo, void* stream);
-/* SepConvGRU arithmetic (:390-405), fp16 [M, *] views: rhx = cat([r*h, x]) from hx = cat([h, x]);  h = (1-z)*h + z*q */
-int mgld_gru_rh(const void* r, int ldr, const void* hx, int ldhx, void* rhx, int ldo, int64_t M, int Ch, int Cx, void* stream);
-int mgld_gru_gate(const void* z, int ldz, const void* q, int ldq, void* h, int ldh, int64_t M, int Ch, void* stream);
+                     int radius, float* out, int ldo, void* stream);
+/* SepConvGRU arithmetic (:390-405), fp32 [M, *] views: rhx = cat([r*h, x]) from hx = cat([h, x]);  h = (1-z)*h + z*q */
+int mgld_gru_rh(const float* r, int ldr, const float* hx, int ldhx, float* rhx, int ldo, int64_t M, int Ch, int Cx, void* stream);
+int mgld_gru_gate(const float* z, int ldz, const float* q, int ldq, float* h, int ldh, int64_t M, int Ch, void* stream);
 /* coords1 += delta (fp32 NHWC [B*HW, ldd] columns 0,1; NULL = no update); flow = coords1 - coords0 (fp32 NCHW), also
- * written as two fp16 columns at `mot` / `fin` (NULL to skip): the motion-feature tail and the flow-conv input (:444,:778-783) */
-int mgld_flow_update(float* coords1, const float* coords0, const float* delta, int ldd, float* flow, void* mot, int ldm, void* fin,
+ * written as two fp32 columns at `mot` / `fin` (NULL to skip): the motion-feature tail and the flow-conv input (:444,:778-783) */
+int mgld_flow_update(float* coords1, const float* coords0, const float* delta, int ldd, float* flow, float* mot, int ldm, float* fin,
                      int ldf, int B, int HW, void* stream);
-/* convex 8x upsampling (:720-731): mask fp16 NHWC [B*H*W, ldm >= 576] (already scaled by 0.25), flow fp32 [B,2,H,W] ->
+/* convex 8x upsampling (:720-731): mask fp32 NHWC [B*H*W, ldm >= 576] (already scaled by 0.25), flow fp32 [B,2,H,W] ->
  * out fp32 [B,2,8H,8W] */
-int mgld_convex_upsample(const float* flow, const void* mask, int ldm, float* out, int B, int H, int W, void* stream);
-/* y = relu(a + b), fp16 [M, C] views (ResidualBlock tail, :138) */
-int mgld_add_relu(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C, void* stream);
+int mgld_convex_upsample(const float* flow, const float* mask, int ldm, float* out, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -417,6 +417,21 @@ extern "C" int mgld_gn_chunks(int rows_per_frame) {
   return cdiv(rows_per_frame, rows_per_chunk_for(rows_per_frame));
 }
 
+// LDS of the kernels that keep [rows per pass][channel window][2] floats: a block of window Cw runs rpi(Cw) = 256 / (Cw / 8) row slots,
+// and rpi(Cw) * Cw is NOT monotonic in Cw — the last, narrower window of a ragged split can need more than the full ones
+// (C = 1280 in windows of 440: the 400-channel tail runs 5 slots x 400 = 2000 channel slots, the full windows 4 x 440 = 1760;
+// ADVICE round 4) — so the launch is sized for the larger of the two window widths it contains.
+static size_t row_slots_lds_one(int Cw) {
+  const int NV = Cw >> 3;
+  const int rpi = NV >= 256 ? 1 : 256 / NV;
+  return (size_t)rpi * Cw * 2 * sizeof(float);
+}
+static size_t row_slots_lds(int C, int Cb) {
+  const int last = C - (cdiv(C, Cb) - 1) * Cb;
+  const size_t a = row_slots_lds_one(Cb), b = row_slots_lds_one(last);
+  return a > b ? a : b;
+}
+
 // channel-window size: whole groups, a multiple of 8 channels, chosen so that about `want_blocks` blocks exist
 static int channel_window(int C, int groups, int64_t blocks_without_split, int want_blocks) {
   const int cg = C / groups;
@@ -440,9 +455,7 @@ extern "C" int mgld_gn_stats(const void* x, int frames, int rows, int C, int ld,
   const int rpc = rows_per_chunk_for(rows);
   const int chunks = cdiv(rows, rpc);
   const int Cb = channel_window(C, groups, (int64_t)chunks * frames, 512);
-  const int NV = Cb >> 3;
-  const int rpi = NV >= 256 ? 1 : 256 / NV;
-  const size_t shm = (size_t)rpi * Cb * 2 * sizeof(float);
+  const size_t shm = row_slots_lds(C, Cb);
   MGLD_REQUIRE(shm <= 64 * 1024, "gn_stats: LDS budget");
   hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, frames, cdiv(C, Cb)), dim3(256), shm, (hipStream_t)stream,
                      (const f16*)x, rows, C, ld, rpc, groups, Cb, gsums);
@@ -468,15 +481,10 @@ static dim3 apply_grid(int frames, int rows, int C, int groups, int* Cb) {
   return dim3(chunks, frames, cdiv(C, *Cb));
 }
 
-// dynamic LDS of the STATS variants: [rows per pass][channel window][2] floats
-static size_t apply_stats_lds(int Cb) {
-  const int NV = Cb >> 3;
-  const int rpi = NV >= 256 ? 1 : 256 / NV;
-  return (size_t)rpi * Cb * 2 * sizeof(float);
-}
+// dynamic LDS of the STATS variants: [rows per pass][channel window][2] floats (largest over the windows of the launch)
 // + the prologue's per-channel table when the input statistics are per-channel tile sums
-static size_t apply_lds(const MgldGnStats* st, int Cb, bool stats_out) {
-  const size_t a = stats_out ? apply_stats_lds(Cb) : 0, b = st->kind == MGLD_GN_CHANNEL_SUMS ? (size_t)2 * Cb * sizeof(float) : 0;
+static size_t apply_lds(const MgldGnStats* st, int C, int Cb, bool stats_out) {
+  const size_t a = stats_out ? row_slots_lds(C, Cb) : 0, b = st->kind == MGLD_GN_CHANNEL_SUMS ? (size_t)2 * Cb * sizeof(float) : 0;
   return a > b ? a : b;
 }
 
@@ -502,7 +510,7 @@ extern "C" int mgld_gn_apply2(const void* x, int ldx, const MgldGnStats* st, flo
   if (int rc = check_stats_in(st, rows, C)) return rc;
   int Cb;
   const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
-  const size_t shm = apply_lds(st, Cb, stats_out != nullptr);
+  const size_t shm = apply_lds(st, C, Cb, stats_out != nullptr);
   MGLD_REQUIRE(shm <= 48 * 1024, "gn_apply: LDS budget of the statistics tables");
   if (stats_out) {
     hipLaunchKernelGGL((gn_apply_kernel<false, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)x, ldx, st->sums, st->kind,
@@ -532,7 +540,7 @@ extern "C" int mgld_spade_apply2(const void* h, int ldh, const MgldGnStats* st, 
   if (int rc = check_stats_in(st, rows, C)) return rc;
   int Cb;
   const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
-  const size_t shm = apply_lds(st, Cb, stats_out != nullptr);
+  const size_t shm = apply_lds(st, C, Cb, stats_out != nullptr);
   MGLD_REQUIRE(shm <= 48 * 1024, "spade_apply: LDS budget of the statistics tables");
   if (stats_out) {
     hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)h, ldh, st->sums, st->kind,

@@ -323,7 +323,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
         """schedule steps per batched pass: at most STRUCTCOND_CHUNK and about 96 frames (bounds the arena of a pass)"""
         return max(1, min(self.STRUCTCOND_CHUNK, 96 // max(1, n_frames)))
 
-    HOIST_TABLE_BUDGET = 24 << 30   # bytes of HBM the hoisted struct-cond + SPADE tables of ONE window may take (288 GB per GPU)
+    HOIST_TABLE_BUDGET = 40 << 30   # bytes of HBM the hoisted struct-cond + SPADE tables of ONE window may take (288 GB per GPU)
 
     def _hoist_window(self, eng, lat_act, S):
         """schedule steps per hoisting window: the per-step tables (struct-cond features of every scale + the SPADE gamma|beta of
@@ -465,15 +465,17 @@ class LatentDiffusionVSRTextWT(nn.Module):
             hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], st["z"], st["noise_stride"])
             sh = eng.shard
             if sh is None:
-                hip.guidance(st["z"], st["ff"], st["fb"], st["fo"], st["bo"], st["coef"], st["step_idx"], st["gscale"], x,
-                             st["work"])
+                # one guidance chain per clip (independent segments batched as clips of this pass each carry their own flows)
+                Tn = self.num_frames
+                for ci, (ff, fb, fo, bo) in enumerate(st["guid"]):
+                    hip.guidance(st["z"][ci * Tn:(ci + 1) * Tn], ff, fb, fo, bo, st["coef"], st["step_idx"], st["gscale"],
+                                 x[ci * Tn:(ci + 1) * Tn], st["work"][ci])
             else:
                 # frame-sharded clip: the guidance chain couples neighbouring frames -> all-gather the (64 KiB/frame)
                 # latents, evaluate the tiny gradient on the whole clip on every rank, keep this rank's frames
                 zf = st["z_full"]
                 eng.collective(lambda: sh.all_gather(st["z"], out=zf))
-                hip.guidance(zf, st["ff"], st["fb"], st["fo"], st["bo"], st["coef"], st["step_idx"], st["gscale"],
-                             st["x_full"], st["work"])
+                hip.guidance(zf, *st["guid"][0], st["coef"], st["step_idx"], st["gscale"], st["x_full"], st["work"][0])
                 x.copy_(sh.local(st["x_full"]))
         else:
             hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], x, st["noise_stride"])
@@ -538,10 +540,17 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 use_graph = use_graph and sh.world == 1
             if flows is not None:
                 T_clip = T_total if sh is None else sh.T
-                assert T_clip == self.num_frames, "guidance expects one clip of num_frames frames"
-                st["ff"], st["fb"], st["fo"], st["bo"] = self._flows_to_device(eng, flows, masks)
+                Tn = self.num_frames
+                # the reference guides ONE clip (b = 1: its p_sample cannot broadcast the t == 0 mask for b > 1, ddpm.py:4348); several
+                # independent segments batched as clips of one pass (pipeline.run_segment with k * num_frames frames) are k such
+                # problems: flows / masks carry a leading clip dimension, every clip runs its own chain
+                nclips = T_clip // Tn
+                assert T_clip % Tn == 0 and (sh is None or nclips == 1), "guidance expects whole clips of num_frames frames"
+                assert flows[0].shape[0] == nclips, f"flows carry {flows[0].shape[0]} clips, the sample has {nclips}"
+                st["guid"] = [self._flows_to_device(eng, tuple(f[i:i + 1] for f in flows), tuple(mk[i:i + 1] for mk in masks))
+                              for i in range(nclips)]
                 st["z"] = torch.empty_like(x)
-                st["work"] = torch.empty(hip.guidance_work_bytes(T_clip, c, h, w), dtype=torch.uint8, device=dev)
+                st["work"] = [torch.empty(hip.guidance_work_bytes(Tn, c, h, w), dtype=torch.uint8, device=dev) for _ in range(nclips)]
                 if sh is not None:
                     st["x_full"] = torch.empty((T_clip, c, h, w), device=dev)
                     st["z_full"] = torch.empty((T_clip, c, h, w), device=dev)

@@ -64,8 +64,8 @@ EXPORTS = [
     "mgld_adain", "mgld_wavelet_reconstruction", "mgld_init_latent", "mgld_to01",
     "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize", "mgld_copy_step",
     "mgld_resize_bicubic", "mgld_resize_bilinear_crop", "mgld_reflect_pad", "mgld_replicate_pad", "mgld_to_uint8_hwc",
+    "mgld_conv_f32", "mgld_instnorm_chunks", "mgld_instnorm_f32", "mgld_nchw_to_nhwc_f32",
     "mgld_avgpool2", "mgld_corr_lookup", "mgld_gru_rh", "mgld_gru_gate", "mgld_flow_update", "mgld_convex_upsample",
-    "mgld_add_relu",
 ]
 
 
@@ -679,7 +679,73 @@ def to_uint8_hwc(x, h=None, w=None):
     return y
 
 
-# ---- RAFT pieces ------------------------------------------------------------------------------------------------------
+# ---- RAFT_SR (all fp32) -------------------------------------------------------------------------------------------------
+class MgldConvF32(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int64),
+        ("N", C.c_int32), ("Cin", C.c_int32), ("lda", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("act", C.c_int32), ("post_relu", C.c_int32),
+        ("alpha", C.c_float), ("batch", C.c_int32),
+        ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
+    ]
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"RAFT kernels take fp32 tensors, got {t.dtype}")
+
+
+def conv_f32(a, w, out, n, hin, win, cin, ksize=(1, 1), stride=1, pad=(0, 0), bias=None, act=ACT_NONE, alpha=1.0, resid=None,
+             post_relu=False, batch=1, strideA=0, strideW=0, strideC=0, n_out=None):
+    """fp32 implicit-GEMM convolution (mgld_conv_f32): a [n*hin*win, lda] NHWC view, w [N, kh*kw*Cin4] (pack_conv_f32),
+    out [n*ho*wo, ldc] view.  batch > 1: LINEAR only, the operands of batch b start b*stride{A,W,C} floats further."""
+    _req_cuda(a, w, out, bias, resid)
+    _f32(a, w, out, bias, resid)
+    kh, kw = ksize
+    ho = (hin + 2 * pad[0] - kh) // stride + 1
+    wo = (win + 2 * pad[1] - kw) // stride + 1
+    p = MgldConvF32()
+    p.A, p.W, p.C, p.bias, p.R = a.data_ptr(), w.data_ptr(), out.data_ptr(), _p(bias).value, _p(resid).value
+    p.M, p.N, p.Cin = n * ho * wo, n_out or w.shape[0], cin
+    assert w.shape[1] == kh * kw * ((cin + 3) // 4 * 4), (w.shape, ksize, cin)
+    assert batch > 1 or out.shape[0] == p.M, (out.shape, p.M)
+    p.lda, p.ldc, p.ldr = _ld(a), _ld(out), _ld(resid) if resid is not None else 0
+    p.Hin, p.Win, p.Hout, p.Wout, p.kh, p.kw, p.stride, p.pad_t, p.pad_l = hin, win, ho, wo, kh, kw, stride, pad[0], pad[1]
+    p.act, p.post_relu, p.alpha, p.batch = act, int(post_relu), alpha, batch
+    p.strideA, p.strideW, p.strideC = strideA, strideW, strideC
+    _chk(lib().mgld_conv_f32(C.byref(p), stream_ptr()), "conv_f32")
+    return out
+
+
+def instnorm_chunks(hw):
+    return int(lib().mgld_instnorm_chunks(int(hw)))
+
+
+def instnorm_f32(x, part, out, n, hw, eps, relu, skip=None):
+    """InstanceNorm2d (no affine) on fp32 NHWC [n*hw, C] (+ ReLU, + relu(skip + y)); part: fp64 scratch [n, instnorm_chunks(hw), C, 2]"""
+    _req_cuda(x, part, out, skip)
+    _f32(x, out, skip)
+    assert part.dtype == torch.float64 and part.numel() >= n * instnorm_chunks(hw) * x.shape[1] * 2
+    _chk(lib().mgld_instnorm_f32(_p(x), _ld(x), _p(part), _p(skip), _ld(skip) if skip is not None else 0, _p(out), _ld(out), n, hw,
+                                 x.shape[1], C.c_float(eps), int(relu), stream_ptr()), "instnorm_f32")
+    return out
+
+
+def nchw_to_nhwc_f32(x, out):
+    """x fp32 [n,c,h,w] -> out fp32 [n*h*w, ld] (columns >= c zeroed)"""
+    _req_cuda(x, out)
+    _f32(x, out)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    assert out.is_contiguous() and out.shape[0] == n * h * w
+    _chk(lib().mgld_nchw_to_nhwc_f32(_p(x), _p(out), n, c, h * w, out.shape[1], stream_ptr()), "nchw_to_nhwc_f32")
+    return out
+
+
 def avgpool2(x):
     """x fp32 [planes, h, w] -> [planes, h//2, w//2]"""
     _req_cuda(x)
@@ -690,8 +756,9 @@ def avgpool2(x):
 
 
 def corr_lookup(levels, coords, radius, out):
-    """levels: list of fp32 [B*H*W, h_l, w_l]; coords fp32 [B,2,H,W]; out fp16 [B*H*W, >= nlev*(2r+1)^2]"""
+    """levels: list of fp32 [B*H*W, h_l, w_l]; coords fp32 [B,2,H,W]; out fp32 [B*H*W, >= nlev*(2r+1)^2]"""
     _req_cuda(coords, out, *levels)
+    _f32(coords, out, *levels)
     n = len(levels)
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in levels])
     hs = (C.c_int * n)(*[t.shape[1] for t in levels])
@@ -703,6 +770,7 @@ def corr_lookup(levels, coords, radius, out):
 
 def gru_rh(r, hx, rhx, Ch):
     _req_cuda(r, hx, rhx)
+    _f32(r, hx, rhx)
     _chk(lib().mgld_gru_rh(_p(r), _ld(r), _p(hx), _ld(hx), _p(rhx), _ld(rhx), C.c_int64(hx.shape[0]), Ch, hx.shape[1] - Ch,
                            stream_ptr()), "gru_rh")
     return rhx
@@ -710,12 +778,14 @@ def gru_rh(r, hx, rhx, Ch):
 
 def gru_gate(z, q, h):
     _req_cuda(z, q, h)
+    _f32(z, q, h)
     _chk(lib().mgld_gru_gate(_p(z), _ld(z), _p(q), _ld(q), _p(h), _ld(h), C.c_int64(h.shape[0]), h.shape[1], stream_ptr()), "gru_gate")
     return h
 
 
 def flow_update(coords1, coords0, delta, flow, mot=None, fin=None):
     _req_cuda(coords1, coords0, flow)
+    _f32(coords1, coords0, delta, flow, mot, fin)
     B, _, H, W = coords1.shape
     _chk(lib().mgld_flow_update(_p(coords1), _p(coords0), _p(delta), _ld(delta) if delta is not None else 0, _p(flow),
                                 _p(mot), _ld(mot) if mot is not None else 0, _p(fin), _ld(fin) if fin is not None else 0, B,
@@ -725,13 +795,8 @@ def flow_update(coords1, coords0, delta, flow, mot=None, fin=None):
 
 def convex_upsample(flow, mask):
     _req_cuda(flow, mask)
+    _f32(flow, mask)
     B, _, H, W = flow.shape
     out = torch.empty(B, 2, 8 * H, 8 * W, dtype=torch.float32, device=flow.device)
     _chk(lib().mgld_convex_upsample(_p(flow), _p(mask), _ld(mask), _p(out), B, H, W, stream_ptr()), "convex_upsample")
     return out
-
-
-def add_relu(a, b, y):
-    _req_cuda(a, b, y)
-    _chk(lib().mgld_add_relu(_p(a), _ld(a), _p(b), _ld(b), _p(y), _ld(y), C.c_int64(a.shape[0]), a.shape[1], stream_ptr()), "add_relu")
-    return y

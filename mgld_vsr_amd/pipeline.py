@@ -194,6 +194,12 @@ class VSRPipeline:
         flows/masks as the reference passes them to sample(); noise: optional dict with 'posterior' [T,4,h,w],
         'x_T' [T,4,h,w], 'steps' [S,T,4,h,w].  Returns HR frames [T,3,H,W] in [0,1] on the device.
 
+        frames may hold k * num_frames frames: k INDEPENDENT segments batched as clips of one pass (round 5; tile=None, unsharded).
+        Every network already treats its frame axis as clips of num_frames (the aggregation sampler batches its tiles that way), the
+        VAE / AdaIN / posterior arithmetic is per frame, and flows / masks then carry k on their leading axis (one guidance chain
+        per clip) — each clip's result is what it produces alone, while every launch sees k x the rows (the 16^2 / 8^2 levels and
+        the projections stop being launch-bound: bench.py --clips).
+
         shard: parallel.FrameShard — the T frames of this segment are split over the ranks (every rank passes the SAME
         full-clip arguments and works on frames [f0, f1)); temporal convolutions exchange one-frame halos, temporal
         attention and the guidance chain all-gather.  With gather=True every rank returns the whole clip."""

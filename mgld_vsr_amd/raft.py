@@ -3,17 +3,20 @@
 `compute_flow` (ddpm.py:3404-3429) runs this network on the quarter-resolution LR frames right before the hot path; with it
 the pipeline no longer needs precomputed flows.  The nn.Modules only own parameters under the reference's state_dict keys
 ('normal' model: fnet = BasicEncoder(256, instance), cnet = BasicEncoder(256, batch), BasicUpdateBlock with SepConvGRU);
-`forward` emits C-ABI launches: every convolution is an `mgld_igemm` (3x3 -> the DMA fast path where Cin % 64 == 0, the
-7x7 / 1x5 / 5x1 / strided 1x1 kernels -> the general-tap path), InstanceNorm = the GroupNorm kernels with groups == C,
-BatchNorm (eval) is folded into the preceding convolution when the weights are packed, the all-pairs correlation is a
-batched NT GEMM with fp32 output, and the pyramid lookup / GRU gates / convex upsampling are the kernels of raft.hip.
-Activations are fp16 NHWC, flow / coordinates / correlation volume fp32.  No CPU fallback.
+`forward` emits C-ABI launches.  Round 5: the whole network runs in **fp32** — the flows feed a thresholded occlusion check
+and sub-pixel warps of the latents, and with fp16 activations through the ten recurrent updates they sat 1.6-2.1e-3 from the
+reference's (one flipped mask pixel moved the sampled latents by 4.8e-3), while the network is < 0.1 % of a segment's
+arithmetic.  Every convolution and the all-pairs correlation is an `mgld_conv_f32` (implicit GEMM on the f32-input MFMA),
+InstanceNorm is `mgld_instnorm_f32` (fp64 sums; the ResidualBlock tail relu(x + y) rides in its apply pass), BatchNorm (eval)
+is folded into the preceding convolution when the weights are packed (ReLU, skip add and the tail ReLU in that convolution's
+epilogue), the pyramid lookup / GRU gates / convex upsampling are the kernels of raft.hip.  Activations are fp32 NHWC matrices.
+No CPU fallback.
 """
 import torch
 import torch.nn as nn
 
 from . import hip
-from .engine import Act, pack_conv, pack_conv1x1, pack_conv3x3
+from .engine import Act
 
 _EPS = 1e-5
 
@@ -62,39 +65,31 @@ class BasicEncoder(nn.Module):
         self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
 
     # ---- launches ----
-    def _conv_norm(self, eng, x, conv, norm, ksize, stride, pad, relu):
-        """conv -> norm -> (relu).  batch: folded, one launch; instance: conv, stats, apply."""
-        kh, kw = ksize
-        is3 = (kh, kw) == (3, 3)
+    def _conv_norm(self, eng, x, conv, norm, ksize, stride, pad, relu, skip=None):
+        """conv -> norm -> (relu) -> (relu(skip + .)).  batch: BatchNorm folded into the weights, everything in the convolution's
+        epilogue (one launch); instance: convolution, then statistics + apply (the apply pass carries ReLU and the skip tail)."""
         if self.norm_fn == "batch":
-            def pk(w, b, g, beta, mean, var):
-                wf, bf = _fold_bn(w, b, g, beta, mean, var)
-                return (pack_conv3x3(wf, x.C) if is3 else pack_conv(wf, x.C)), bf
-            wp, bp = eng.weight("cbn", (conv.weight, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var), pk)
-            act = hip.ACT_RELU if relu else hip.ACT_NONE
-            if is3:
-                return eng.conv3x3(x, wp, bp, conv.out_channels, stride=stride, act=act)
-            return eng.conv2d(x, wp, bp, conv.out_channels, ksize, stride, pad, act=act)
-        wp = eng.weight("c", (conv.weight,), lambda w: pack_conv3x3(w, x.C) if is3 else pack_conv(w, x.C))
-        b = eng.f32("b", conv.bias)
-        y = eng.conv3x3(x, wp, b, conv.out_channels, stride=stride) if is3 else eng.conv2d(x, wp, b, conv.out_channels, ksize,
-                                                                                       stride, pad)
-        C = conv.out_channels
-        ones, zeros = _affine_identity(eng, C)
-        return eng.gn_apply(y, eng.gn_stats(y, _EPS, groups=C), ones, zeros, 2 if relu else 0, groups=C)
-
-    def _block(self, eng, blk, x):
-        y = self._conv_norm(eng, x, blk.conv1, blk.norm1, (3, 3), blk.stride, (1, 1), True)
-        y = self._conv_norm(eng, y, blk.conv2, blk.norm2, (3, 3), 1, (1, 1), True)
-        if blk.downsample is not None:
-            x = self._conv_norm(eng, x, blk.downsample[0], blk.downsample[1], (1, 1), blk.stride, (0, 0), False)
-        out = eng.act(y.n, y.h, y.w, y.C)
-        hip.add_relu(x.v, y.v, out.v)
-        eng.launches += 1
+            wp, bp = eng.weight("cbn32", (conv.weight, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var),
+                                lambda *a: (lambda wf, bf: (pack_conv_f32(wf), bf))(*_fold_bn(*a)), torch.float32)
+            return _conv(eng, x, wp, bp, conv.out_channels, ksize, stride, pad, act=hip.ACT_RELU if relu else hip.ACT_NONE, resid=skip,
+                         post_relu=skip is not None)
+        y = _conv(eng, x, eng.weight("c32", (conv.weight,), pack_conv_f32, torch.float32), eng.f32("b", conv.bias), conv.out_channels,
+                  ksize, stride, pad)
+        part = eng.arena.alloc((y.n * hip.instnorm_chunks(y.hw) * y.C * 2,), torch.float64)
+        out = eng.act(y.n, y.h, y.w, y.C, torch.float32)
+        hip.instnorm_f32(y.v, part, out.v, y.n, y.hw, _EPS, relu, skip=None if skip is None else skip.v)
+        eng.launches += 2
         return out
 
+    def _block(self, eng, blk, x):
+        """ResidualBlock.forward (raft_arch.py:130-138)"""
+        y = self._conv_norm(eng, x, blk.conv1, blk.norm1, (3, 3), blk.stride, (1, 1), True)
+        if blk.downsample is not None:
+            x = self._conv_norm(eng, x, blk.downsample[0], blk.downsample[1], (1, 1), blk.stride, (0, 0), False)
+        return self._conv_norm(eng, y, blk.conv2, blk.norm2, (3, 3), 1, (1, 1), True, skip=x)
+
     def run(self, eng, x):
-        """x: Act [n,h,w,8] (RGB zero-padded to 8 channels) -> Act [n,h/8,w/8,output_dim] (caller applies tanh/relu splits)"""
+        """x: fp32 Act [n,h,w,4] (RGB + one zero column) -> Act [n,h/8,w/8,128] (the caller applies conv2 and the tanh / relu split)"""
         h = self._conv_norm(eng, x, self.conv1, self.norm1, (7, 7), 2, (3, 3), True)
         for layer in (self.layer1, self.layer2, self.layer3):
             for blk in layer:
@@ -102,8 +97,30 @@ class BasicEncoder(nn.Module):
         return h
 
 
-def _affine_identity(eng, C):
-    return eng.const(("in_affine", C), lambda: (torch.ones(C, device=eng.device), torch.zeros(C, device=eng.device)))
+def pack_conv_f32(w):
+    """[Cout, Cin, kh, kw] (or [Cout, Cin]) fp32 -> [Cout, kh*kw*Cin4], K index = (ky*kw+kx)*Cin4 + c, Cin4 = Cin rounded up to 4
+    (mgld_conv_f32's layout: every float4 of a row lies inside one tap)"""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, kh, kw = w.shape
+    c4 = (cin + 3) // 4 * 4
+    out = torch.zeros(cout, kh * kw, c4, dtype=torch.float32)
+    out[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    return out.reshape(cout, kh * kw * c4).contiguous()
+
+
+def _conv(eng, x, wp, bias, cout, ksize=(1, 1), stride=1, pad=(0, 0), act=hip.ACT_NONE, alpha=1.0, out=None, resid=None, post_relu=False,
+          cin=None):
+    """one mgld_conv_f32 launch on an fp32 Act; out: optional Act view (column slice of a concat buffer)"""
+    kh, kw = ksize
+    ho = (x.h + 2 * pad[0] - kh) // stride + 1
+    wo = (x.w + 2 * pad[1] - kw) // stride + 1
+    if out is None:
+        out = eng.act(x.n, ho, wo, cout, torch.float32)
+    hip.conv_f32(x.v, wp, out.v, x.n, x.h, x.w, cin or x.C, ksize, stride, pad, bias=bias, act=act, alpha=alpha,
+                 resid=None if resid is None else resid.v, post_relu=post_relu)
+    eng.launches += 1
+    return out
 
 
 class BasicMotionEncoder(nn.Module):
@@ -198,22 +215,29 @@ class RAFT_SR(nn.Module):
             raise ValueError(f"RAFT needs frames of at least {8 * 2 ** (self.corr_levels - 1)} px per side, got {ht}x{wd}")
         hw, M = H8 * W8, N * H8 * W8
 
-        # feature / context encoders
-        fm = self.fnet.run(eng, eng.from_nchw(torch.cat([ref, sup], 0), 8))
-        c2 = self.fnet.conv2
-        fmap = eng.linear(fm, eng.weight("c1", (c2.weight,), pack_conv1x1), eng.f32("b", c2.bias))          # [2M, 256]
-        cm = self.cnet.run(eng, eng.from_nchw(ref, 8))
+        # feature / context encoders (fp32 NHWC, RGB padded to 4 columns)
+        def nhwc(t):
+            a = eng.act(t.shape[0], H, W, 4, torch.float32)
+            hip.nchw_to_nhwc_f32(t, a.v)
+            eng.launches += 1
+            return a
+        pk = lambda tag, conv: eng.weight(tag, (conv.weight,), pack_conv_f32, torch.float32)
+        fm = self.fnet.run(eng, nhwc(torch.cat([ref, sup], 0)))
+        fmap = _conv(eng, fm, pk("c32", self.fnet.conv2), eng.f32("b", self.fnet.conv2.bias), 256)                 # [2M, 256]
+        cm = self.cnet.run(eng, nhwc(ref))
         k2 = self.cnet.conv2
-        hx = eng.arena.alloc((M, 384), torch.float16)          # cat([net(128), inp(128), motion(128)])
-        rhx = eng.arena.alloc((M, 384), torch.float16)
-        wk, bk = eng.weight("c1", (k2.weight,), pack_conv1x1), eng.f32("b", k2.bias)
-        eng.linear(cm.v, wk[:128], bk[:128], out=hx[:, 0:128], act=hip.ACT_TANH)      # net = tanh(.)   (:757-759)
-        eng.linear(cm.v, wk[128:], bk[128:], out=hx[:, 128:256], act=hip.ACT_RELU)    # inp = relu(.)
+        f32 = torch.float32
+        hx = eng.arena.alloc((M, 384), f32)          # cat([net(128), inp(128), motion(126), flow(2)])
+        rhx = eng.arena.alloc((M, 384), f32)
+        act_of = lambda v: Act(v, N, H8, W8)
+        wk, bk = pk("c32", k2), eng.f32("b", k2.bias)
+        _conv(eng, cm, wk[:128], bk[:128], 128, out=act_of(hx[:, 0:128]), act=hip.ACT_TANH)       # net = tanh(.)   (:757-759)
+        _conv(eng, cm, wk[128:], bk[128:], 128, out=act_of(hx[:, 128:256]), act=hip.ACT_RELU)     # inp = relu(.)
 
-        # all-pairs correlation (fp32) and its pyramid (:78-86, :47-51)
-        corr = torch.empty(N, hw, hw, dtype=torch.float32, device=dev)
-        hip.igemm(fmap.v[:M], fmap.v[M:], corr.view(N * hw, hw), M=hw, N=hw, K=256, batch=N, strideA=hw * 256,
-                  strideW=hw * 256, strideC=hw * hw, alpha=1.0 / 16.0)
+        # all-pairs correlation and its pyramid (:78-86, :47-51): per pair fmap1 [hw,256] . fmap2^T / sqrt(256)
+        corr = torch.empty(N, hw, hw, dtype=f32, device=dev)
+        hip.conv_f32(fmap.v[:M], fmap.v[M:], corr.view(N * hw, hw), 1, H8, W8, 256, alpha=1.0 / 16.0, batch=N, strideA=hw * 256,
+                     strideW=hw * 256, strideC=hw * hw, n_out=hw)
         eng.launches += 1
         levels = [corr.view(N * hw, H8, W8)]
         for _ in range(self.corr_levels - 1):
@@ -226,30 +250,25 @@ class RAFT_SR(nn.Module):
         ub = self.update_block
         enc, gru = ub.encoder, ub.gru
         D = self.corr_levels * (2 * self.corr_radius + 1) ** 2                                          # 324
-        cfeat = eng.arena.alloc((M, (D + 7) // 8 * 8), torch.float16)
-        cfeat.zero_()                                                                                    # pad columns stay 0
-        fin = eng.arena.alloc((M, 8), torch.float16)
+        cfeat = eng.arena.alloc((M, D), f32)
+        fin = eng.arena.alloc((M, 4), f32)                                                               # flow in columns 0, 1
         fin.zero_()
-        corflo = eng.arena.alloc((M, 256), torch.float16)
-        delta = torch.zeros(M, 8, dtype=torch.float32, device=dev)
-        zr = eng.arena.alloc((M, 256), torch.float16)
-        q = eng.arena.alloc((M, 128), torch.float16)
-        act_of = lambda v: Act(v, N, H8, W8)
+        corflo = eng.arena.alloc((M, 256), f32)
+        delta = eng.arena.alloc((M, 4), f32)
+        zr = eng.arena.alloc((M, 256), f32)
+        q = eng.arena.alloc((M, 128), f32)
 
-        w_c1 = eng.weight("c1", (enc.convc1.weight,), lambda w: pack_conv1x1(w, cfeat.shape[1]))
-        w_c2 = eng.weight("c3", (enc.convc2.weight,), pack_conv3x3)
-        w_f1 = eng.weight("c", (enc.convf1.weight,), lambda w: pack_conv(w, 8))
-        w_f2 = eng.weight("c3", (enc.convf2.weight,), pack_conv3x3)
-        w_cv = eng.weight("c3", (enc.conv.weight,), pack_conv3x3)
+        w_c1, w_c2, w_f1, w_f2, w_cv = (pk("c32", c) for c in (enc.convc1, enc.convc2, enc.convf1, enc.convf2, enc.conv))
         gw = {}
         for n_, ks in (("1", (1, 5)), ("2", (5, 1))):
             cz, cr, cq = getattr(gru, "convz" + n_), getattr(gru, "convr" + n_), getattr(gru, "convq" + n_)
-            gw[n_] = (eng.weight("zr", (cz.weight, cr.weight), lambda a, b: pack_conv(torch.cat([a, b], 0))),
-                      eng.weight("zrb", (cz.bias, cr.bias), lambda a, b: torch.cat([a, b], 0), torch.float32),
-                      eng.weight("c", (cq.weight,), pack_conv), eng.f32("b", cq.bias), ks)
+            gw[n_] = (eng.weight("zr32", (cz.weight, cr.weight), lambda a, b: pack_conv_f32(torch.cat([a, b], 0)), f32),
+                      eng.weight("zrb", (cz.bias, cr.bias), lambda a, b: torch.cat([a, b], 0), f32),
+                      pk("c32", cq), eng.f32("b", cq.bias), ks)
         fh, mk = ub.flow_head, ub.mask
-        w_h1, w_h2 = eng.weight("c3", (fh.conv1.weight,), pack_conv3x3), eng.weight("c3", (fh.conv2.weight,), pack_conv3x3)
-        w_m0, w_m2 = eng.weight("c3", (mk[0].weight,), pack_conv3x3), eng.weight("c1", (mk[2].weight,), pack_conv1x1)
+        w_h1, w_h2, w_m0, w_m2 = (pk("c32", c) for c in (fh.conv1, fh.conv2, mk[0], mk[2]))
+        b_ = lambda conv: eng.f32("b", conv.bias)
+        P1 = (1, 1)
 
         mask = None
         for it in range(iters):
@@ -258,27 +277,27 @@ class RAFT_SR(nn.Module):
             hip.corr_lookup(levels, coords1, self.corr_radius, cfeat)
             eng.launches += 2
             # motion encoder                                                                          (:436-444)
-            cor = eng.linear(cfeat, w_c1, eng.f32("b", enc.convc1.bias), act=hip.ACT_RELU)
-            eng.conv3x3(act_of(cor), w_c2, eng.f32("b", enc.convc2.bias), 192, out=act_of(corflo[:, 0:192]), act=hip.ACT_RELU)
-            flo = eng.conv2d(act_of(fin), w_f1, eng.f32("b", enc.convf1.bias), 128, (7, 7), 1, (3, 3), act=hip.ACT_RELU)
-            eng.conv3x3(flo, w_f2, eng.f32("b", enc.convf2.bias), 64, out=act_of(corflo[:, 192:256]), act=hip.ACT_RELU)
-            eng.conv3x3(act_of(corflo), w_cv, eng.f32("b", enc.conv.bias), 126, out=act_of(hx[:, 256:382]), act=hip.ACT_RELU)
+            cor = _conv(eng, act_of(cfeat), w_c1, b_(enc.convc1), 256, act=hip.ACT_RELU)
+            _conv(eng, cor, w_c2, b_(enc.convc2), 192, (3, 3), 1, P1, act=hip.ACT_RELU, out=act_of(corflo[:, 0:192]))
+            flo = _conv(eng, act_of(fin), w_f1, b_(enc.convf1), 128, (7, 7), 1, (3, 3), act=hip.ACT_RELU, cin=2)
+            _conv(eng, flo, w_f2, b_(enc.convf2), 64, (3, 3), 1, P1, act=hip.ACT_RELU, out=act_of(corflo[:, 192:256]))
+            _conv(eng, act_of(corflo), w_cv, b_(enc.conv), 126, (3, 3), 1, P1, act=hip.ACT_RELU, out=act_of(hx[:, 256:382]))
             # SepConvGRU: horizontal then vertical pass                                               (:390-405)
             for n_ in ("1", "2"):
                 wzr, bzr, wq, bq, ks = gw[n_]
                 pd = (0, 2) if ks == (1, 5) else (2, 0)
-                eng.conv2d(act_of(hx), wzr, bzr, 256, ks, 1, pd, out=act_of(zr), act=hip.ACT_SIGMOID)
+                _conv(eng, act_of(hx), wzr, bzr, 256, ks, 1, pd, act=hip.ACT_SIGMOID, out=act_of(zr))
                 hip.gru_rh(zr[:, 128:256], hx, rhx, 128)
-                eng.conv2d(act_of(rhx), wq, bq, 128, ks, 1, pd, out=act_of(q), act=hip.ACT_TANH)
+                _conv(eng, act_of(rhx), wq, bq, 128, ks, 1, pd, act=hip.ACT_TANH, out=act_of(q))
                 hip.gru_gate(zr[:, 0:128], q, hx[:, 0:128])
                 eng.launches += 2
             net = act_of(hx[:, 0:128])
-            # flow head (fp32 delta) and, on the last iteration only, the upsampling mask              (:481-485)
-            d1 = eng.conv3x3(net, w_h1, eng.f32("b", fh.conv1.bias), 256, act=hip.ACT_RELU)
-            eng.conv3x3(d1, w_h2, eng.f32("b", fh.conv2.bias), 2, out=Act(delta[:, :2], N, H8, W8), out_dtype=torch.float32)
+            # flow head and, on the last iteration only, the upsampling mask                           (:481-485)
+            d1 = _conv(eng, net, w_h1, b_(fh.conv1), 256, (3, 3), 1, P1, act=hip.ACT_RELU)
+            _conv(eng, d1, w_h2, b_(fh.conv2), 2, (3, 3), 1, P1, out=act_of(delta[:, :2]))
             if it == iters - 1:
-                m1 = eng.conv3x3(net, w_m0, eng.f32("b", mk[0].bias), 256, act=hip.ACT_RELU)
-                mask = eng.linear(m1, w_m2, eng.f32("b", mk[2].bias), alpha=0.25)      # .25 * mask(net): alpha * (acc + bias)
+                m1 = _conv(eng, net, w_m0, b_(mk[0]), 256, (3, 3), 1, P1, act=hip.ACT_RELU)
+                mask = _conv(eng, m1, w_m2, b_(mk[2]), 576, alpha=0.25)      # .25 * mask(net): alpha * (acc + bias)
         hip.flow_update(coords1, coords0, delta[:, :2], flow)
         up = hip.convex_upsample(flow, mask.v)
         eng.launches += 2

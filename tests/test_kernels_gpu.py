@@ -940,7 +940,10 @@ def test_spade_apply(hip):
     assert rel_l2(_from_tok(y.cpu().float(), frames, h, w), ref) < 1e-3
 
 
-@pytest.mark.parametrize("frames,C,h,w", [(2, 320, 64, 64), (3, 640, 32, 32), (1, 2560, 20, 24), (2, 128, 48, 40), (2, 960, 17, 23)])
+@pytest.mark.parametrize("frames,C,h,w", [(2, 320, 64, 64), (3, 640, 32, 32), (1, 2560, 20, 24), (2, 128, 48, 40), (2, 960, 17, 23),
+                                          # ragged channel split: the LAST window is narrower and runs MORE row slots than
+                                          # the full ones (C = 1280 -> windows of 440 + a 400 tail), the LDS must be sized for it
+                                          (5, 1280, 24, 24), (3, 1280, 32, 32), (7, 1280, 20, 20)])
 def test_groupnorm_stats_of_output(hip, frames, C, h, w):
     """mgld_spade_apply2 / mgld_gn_apply2 with stats_out: the output bits do not change, the per-group chunk sums add up to the moments of
     the stored output, and a GroupNorm fed by them agrees with one fed by mgld_gn_stats on that output"""

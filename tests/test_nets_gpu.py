@@ -638,8 +638,8 @@ def test_raft_flow_vs_oracle(hip):
     with torch.no_grad():
         rf, rb = oraft.compute_flow(net.state_dict(), lrs, iters=4)
     e = max(record("raft_flow_fwd", rel_l2(ff, rf)), record("raft_flow_bwd", rel_l2(fb, rb)))
-    # fp16 activations through the recurrent update (tolerance stated here: flows feed sub-pixel warps of 64x64 latents)
-    assert e < 2.4e-3
+    # round 5: the whole estimator runs in fp32 (f32-input MFMA): what is left is summation order (was 1.6e-3 with fp16 activations)
+    assert e < 1e-4
     record("raft_flow_max_abs_px", float((ff.cpu() - rf).abs().max()))
 
 
@@ -664,10 +664,10 @@ def test_pipeline_estimate_flows_vs_oracle(hip):
         r0, r1 = oflow.resize_flow(rf[0], H // 8, H // 8), oflow.resize_flow(rb[0], H // 8, H // 8)
         rfo, rbo = oflow.forward_backward_consistency_check(r1, r0)
     assert f0.shape == (1, Tn - 1, 2, H // 8, H // 8) and fo.shape == (1, Tn - 1, 1, H // 8, H // 8)
-    assert max(record("flowprep_fwd", rel_l2(f0[0], r0)), record("flowprep_bwd", rel_l2(f1[0], r1))) < 2.6e-3
-    # the occlusion masks are thresholded (0/1): only pixels sitting on the threshold may flip
+    assert max(record("flowprep_fwd", rel_l2(f0[0], r0)), record("flowprep_bwd", rel_l2(f1[0], r1))) < 1e-4
+    # the occlusion masks are thresholded (0/1): only pixels sitting on the threshold may flip — with fp32 flows none does here
     flips = float((fo[0, :, 0].cpu() != rfo).float().mean()) + float((bo[0, :, 0].cpu() != rbo).float().mean())
-    assert record("flowprep_mask_flip_fraction", flips) < 2.5e-4      # measured 1.2e-4 of the mask pixels
+    assert record("flowprep_mask_flip_fraction", flips) < 7e-5        # < 1 pixel of the 2 x 2 x 64 x 64 masks (fp16 RAFT: 1.2e-4)
 
 
 def test_text_tower_vs_oracle(hip):
@@ -717,3 +717,51 @@ def test_two_segments_in_flight_match_sequential(hip):
     for i in range(2):
         assert torch.equal(outs[i], alone[i])
     hip.set_workspace(hip._test_ws)
+
+
+def test_segments_batched_as_clips_match_alone(hip):
+    """bench.py --clips: k independent segments concatenated along the frame axis run as clips of ONE pass (encode, guided sampling with
+    one guidance chain per clip, video decode, AdaIN).  Every clip must come out as it does alone — up to the fp16 rounding of the
+    kernels the planner picks for k x the rows: two fp16 evaluations of these reduced 4-step nets sit 1.1-1.3e-3 from the fp32 oracle
+    each (sample_plain_guided), i.e. up to ~2e-3 from one another; a wrong clip boundary would show as 1e-1.  The structural check is
+    exact: permuting the clips permutes the result bit for bit."""
+    from mgld_vsr_amd.flowops import forward_backward_consistency_check
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    Tn, S, H, h, k = 3, 4, 128, 16, 3
+    cfgs = model_configs(Tn, unet_overrides=dict(model_channels=64, context_dim=64, semb_channels=64),
+                         struct_overrides=dict(model_channels=64, out_channels=64, num_heads=1),
+                         vae_overrides=dict(ch=32, resolution=H), context_dim=64)
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=S, configs=cfgs)
+    ins = []
+    for i in range(k):
+        x = synth.synth_tensor(f"clips/x{i}", (Tn, 3, H, H), 0.5).clamp(-1, 1)
+        noise = {"posterior": synth.synth_tensor(f"clips/np{i}", (Tn, 4, h, h)), "x_T": synth.synth_tensor(f"clips/n0{i}", (Tn, 4, h, h)),
+                 "steps": torch.stack([synth.synth_tensor(f"clips/n{i}_{j}", (Tn, 4, h, h)) for j in range(S)])}
+        ff, fb = (0.3 * synth.smooth_flow(f"clips/ff{i}", Tn - 1, h, h)).cuda(), (0.3 * synth.smooth_flow(f"clips/fb{i}", Tn - 1, h, h)).cuda()
+        fo, bo = forward_backward_consistency_check(fb, ff)
+        assert 0.05 < float(fo.mean()) < 0.95 or 0.05 < float(bo.mean()) < 0.95       # the guidance term is partly active
+        ins.append((x, noise, (ff[None], fb[None]), (fo[None, :, None], bo[None, :, None])))
+    alone = [pipe.run_segment(x, flows=fl, masks=mk, noise=nz, return_latents=True) for x, nz, fl, mk in ins]
+    alone = [(o.clone(), l.clone()) for o, l in alone]
+    xb = torch.cat([i[0] for i in ins])
+    nb = {"posterior": torch.cat([i[1]["posterior"] for i in ins]), "x_T": torch.cat([i[1]["x_T"] for i in ins]),
+          "steps": torch.cat([i[1]["steps"] for i in ins], 1)}
+    fl = tuple(torch.cat([i[2][j] for i in ins]) for j in range(2))
+    mk = tuple(torch.cat([i[3][j] for i in ins]) for j in range(2))
+    out, lat = pipe.run_segment(xb, flows=fl, masks=mk, noise=nb, return_latents=True)
+    assert out.shape == (k * Tn, 3, H, H) and lat.shape == (k * Tn, 4, h, h)
+    for i in range(k):
+        sl = slice(i * Tn, (i + 1) * Tn)
+        e_lat, e_out = rel_l2(lat[sl], alone[i][1]), rel_l2(out[sl], alone[i][0])
+        record(f"clips_vs_alone_latent_{i}", e_lat)
+        assert e_lat < 3e-3 and e_out < 2e-3, (i, e_lat, e_out)
+    # clips really are independent: swapping the ORDER of the clips permutes the result
+    perm = [2, 0, 1]
+    xb2 = torch.cat([ins[p][0] for p in perm])
+    nb2 = {"posterior": torch.cat([ins[p][1]["posterior"] for p in perm]), "x_T": torch.cat([ins[p][1]["x_T"] for p in perm]),
+           "steps": torch.cat([ins[p][1]["steps"] for p in perm], 1)}
+    fl2 = tuple(torch.cat([ins[p][2][j] for p in perm]) for j in range(2))
+    mk2 = tuple(torch.cat([ins[p][3][j] for p in perm]) for j in range(2))
+    out2 = pipe.run_segment(xb2, flows=fl2, masks=mk2, noise=nb2)
+    for q, p_ in enumerate(perm):
+        assert torch.equal(out2[q * Tn:(q + 1) * Tn], out[p_ * Tn:(p_ + 1) * Tn])

@@ -274,34 +274,111 @@ def test_corr_lookup_and_convex_upsample_vs_oracle(hip):
     coords = oraft.coords_grid(B, H, W) + torch.randn(B, 2, H, W, generator=g) * 2.5
     ref = cb(coords)                                                                  # [B, 324, H, W]
     levels = [p[:, 0].contiguous().cuda() for p in cb.pyramid]                        # [B*H*W, h_l, w_l]
-    out = torch.zeros(B * H * W, 328, dtype=torch.half, device="cuda")
+    out = torch.zeros(B * H * W, 324, dtype=torch.float32, device="cuda")
     hip.corr_lookup(levels, coords.cuda().contiguous(), 4, out)
-    got = out[:, :324].float().cpu().view(B, H, W, 324).permute(0, 3, 1, 2)
-    assert rel_l2(got, ref) < 1e-3                                                    # fp16 storage of the looked-up values
+    got = out.cpu().view(B, H, W, 324).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 1e-6                                                    # fp32 end to end (round 5)
     flow = torch.randn(B, 2, H, W, generator=g)
     mask = torch.randn(B, 576, H, W, generator=g)
-    up = hip.convex_upsample(flow.cuda().contiguous(), mask.permute(0, 2, 3, 1).reshape(B * H * W, 576).half().cuda().contiguous())
-    assert rel_l2(up.cpu(), oraft.upsample_flow(flow, mask.half().float())) < 1e-5
+    up = hip.convex_upsample(flow.cuda().contiguous(), mask.permute(0, 2, 3, 1).reshape(B * H * W, 576).cuda().contiguous())
+    assert rel_l2(up.cpu(), oraft.upsample_flow(flow, mask)) < 1e-6
 
 
 def test_gru_and_flow_update_kernels(hip):
     g = torch.Generator().manual_seed(6)
     M, Ch, Cx = 300, 128, 256
-    hx = torch.randn(M, Ch + Cx, generator=g).half().cuda()
-    r, z, q = (torch.rand(M, Ch, generator=g).half().cuda() for _ in range(3))
+    hx = torch.randn(M, Ch + Cx, generator=g).cuda()
+    r, z, q = (torch.rand(M, Ch, generator=g).cuda() for _ in range(3))
     rhx = torch.empty_like(hx)
     hip.gru_rh(r, hx, rhx, Ch)
-    assert torch.allclose(rhx[:, :Ch].float(), (r.float() * hx[:, :Ch].float()), atol=2e-3) and torch.equal(rhx[:, Ch:], hx[:, Ch:])
-    h0 = hx[:, :Ch].float().clone()
+    assert torch.allclose(rhx[:, :Ch], r * hx[:, :Ch], atol=1e-6) and torch.equal(rhx[:, Ch:], hx[:, Ch:])
+    h0 = hx[:, :Ch].clone()
     hip.gru_gate(z, q, hx[:, :Ch])
-    assert torch.allclose(hx[:, :Ch].float(), (1 - z.float()) * h0 + z.float() * q.float(), atol=2e-3)
+    assert torch.allclose(hx[:, :Ch], (1 - z) * h0 + z * q, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        hip.gru_gate(z.half(), q.half(), hx[:, :Ch].half())                      # the RAFT kernels are fp32 only
     B, H, W = 2, 5, 6
     c0 = torch.randn(B, 2, H, W, generator=g).cuda()
     c1 = c0 + 1.0
     d = torch.randn(B * H * W, 8, generator=g).cuda()
     flow = torch.empty_like(c0)
-    mot = torch.zeros(B * H * W, 8, dtype=torch.half, device="cuda")
+    mot = torch.zeros(B * H * W, 8, dtype=torch.float32, device="cuda")
     c1_ref = c1 + d[:, :2].reshape(B, H, W, 2).permute(0, 3, 1, 2)
     hip.flow_update(c1, c0, d[:, :2], flow, mot=mot[:, 6:8])
     assert torch.allclose(c1, c1_ref) and torch.allclose(flow, c1_ref - c0)
-    assert torch.allclose(mot[:, 6:8].float(), flow.permute(0, 2, 3, 1).reshape(-1, 2), atol=5e-3)
+    assert torch.equal(mot[:, 6:8], flow.permute(0, 2, 3, 1).reshape(-1, 2)) and float(mot[:, :6].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("geo", [
+    # n, h, w, cin, cout, ksize, stride, pad, act            (every convolution shape of RAFT_SR, raft_arch.py)
+    (2, 31, 29, 3, 64, (7, 7), 2, (3, 3), "none"),            # encoder stem: RGB padded to 4 columns, odd sizes
+    (2, 16, 20, 64, 96, (3, 3), 2, (1, 1), "relu"),           # strided ResidualBlock conv
+    (2, 16, 20, 64, 96, (1, 1), 2, (0, 0), "none"),           # downsample branch
+    (3, 9, 11, 384, 256, (1, 5), 1, (0, 2), "sigmoid"),       # SepConvGRU horizontal z|r
+    (3, 9, 11, 384, 128, (5, 1), 1, (2, 0), "tanh"),          # SepConvGRU vertical q
+    (3, 9, 11, 2, 128, (7, 7), 1, (3, 3), "relu"),            # flow conv: 2 used channels of a 4-column buffer
+    (1, 9, 11, 324, 256, (1, 1), 1, (0, 0), "relu"),          # correlation features (324 = 20 slices + 4)
+    (1, 9, 11, 256, 126, (3, 3), 1, (1, 1), "relu"),          # 126 output channels into a column slice
+    (1, 9, 11, 256, 2, (3, 3), 1, (1, 1), "none"),            # flow head
+])
+def test_conv_f32_vs_torch(hip, geo):
+    """mgld_conv_f32 (f32-input MFMA implicit GEMM) vs F.conv2d in fp64: fp32 round-off only"""
+    from mgld_vsr_amd.raft import pack_conv_f32
+    n, h, w, cin, cout, ks, st, pad, act = geo
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, *ks, generator=g) / (cin * ks[0] * ks[1]) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=st, padding=pad)
+    ref = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](1.5 * ref)
+    ho, wo = ref.shape[-2:]
+    ld_in = (cin + 3) // 4 * 4
+    xin = torch.zeros(n * h * w, ld_in + 4, device="cuda")
+    xin[:, :cin] = x.permute(0, 2, 3, 1).reshape(-1, cin).cuda()
+    out = torch.full((n * ho * wo, cout + 6), 7.0, device="cuda")
+    code = {"none": hip.ACT_NONE, "relu": hip.ACT_RELU, "sigmoid": hip.ACT_SIGMOID, "tanh": hip.ACT_TANH}[act]
+    hip.conv_f32(xin[:, :ld_in], pack_conv_f32(wt).cuda(), out[:, 2:2 + cout], n, h, w, cin, ks, st, pad, bias=b.cuda(), act=code, alpha=1.5)
+    got = out[:, 2:2 + cout].cpu().view(n, ho, wo, cout).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref.float()) < 2e-6
+    assert float((out[:, :2] - 7.0).abs().max()) == 0.0 and float((out[:, 2 + cout:] - 7.0).abs().max()) == 0.0     # slice only
+    # ResidualBlock tail in the epilogue: relu(skip + act(.))
+    skip = torch.randn(n * ho * wo, cout, generator=g).cuda()
+    out2 = torch.empty(n * ho * wo, cout, device="cuda")
+    hip.conv_f32(xin[:, :ld_in], pack_conv_f32(wt).cuda(), out2, n, h, w, cin, ks, st, pad, bias=b.cuda(), act=code, alpha=1.5, resid=skip,
+                 post_relu=True)
+    ref2 = torch.relu(ref.permute(0, 2, 3, 1).reshape(-1, cout).float() + skip.cpu())
+    assert rel_l2(out2.cpu(), ref2) < 2e-6
+
+
+def test_conv_f32_batched_correlation(hip):
+    """the all-pairs correlation (raft_arch.py:82-85) as the batched LINEAR form: per pair fmap1 [hw,256] . fmap2^T / 16"""
+    g = torch.Generator().manual_seed(12)
+    B, hw, D = 3, 15 * 17, 256
+    f = torch.randn(2 * B * hw, D, generator=g).cuda()
+    corr = torch.empty(B * hw, hw, device="cuda")
+    hip.conv_f32(f[:B * hw], f[B * hw:], corr, 1, 15, 17, D, alpha=1.0 / 16.0, batch=B, strideA=hw * D, strideW=hw * D, strideC=hw * hw,
+                 n_out=hw)
+    ref = torch.matmul(f[:B * hw].cpu().double().view(B, hw, D), f[B * hw:].cpu().double().view(B, hw, D).transpose(1, 2)) / 16.0
+    assert rel_l2(corr.cpu().view(B, hw, hw), ref.float()) < 2e-6
+
+
+@pytest.mark.parametrize("n,h,w,C", [(3, 64, 64, 64), (2, 17, 13, 96), (1, 8, 8, 128)])
+def test_instnorm_f32_vs_torch(hip, n, h, w, C):
+    """mgld_instnorm_f32 vs F.instance_norm (no affine, eps 1e-5) incl. ReLU and the relu(skip + y) tail; a channel with a large
+    mean (the fp64 sums are there for it)"""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, C, h, w, generator=g)
+    x[:, 5] += 300.0
+    skip = torch.randn(n, C, h, w, generator=g)
+    xin = x.permute(0, 2, 3, 1).reshape(-1, C).cuda().contiguous()
+    sk = skip.permute(0, 2, 3, 1).reshape(-1, C).cuda().contiguous()
+    part = torch.empty(n * hip.instnorm_chunks(h * w) * C * 2, dtype=torch.float64, device="cuda")
+    ref = F.instance_norm(x.double(), eps=1e-5)
+    for relu, use_skip in ((False, False), (True, False), (True, True)):
+        out = torch.empty_like(xin)
+        hip.instnorm_f32(xin, part, out, n, h * w, 1e-5, relu, skip=sk if use_skip else None)
+        r = torch.relu(ref) if relu else ref
+        if use_skip:
+            r = torch.relu(r + skip.double())
+        got = out.cpu().view(n, h, w, C).permute(0, 3, 1, 2)
+        assert float((got - r.float()).abs().max()) < 2e-4 and rel_l2(got, r.float()) < 2e-6

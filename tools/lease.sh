@@ -60,5 +60,16 @@ case "$recipe" in
   pmc)        # HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes) -> gpurun_out/pmc_traffic.json
     bash tools/pmc_traffic.sh
     ;;
+  r5a)        # round 5, first contact: fp32 RAFT kernels + network, clip batching, ragged GroupNorm windows; then clips vs in-flight A/B; then the x0 probe
+    timeout 900 python -m pytest tests/test_sampler_kernels_gpu.py tests/test_kernels_gpu.py tests/test_nets_gpu.py -q -x \
+      -k "conv_f32 or instnorm or corr_lookup or gru_and or groupnorm_stats_of_output or raft or estimate_flows or clips" 2>&1 | tail -25 | tee gpurun_out/r5a_tests.log
+    timeout 600 python -m pytest tests/test_cli_gpu.py -q -x -k "fixed_size_cli_reproduces_the_reference_script_at_the_production_schedule" 2>&1 | tail -25 | tee gpurun_out/r5a_cli.log
+    for cfg in "--inflight 3" "--clips 3 --inflight 1" "--clips 2 --inflight 2" "--clips 2 --inflight 1" "--inflight 1"; do
+      tag=$(echo "$cfg" | tr -d ' -')
+      timeout 400 python bench.py $cfg --steps 6 --warmup 2 --no-roofline --no-cpu-baseline --no-one-at-a-time 2> gpurun_out/r5a_bench_$tag.err | tail -1 > gpurun_out/r5a_bench_$tag.json
+      python -c "import json;d=json.load(open('gpurun_out/r5a_bench_$tag.json'));print('$cfg:',d['value'],'fps',d['ms_per_step'],'ms/step')" 2>&1 | tee -a gpurun_out/r5a_bench.log
+    done
+    for c in "$@"; do timeout 600 python tools/x0_probe.py $c 50 "default" 2>&1 | grep -v amdgpu.ids | tail -4 | tee -a gpurun_out/r5a_probe.log; done
+    ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac
