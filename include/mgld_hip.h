@@ -125,6 +125,8 @@ typedef struct MgldIGemm {
                              patch convolution today; 0: it does not, and a launch with gn_part set is refused).  The consumer passes
                              {gn_part, MGLD_GN_CHANNEL_SUMS, chunks} to mgld_gn_apply2 / mgld_spade_apply2 instead of launching mgld_gn_stats
                              (GroupNorm32 on a convolution's output: openaimodel.py:401-405,429-436).                                */
+  int32_t r_f32;          /* 1: R is fp32 [M, ldr] (needs out_f32, batch <= 1): the fp32 residual stream of the high-precision first-stage
+                             encoder (mgld_hp_*, model.py:124-183 ResnetBlock `x + h`); kernels with an fp16-only epilogue are not picked  */
 } MgldIGemm;
 
 /* tiles per frame of the statistics output (see gn_part), or 0 when the kernel picked for this problem does not produce it */
@@ -387,6 +389,23 @@ int mgld_flow_update(float* coords1, const float* coords0, const float* delta, i
 /* convex 8x upsampling (:720-731): mask fp32 NHWC [B*H*W, ldm >= 576] (already scaled by 0.25), flow fp32 [B,2,H,W] ->
  * out fp32 [B,2,8H,8W] */
 int mgld_convex_upsample(const float* flow, const float* mask, int ldm, float* out, int B, int H, int W, void* stream);
+
+/* ---- high-precision first-stage encoder (round 5; model.py:473-572 Encoder behind encode_first_stage, ddpm.py:3906-3943) --------
+ * The first-stage latent conditions every sampling step, so its error does not average out: fp32 activations between the kernels,
+ * split-fp16 operands inside the contractions (activation row [ah | 16 al | ah/256] against weight row [wh | wh/16 | 256 wl]: three
+ * times the channels through the ordinary mgld_igemm with out_f32 / r_f32), see csrc/hpenc.hip. */
+/* row chunks the two kernels below split a frame of `rows` rows into */
+int mgld_hp_chunks(int rows);
+/* GroupNorm statistics of an fp32 NHWC tensor [frames*rows, ldx] (model.py:42-43 Normalize): gsums[frame][chunk][group][2] fp64
+ * (sum, sumsq), chunk < mgld_hp_chunks(rows); deterministic.  C % 4 == 0, C <= 1024. */
+int mgld_hp_gn_stats(const float* x, int ldx, int frames, int rows, int C, int groups, double* gsums, void* stream);
+/* y = [silu]((x - mean) * rstd * gamma + beta) from those statistics (gsums == NULL: y = x), written either as the split-fp16
+ * contraction operand fp16 [frames*rows, ldo >= 3C] = [yh | 16 yl | yh/256] (out_f32 = 0) or as fp32 [frames*rows, ldo >= C]
+ * (out_f32 = 1; the attention block's input).  model.py:134-139 (norm1 / swish), :474 ff. */
+int mgld_hp_gn_split(const float* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta, int silu, void* out,
+                     int ldo, int out_f32, int frames, int rows, int C, int groups, void* stream);
+/* in-place softmax over the `cols` entries of every fp32 row (the mid attention's key axis, model.py:226-229) */
+int mgld_hp_softmax_rows(float* S, int64_t rows, int cols, int ld, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgld_hip.so")
 STAMP = os.path.join(HERE, "csrc", ".build_stamp")
-SOURCES = ["runtime.hip", "igemm.hip", "conv3q.hip", "ppgemm.hip", "conv3r.hip", "pptconv.hip", "norm.hip", "attention.hip", "elementwise.hip", "raft.hip"]
+SOURCES = ["runtime.hip", "igemm.hip", "conv3q.hip", "ppgemm.hip", "conv3r.hip", "pptconv.hip", "norm.hip", "attention.hip", "elementwise.hip", "raft.hip", "hpenc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 
 

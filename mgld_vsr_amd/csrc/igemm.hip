@@ -501,7 +501,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MgldIGemm p, c
       if (p.bias) x += p.bias[n];
       if (rv) x += rv[n];
       x = apply_act(x, p.act) * p.alpha;
-      if (R) x += p.beta * (float)R[(int64_t)m * p.ldr + n];
+      if (p.r_f32 && p.R) x += p.beta * ((const float*)p.R)[(int64_t)m * p.ldr + n];
+      else if (R) x += p.beta * (float)R[(int64_t)m * p.ldr + n];
       if (p.out_f32) ((float*)p.C)[(int64_t)m * p.ldc + n] = x;
       else ((f16*)p.C)[(int64_t)m * p.ldc + n] = (f16)x;
     }
@@ -815,6 +816,8 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
     MGLD_REQUIRE(!(p->mode == MGLD_MODE_LINEAR && p->tune == 9), "igemm: the register-staged LINEAR variant does not take W2");
   }
   if (p->rowvec) MGLD_REQUIRE(p->rows_per_frame > 0, "igemm: rows_per_frame");
+  if (p->r_f32) MGLD_REQUIRE(p->R && p->out_f32 && p->batch <= 1 && p->act != MGLD_ACT_GEGLU && ((((uintptr_t)p->R) & 3) == 0),
+                             "igemm: an fp32 residual (r_f32) goes with an fp32 output, batch 1");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;

@@ -232,6 +232,10 @@ __device__ __forceinline__ void epi_rows(const MgldIGemm& p, const RowMap rmap, 
         const f16* rp = R + (int64_t)m * p.ldr + n;
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * (float)rp[j];
+      } else if (p.r_f32 && p.R) {      // fp32 residual stream (MgldIGemm.r_f32: the high-precision VAE encoder)
+        const float* rp = (const float*)p.R + (int64_t)m * p.ldr + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * rp[j];
       }
       if (of32) {
         float* cp = (float*)outp + cbase + (int64_t)m * ldo + n;
@@ -280,7 +284,7 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
   const int64_t cbase = splitk ? (int64_t)kz * M * N : (int64_t)bz * p.strideC;
   const int ldo = splitk ? N : p.ldc;
   const bool of32 = splitk || p.out_f32;
-  const f16* __restrict__ R = (!splitk && p.R) ? (const f16*)p.R + (int64_t)bz * p.strideR : nullptr;
+  const f16* __restrict__ R = (!splitk && p.R && !p.r_f32) ? (const f16*)p.R + (int64_t)bz * p.strideR : nullptr;
   const int act = splitk ? MGLD_ACT_NONE : p.act;
   const float alpha = splitk ? 1.f : p.alpha;
   char* outp = splitk ? (char*)ws : (char*)p.C;

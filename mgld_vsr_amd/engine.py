@@ -98,6 +98,16 @@ def pack_geglu(w, b):
     return wp, bp
 
 
+def pack_hp(w32):
+    """split-fp16 weights of the high-precision encoder (csrc/hpenc.hip): [Cout, Cin, ...] fp32 -> [Cout, 3*Cin, ...] =
+    [wh | wh / 16 | 256 wl] along the input-channel axis (wh = fp16(w), wl = w - wh), every entry exactly representable in fp16 (wl to
+    2^-11 of itself); meets activation rows [ah | 16 al | ah / 256], so one ordinary contraction over 3 Cin channels yields
+    ah wh + al wh + ah wl."""
+    wh = w32.to(torch.float16).to(torch.float32)
+    wl = w32 - wh
+    return torch.cat([wh, wh / 16.0, wl * 256.0], 1)
+
+
 def split_residual(w32, scale=None):
     """fp32 packed weights -> (hi, lo): hi = fp16(w), lo = fp16((w - hi) / scale) with scale = 2^-11, i.e. the rounding residual of
     the weights lifted into fp16's normal range (MgldIGemm.W2: the kernel computes scale * (A lo^T) + A hi^T)."""

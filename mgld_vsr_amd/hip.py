@@ -33,7 +33,7 @@ class MgldIGemm(C.Structure):
         ("batch", C.c_int32), ("tap_inner", C.c_int32),
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
         ("t_off", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("tune", C.c_int32),
-        ("w2_scale", C.c_float), ("W2", C.c_void_p), ("gn_part", C.c_void_p),
+        ("w2_scale", C.c_float), ("W2", C.c_void_p), ("gn_part", C.c_void_p), ("r_f32", C.c_int32),
     ]
 
 
@@ -64,6 +64,7 @@ EXPORTS = [
     "mgld_adain", "mgld_wavelet_reconstruction", "mgld_init_latent", "mgld_to01",
     "mgld_crop", "mgld_tile_accumulate", "mgld_tile_normalize", "mgld_copy_step",
     "mgld_resize_bicubic", "mgld_resize_bilinear_crop", "mgld_reflect_pad", "mgld_replicate_pad", "mgld_to_uint8_hwc",
+    "mgld_hp_chunks", "mgld_hp_gn_stats", "mgld_hp_gn_split", "mgld_hp_softmax_rows",
     "mgld_conv_f32", "mgld_instnorm_chunks", "mgld_instnorm_f32", "mgld_nchw_to_nhwc_f32",
     "mgld_avgpool2", "mgld_corr_lookup", "mgld_gru_rh", "mgld_gru_gate", "mgld_flow_update", "mgld_convex_upsample",
 ]
@@ -144,6 +145,7 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
     p.rows_per_frame = rows_per_frame
     p.act = act
     p.out_f32 = 1 if out.dtype == torch.float32 else 0
+    p.r_f32 = 1 if (resid is not None and resid.dtype == torch.float32) else 0
     p.alpha, p.beta = alpha, beta
     p.batch = batch
     p.tap_inner = tap_inner
@@ -800,3 +802,37 @@ def convex_upsample(flow, mask):
     out = torch.empty(B, 2, 8 * H, 8 * W, dtype=torch.float32, device=flow.device)
     _chk(lib().mgld_convex_upsample(_p(flow), _p(mask), _ld(mask), _p(out), B, H, W, stream_ptr()), "convex_upsample")
     return out
+
+
+# ---- high-precision first-stage encoder glue (csrc/hpenc.hip) -----------------------------------------------------------------
+def hp_chunks(rows):
+    return int(lib().mgld_hp_chunks(int(rows)))
+
+
+def hp_gn_stats(x, frames, rows, groups, gsums):
+    """x fp32 [frames*rows, C] view -> gsums fp64 [frames, hp_chunks(rows), groups, 2]"""
+    _req_cuda(x, gsums)
+    _f32(x)
+    assert gsums.dtype == torch.float64 and gsums.numel() >= frames * hp_chunks(rows) * groups * 2
+    _chk(lib().mgld_hp_gn_stats(_p(x), _ld(x), frames, rows, x.shape[1], groups, _p(gsums), stream_ptr()), "hp_gn_stats")
+    return gsums
+
+
+def hp_gn_split(x, gsums, eps, gamma, beta, silu, out, frames, rows, groups):
+    """GroupNorm (+ SiLU) of fp32 x from hp_gn_stats' sums (gsums None: identity), written as the split-fp16 operand
+    [yh | 16 yl | yh/256] (out fp16 [frames*rows, 3C]) or as fp32 (out fp32 [frames*rows, C])"""
+    _req_cuda(x, gsums, gamma, beta, out)
+    _f32(x, gamma, beta)
+    of32 = out.dtype == torch.float32
+    assert of32 or (out.dtype == torch.float16 and out.shape[1] == 3 * x.shape[1])
+    _chk(lib().mgld_hp_gn_split(_p(x), _ld(x), _p(gsums), C.c_float(eps), _p(gamma), _p(beta), int(bool(silu)), _p(out), _ld(out),
+                                int(of32), frames, rows, x.shape[1], groups, stream_ptr()), "hp_gn_split")
+    return out
+
+
+def hp_softmax_rows(S):
+    """in-place row softmax of an fp32 [rows, cols] view"""
+    _req_cuda(S)
+    _f32(S)
+    _chk(lib().mgld_hp_softmax_rows(_p(S), C.c_int64(S.shape[0]), S.shape[1], _ld(S), stream_ptr()), "hp_softmax_rows")
+    return S

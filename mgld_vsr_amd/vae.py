@@ -13,9 +13,16 @@ the conv gather; the single-head d=512 mid attention runs as two batched GEMMs a
 import torch
 import torch.nn as nn
 
+import os
+
 from . import hip
-from .engine import Act, Engine, pack_conv1x1, pack_conv3x3
+from .engine import Act, Engine, pack_conv1x1, pack_conv3x3, pack_hp
 from .unet import SpatialTemporalConv, _meta_module
+
+# High-precision first-stage encoder (round 5, csrc/hpenc.hip): the latent it produces conditions every sampling step, so its fp16
+# error is a bias on x_0 (2.4e-3 on smooth frames against 9.0e-4 with an exact latent).  fp32 activations between the kernels,
+# split-fp16 operands inside the contractions (3x the encoder's MFMA work = +6 % of a segment's).  MGLD_HP_ENCODER=0: the fp16 encoder.
+HP_ENCODER = os.environ.get("MGLD_HP_ENCODER", "1") != "0"
 
 
 def Normalize(in_channels, num_groups=32):
@@ -38,6 +45,41 @@ def _gn(eng, norm, x, silu):
     return eng.groupnorm(x, eng.f32("g", norm.weight), eng.f32("b", norm.bias), norm.eps, silu)
 
 
+# ---- high-precision (hp) building blocks: fp32 Acts in and out ---------------------------------------------------------------
+def _hp_split(eng, x, norm=None, silu=False, out_f32=False):
+    """fp32 Act -> [GroupNorm (+ SiLU) in fp32 ->] the split-fp16 contraction operand [yh | 16 yl | yh/256] (Act fp16 [rows, 3C]),
+    or the normalised tensor itself as fp32 (out_f32)"""
+    gs = g = b = None
+    if norm is not None:
+        gs = eng.arena.alloc((x.n * hip.hp_chunks(x.hw) * norm.num_groups * 2,), torch.float64)
+        hip.hp_gn_stats(x.v, x.n, x.hw, norm.num_groups, gs)
+        g, b = eng.f32("g", norm.weight), eng.f32("b", norm.bias)
+        eng.launches += 1
+    out = eng.act(x.n, x.h, x.w, x.C if out_f32 else 3 * x.C, torch.float32 if out_f32 else torch.float16)
+    hip.hp_gn_split(x.v, gs, norm.eps if norm is not None else 0.0, g, b, silu, out.v, x.n, x.hw, norm.num_groups if norm is not None else 1)
+    eng.launches += 1
+    return out
+
+
+def _hp_conv3(eng, conv, a3, resid=None, stride=1, pad=(1, 1), hw_out=None):
+    """3x3 convolution of a split operand against split weights -> fp32 Act (+ fp32 residual)"""
+    w = eng.weight("c3hp", (conv.weight,), lambda t: pack_conv3x3(pack_hp(t), a3.C))
+    return eng.conv3x3(a3, w, eng.f32("b", conv.bias), conv.out_channels, resid=resid, stride=stride, pad=pad, hw_out=hw_out,
+                       out_dtype=torch.float32)
+
+
+def _hp_conv1(eng, conv, a3, resid=None):
+    w = eng.weight("c1hp", (conv.weight,), lambda t: pack_conv1x1(pack_hp(t.reshape(t.shape[0], t.shape[1])), a3.C))
+    return eng.linear(a3, w, eng.f32("b", conv.bias), resid=resid, out_dtype=torch.float32)
+
+
+def _f32_conv(eng, conv, x, ksize=(1, 1), pad=(0, 0), resid=None, out=None, cin=None):
+    """a convolution on the f32-input MFMA (mgld_conv_f32): the 3- / 8-channel ends of the encoder and its attention block"""
+    from .raft import _conv, pack_conv_f32
+    w = eng.weight("c32", (conv.weight,), pack_conv_f32, torch.float32)
+    return _conv(eng, x, w, eng.f32("b", conv.bias), conv.out_channels, ksize, 1, pad, resid=resid, out=out, cin=cin)
+
+
 class Upsample(nn.Module):
     def __init__(self, in_channels, with_conv):
         super().__init__()
@@ -58,6 +100,9 @@ class Downsample(nn.Module):
         # F.pad (0,1,0,1) then stride-2 valid conv (model.py:114-118): pad_t = pad_l = 0, bottom/right implied
         return _conv3(eng, self.conv, x, stride=2, pad=(0, 0), hw_out=(x.h // 2, x.w // 2))
 
+    def run_hp(self, eng, x):
+        return _hp_conv3(eng, self.conv, _hp_split(eng, x), stride=2, pad=(0, 0), hw_out=(x.h // 2, x.w // 2))
+
 
 class ResnetBlock(nn.Module):
     def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout, temb_channels=512):
@@ -77,6 +122,12 @@ class ResnetBlock(nn.Module):
         h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True), stats=True)          # norm2 reads the epilogue's statistics
         skip = x if self.in_channels == self.out_channels else _conv1(eng, self.nin_shortcut, x)
         return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip, stats=True)   # the next block's norm likewise
+
+    def run_hp(self, eng, x):
+        """model.py:162-183 with fp32 activations (x, the result and the skip are fp32 Acts)"""
+        h = _hp_conv3(eng, self.conv1, _hp_split(eng, x, self.norm1, True))
+        skip = x if self.in_channels == self.out_channels else _hp_conv1(eng, self.nin_shortcut, _hp_split(eng, x))
+        return _hp_conv3(eng, self.conv2, _hp_split(eng, h, self.norm2, True), resid=skip)
 
 
 class AttnBlock(nn.Module):
@@ -110,6 +161,25 @@ class AttnBlock(nn.Module):
         hip.igemm(P, vt, o.v, M=N, N=C, K=N, batch=F, strideA=N * N, strideW=C * N, strideC=N * C)
         eng.launches += 4
         return _conv1(eng, self.proj_out, o, resid=x)
+
+    def run_hp(self, eng, x):
+        """the same block entirely in fp32 on the f32-input MFMA (model.py:209-244): q, k, v^T, S = q k^T / sqrt(C), row softmax,
+        P v (+ the v bias: the rows of P sum to one), proj_out + x"""
+        from .raft import _conv, pack_conv_f32
+        C, N, F = self.in_channels, x.hw, x.n
+        f32 = torch.float32
+        hn = _hp_split(eng, x, self.norm, False, out_f32=True)
+        q, k = _f32_conv(eng, self.q, hn), _f32_conv(eng, self.k, hn)
+        wv = eng.weight("c32", (self.v.weight,), pack_conv_f32, f32)                    # [C, C]
+        vt = eng.arena.alloc((F * C, N), f32)                                           # per frame V^T [C, N] = Wv hn^T
+        hip.conv_f32(wv, hn.v, vt, 1, 1, C, C, batch=F, strideA=0, strideW=N * C, strideC=C * N, n_out=N)
+        S = eng.arena.alloc((F * N, N), f32)
+        hip.conv_f32(q.v, k.v, S, 1, x.h, x.w, C, alpha=float(int(C) ** (-0.5)), batch=F, strideA=N * C, strideW=N * C, strideC=N * N, n_out=N)
+        hip.hp_softmax_rows(S)
+        o = eng.act(x.n, x.h, x.w, C, f32)
+        hip.conv_f32(S, vt, o.v, 1, x.h, x.w, N, bias=eng.f32("b", self.v.bias), batch=F, strideA=N * N, strideW=C * N, strideC=N * C, n_out=C)
+        eng.launches += 4
+        return _f32_conv(eng, self.proj_out, o, resid=x)
 
 
 def make_attn(in_channels, attn_type="vanilla"):
@@ -169,6 +239,23 @@ class Encoder(nn.Module):
         h = self.mid.block_2.run(eng, h)
         h = _conv3(eng, self.conv_out, _gn(eng, self.norm_out, h, True))
         return h, fea
+
+    def run_hp(self, eng, x):
+        """the encoder in high precision (csrc/hpenc.hip): x NCHW fp32 device tensor -> fp32 Act [n, h/8, w/8, 2z]"""
+        n, c, H, W = x.shape
+        xa = eng.act(n, H, W, 4, torch.float32)
+        hip.nchw_to_nhwc_f32(x, xa.v)
+        eng.launches += 1
+        h = _f32_conv(eng, self.conv_in, xa, (3, 3), (1, 1))
+        for lvl in range(self.num_resolutions):
+            for blk in self.down[lvl].block:
+                h = blk.run_hp(eng, h)
+            if lvl != self.num_resolutions - 1:
+                h = self.down[lvl].downsample.run_hp(eng, h)
+        h = self.mid.block_1.run_hp(eng, h)
+        h = self.mid.attn_1.run_hp(eng, h)
+        h = self.mid.block_2.run_hp(eng, h)
+        return _f32_conv(eng, self.conv_out, _hp_split(eng, h, self.norm_out, True, out_f32=True), (3, 3), (1, 1))
 
 
 class Decoder(nn.Module):
@@ -469,12 +556,24 @@ class AutoencoderKL(_AutoencoderBase):
             out = self.decoder.run(eng, zq)
         return eng.to_nchw(out, self.decoder.out_ch)
 
+    def _moments_hp(self, eng, x):
+        """the moments through the high-precision encoder + quant_conv on the f32-input MFMA -> NCHW fp32"""
+        h = self.encoder.run_hp(eng, x.contiguous())
+        m = _f32_conv(eng, self.quant_conv, h)
+        out = torch.empty(m.n, m.C, m.h, m.w, dtype=torch.float32, device=eng.device)
+        hip.nhwc_to_nchw(m.v, out)
+        eng.launches += 1
+        return out
+
     @torch.no_grad()
     def encode(self, x, return_encfea=False):
         """autoencoder.py:347-353: the posterior, plus the moments tensor it was built from when `return_encfea`"""
         eng = self.engine()
         eng.reset()
-        m, _ = self._moments(eng, x.to(eng.device, torch.float32))
+        if HP_ENCODER:
+            m = self._moments_hp(eng, x.to(eng.device, torch.float32))
+        else:
+            m, _ = self._moments(eng, x.to(eng.device, torch.float32))
         posterior = DiagonalGaussianDistribution(m)
         return (posterior, m) if return_encfea else posterior
 

@@ -1,13 +1,15 @@
 """TEST INFRASTRUCTURE — CPU fp32 restatement of FrozenOpenCLIPEmbedder.encode_with_transformer
 (ldm/modules/encoders/modules.py:181-199) over open_clip's text-transformer state_dict.
 
-PARITY against the reference's dependency `open_clip` (open_clip_torch, imported at modules.py:12, un-vendored) is UNPINNED:
-it is not installed in this image, so the reference class cannot be instantiated to produce golden vectors.  The restatement
-follows open_clip's published text tower — token embedding + positional embedding, pre-LN residual blocks
-x += MHA(ln_1(x), causal mask); x += c_proj(GELU(c_fc(ln_2(x)))), ln_final — on torch.nn.functional.multi_head_attention_forward,
-the function nn.MultiheadAttention (open_clip's `attn`) itself calls, and IS pinned to an independent implementation of the
-same tower: transformers' CLIPTextModel, the class the reference's FrozenCLIPEmbedder binds (modules.py:7, :207), on synthetic
-weights, `last` and `penultimate` layer (tests/golden/g_text_hf.npz, tests/test_oracle_golden.py::test_text_tower_golden).
+PINNED (round 5) to the reference's own embedder class: tests/golden/g_text_openclip.npz holds outputs of
+`FrozenOpenCLIPEmbedder.encode_with_transformer` (the reference's code: embedding sum, permutes, `attn_mask`, the `penultimate` layer
+slice, `ln_final`) run in the build container on a stand-in for the model object `open_clip.create_model_and_transforms` returns —
+open_clip_torch itself (un-vendored dependency, modules.py:12) is not installed, so the ResidualAttentionBlock it would supply
+(x += MHA(ln_1(x), causal mask); x += c_proj(GELU(c_fc(ln_2(x))))) is restated there from its published definition, on
+nn.MultiheadAttention as open_clip has it (tests/test_oracle_golden.py::test_text_tower_openclip_golden, 1e-5).  Second, independent
+pin: transformers' CLIPTextModel, the class the reference's FrozenCLIPEmbedder binds (modules.py:7, :207), on synthetic weights,
+`last` and `penultimate` layer (tests/golden/g_text_hf.npz, ::test_text_tower_golden).  What stays unpinned: open_clip's own block
+implementation bit for bit (its attention goes through the same torch function this file calls).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package."""
 import torch
 import torch.nn.functional as F

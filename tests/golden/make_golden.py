@@ -888,6 +888,98 @@ def gen_text_hf():
     save("g_text_hf", tokens=tokens, last=out.last_hidden_state, penultimate=pen, names_shapes=names_shapes(m))
 
 
+def gen_text_openclip():
+    """Text tower pin, round 5: the REFERENCE's own FrozenOpenCLIPEmbedder (ldm/modules/encoders/modules.py:140-199) is instantiated and
+    its `encode_with_transformer` / `text_transformer_forward` run — the embedding sum, NLD <-> LND permutes, the `attn_mask` it passes,
+    the layer slice of layer="penultimate" (`break` at len(resblocks) - layer_idx) and `ln_final` are the reference's code, executed.
+    What the reference binds through `open_clip.create_model_and_transforms` is NOT installable here (un-vendored dependency
+    open_clip_torch, modules.py:12); the model object handed to the reference class is a stand-in that restates open_clip's published
+    text tower attribute for attribute (token_embedding, positional_embedding, transformer.resblocks[i] = ResidualAttentionBlock
+    {ln_1, attn = nn.MultiheadAttention, ln_2, mlp.c_fc / gelu / c_proj} with forward x + attn(ln_1 x, mask); x + mlp(ln_2 x),
+    ln_final, the additive causal `attn_mask` buffer, transformer.grad_checkpointing) at reduced width.  The fixture holds tokens and the
+    reference class's outputs for both layer choices; oracle/text.py and the product's tower are compared against it."""
+    import collections
+    import types
+    import torch.nn as nn
+
+    class ResidualAttentionBlock(nn.Module):
+        def __init__(self, d_model, n_head):
+            super().__init__()
+            self.ln_1 = nn.LayerNorm(d_model)
+            self.attn = nn.MultiheadAttention(d_model, n_head)
+            self.ln_2 = nn.LayerNorm(d_model)
+            self.mlp = nn.Sequential(collections.OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", nn.GELU()),
+                                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
+
+        def forward(self, x, attn_mask=None):
+            h = self.ln_1(x)
+            x = x + self.attn(h, h, h, need_weights=False, attn_mask=attn_mask)[0]
+            return x + self.mlp(self.ln_2(x))
+
+    class Transformer(nn.Module):
+        def __init__(self, width, layers, heads):
+            super().__init__()
+            self.grad_checkpointing = False
+            self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+    class CLIPStandIn(nn.Module):
+        def __init__(self, vocab=512, ctx=77, width=128, layers=4, heads=2):
+            super().__init__()
+            self.visual = nn.Identity()                                  # (the reference deletes it, modules.py:154)
+            self.token_embedding = nn.Embedding(vocab, width)
+            self.positional_embedding = nn.Parameter(torch.empty(ctx, width))
+            self.transformer = Transformer(width, layers, heads)
+            self.ln_final = nn.LayerNorm(width)
+            self.text_projection = nn.Parameter(torch.empty(width, width))
+            self.logit_scale = nn.Parameter(torch.ones([]))
+            mask = torch.empty(ctx, ctx).fill_(float("-inf")).triu_(1)   # open_clip build_attention_mask
+            self.register_buffer("attn_mask", mask, persistent=False)
+
+    made = []
+
+    def create_model_and_transforms(arch, device=None, pretrained=None):
+        made.append((arch, pretrained))
+        return CLIPStandIn(), None, None
+
+    import importlib.machinery
+    if "torchvision" in sys.modules and getattr(sys.modules["torchvision"], "__spec__", None) is None:   # the shim's stub: transformers probes find_spec()
+        for k in [k for k in sys.modules if k == "torchvision" or k.startswith("torchvision.")]:
+            sys.modules[k].__spec__ = importlib.machinery.ModuleSpec(k, None)
+    import transformers  # noqa: F401  (modules.py:6-7 imports it; resolve it before the shim stubs torchvision)
+    from transformers import CLIPTextModel, CLIPTokenizer  # noqa: F401
+    import transformers.models.clip.modeling_clip as hf_clip
+    if not hasattr(hf_clip, "CLIPTextTransformer"):      # transformers 5.x dropped the class transformer_utils.py:5 subclasses for an
+        hf_clip.CLIPTextTransformer = type("CLIPTextTransformer", (nn.Module,), {})   # embedder that is not on this path (CLIPTextTransformer_M)
+    ref_import.install()
+    for name in ("clip", "kornia"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    oc = types.ModuleType("open_clip")
+    oc.create_model_and_transforms, oc.tokenize = create_model_and_transforms, None
+    sys.modules["open_clip"] = oc
+    mods = ref_import.ref("ldm.modules.encoders.modules")
+    tokens = torch.zeros(3, 77, dtype=torch.long)
+    tokens[0, 0], tokens[0, 1] = 510, 511                                 # the empty prompt: [SOT, EOT, 0...]
+    g = torch.Generator().manual_seed(7)
+    tokens[1, 0] = 510
+    tokens[1, 1:40] = torch.randint(1, 510, (39,), generator=g)
+    tokens[1, 40] = 511
+    tokens[2, 0] = 510
+    tokens[2, 1:76] = torch.randint(1, 510, (75,), generator=g)          # a full-length prompt (EOT in the last slot)
+    tokens[2, 76] = 511
+    out = {"tokens": tokens}
+    for layer in ("last", "penultimate"):
+        emb = mods.FrozenOpenCLIPEmbedder(arch="ViT-H-14", version="laion2b_s32b_b79k", device="cpu", layer=layer)
+        assert made[-1] == ("ViT-H-14", "laion2b_s32b_b79k") and not hasattr(emb.model, "visual")
+        synth.fill_module_(emb, "clip")
+        with torch.no_grad():
+            emb.model.positional_embedding.mul_(10.0)                    # (the synthetic 1-D recipe is tiny: give the embeddings scale;
+            emb.model.token_embedding.weight.mul_(10.0)                  #  tests/test_nets_gpu.py::test_text_tower_vs_oracle does the same)
+            out[layer] = emb.encode_with_transformer(tokens)
+        out["names_shapes"] = names_shapes(emb)
+    save("g_text_openclip", **out)
+
+
 def gen_signatures():
     """Argument lists of the reference's public entry points on this path (interface data for the drop-in check in
     tests/test_host_cpu.py::test_drop_in_signatures): read with `ast` from the reference sources, nothing is imported."""

@@ -1208,3 +1208,78 @@ def test_layout_roundtrip(hip):
     assert torch.equal(z[:, 16:24], y[:, :8])
     hip.axpby(y[:, :8], z[:, 16:24], 2.0, 0.5)
     assert torch.allclose(z[:, 16:24].float(), y[:, :8].float() * 2.5, atol=2e-3, rtol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# high-precision first-stage encoder pieces (csrc/hpenc.hip, MgldIGemm.r_f32)
+# ------------------------------------------------------------------------------------------------------------------
+def _unsplit(a3, C):
+    """[ah | 16 al | ah/256] -> ah + al"""
+    return a3[:, :C].double() + a3[:, C:2 * C].double() / 16.0
+
+
+@pytest.mark.parametrize("frames,rows,C,groups", [(2, 4096, 128, 32), (3, 1000, 512, 32), (1, 300, 32, 32), (2, 64, 64, 32)])
+def test_hp_groupnorm_split(hip, frames, rows, C, groups):
+    """mgld_hp_gn_stats + mgld_hp_gn_split vs F.group_norm (+ SiLU) in fp64: fp32 output to 1e-6, the split operand reassembles to 2^-21,
+    its third block is the first / 256; identity mode (no statistics) splits the input itself"""
+    x = rnd(frames * rows, C, seed=500) * 3 + 0.7
+    x[:, 5] += 40.0                                                   # a channel with a large mean
+    gamma, beta = 1 + 0.1 * rnd(C, seed=501), 0.1 * rnd(C, seed=502)
+    xd = x.to(DEV)
+    gs = torch.empty(frames * hip.hp_chunks(rows) * groups * 2, dtype=torch.float64, device=DEV)
+    hip.hp_gn_stats(xd, frames, rows, groups, gs)
+    xr = x.double().view(frames, rows, C).permute(0, 2, 1)
+    for silu in (False, True):
+        ref = F.group_norm(xr, groups, gamma.double(), beta.double(), 1e-6)
+        if silu:
+            ref = ref * torch.sigmoid(ref)
+        ref = ref.permute(0, 2, 1).reshape(frames * rows, C)
+        o32 = torch.empty(frames * rows, C, device=DEV)
+        hip.hp_gn_split(xd, gs, 1e-6, gamma.to(DEV), beta.to(DEV), silu, o32, frames, rows, groups)
+        assert rel_l2(o32.cpu().double(), ref) < 2e-6
+        o3 = torch.empty(frames * rows, 3 * C, dtype=torch.half, device=DEV)
+        hip.hp_gn_split(xd, gs, 1e-6, gamma.to(DEV), beta.to(DEV), silu, o3, frames, rows, groups)
+        assert rel_l2(_unsplit(o3.cpu(), C), ref) < 3e-6
+        assert torch.equal(o3[:, 2 * C:].cpu().float(), (o3[:, :C].cpu().float() / 256.0).half().float())
+    o3 = torch.empty(frames * rows, 3 * C, dtype=torch.half, device=DEV)
+    hip.hp_gn_split(xd, None, 0.0, None, None, False, o3, frames, rows, 1)
+    assert rel_l2(_unsplit(o3.cpu(), C), x.double()) < 1e-6
+    # deterministic: a second pass gives the same bits
+    gs2 = torch.empty_like(gs)
+    hip.hp_gn_stats(xd, frames, rows, groups, gs2)
+    assert torch.equal(gs, gs2)
+
+
+def test_hp_softmax_rows(hip):
+    S = (rnd(300, 1000, seed=510) * 4).to(DEV)
+    ref = torch.softmax(S.cpu().double(), -1)
+    hip.hp_softmax_rows(S)
+    assert rel_l2(S.cpu().double(), ref) < 1e-6 and float((S.sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,stride", [(2, 32, 32, 128, 128, 1), (1, 64, 48, 128, 256, 1), (2, 16, 16, 512, 512, 1), (2, 32, 32, 128, 128, 2),
+                                                    (1, 8, 8, 64, 32, 1)])
+def test_hp_split_convolution(hip, n, h, w, cin, cout, stride):
+    """the split-fp16 contraction end to end: fp32 input -> mgld_hp_gn_split (identity) -> mgld_igemm over 3 Cin channels against
+    engine.pack_hp weights, fp32 output + fp32 residual (MgldIGemm.r_f32) vs F.conv2d in fp64: ~1e-6 where the plain fp16 kernels
+    give 3e-4.  stride 2 = the encoder's Downsample (F.pad (0,1,0,1) + valid conv, model.py:114-118)."""
+    from mgld_vsr_amd.engine import Act, Engine, pack_conv3x3, pack_hp
+    eng = Engine()
+    x = rnd(n, cin, h, w, seed=520) * 2
+    wt = rnd(cout, cin, 3, 3, seed=521) / (cin * 9) ** 0.5
+    b = 0.1 * rnd(cout, seed=522)
+    if stride == 1:
+        ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    else:
+        ref = F.conv2d(F.pad(x.double(), (0, 1, 0, 1)), wt.double(), b.double(), stride=2)
+    ho, wo = ref.shape[-2:]
+    skip = rnd(n * ho * wo, cout, seed=523)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, cout) + skip.double()
+    xa = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV)
+    a3 = torch.empty(xa.shape[0], 3 * cin, dtype=torch.half, device=DEV)
+    hip.hp_gn_split(xa, None, 0.0, None, None, False, a3, n, h * w, 1)
+    wp = pack_conv3x3(pack_hp(wt), 3 * cin).half().to(DEV)
+    kw = dict(stride=2, pad=(0, 0), hw_out=(ho, wo)) if stride == 2 else {}
+    out = eng.conv3x3(Act(a3, n, h, w), wp, b.to(DEV), cout, resid=Act(skip.to(DEV), n, ho, wo), out_dtype=torch.float32, **kw)
+    assert out.v.dtype == torch.float32
+    assert rel_l2(out.v.cpu().double(), ref) < 3e-6

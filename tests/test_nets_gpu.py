@@ -137,7 +137,9 @@ def test_vae_small_vs_golden(hip):
     dd.pop("num_frames")
     fs = synth.fill_module_(AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4), "first_stage")
     post = fs.encode(gf["x"].cuda())
-    assert record("first_stage_mean", rel_l2(post.mean, gf["mean"])) < 2e-3
+    # round 5: the first-stage encoder runs in high precision (fp32 activations, split-fp16 contractions, csrc/hpenc.hip): fp32
+    # round-off against the reference's fp32 CPU result (the fp16 encoder sat at 1.5e-3 here and 1.07e-3 on the full-width smooth workload)
+    assert record("first_stage_mean", rel_l2(post.mean, gf["mean"])) < 2e-5
 
 
 def test_vae_decoder_with_outlier_channels_vs_oracle(hip):
@@ -688,6 +690,43 @@ def test_text_tower_vs_oracle(hip):
     assert record("text_tower", rel_l2(out, ref)) < 8.5e-4
     with pytest.raises(NotImplementedError):
         emb(["a photo"])
+
+
+def test_text_tower_vs_reference_embedder_golden(hip, tmp_path, monkeypatch):
+    """the product's tower against outputs of the REFERENCE's own FrozenOpenCLIPEmbedder class (g_text_openclip.npz): both layer choices,
+    the empty prompt, a 40-token and a full-length prompt; then a non-empty TEXT prompt end to end through the BPE tokenizer with a merge
+    table supplied by the test (open_clip's file format) — no NotImplementedError when a table is there."""
+    import gzip
+    from mgld_vsr_amd import tokenizer
+    from mgld_vsr_amd.text import FrozenOpenCLIPEmbedder
+    from oracle import text as otext
+    g = G("g_text_openclip")
+    tokens = g["tokens"].long()
+    for layer in ("last", "penultimate"):
+        emb = FrozenOpenCLIPEmbedder(layer=layer, context_dim=128, build_tower=True, heads=2, layers=4, vocab_size=512)
+        synth.fill_module_(emb, "clip")
+        with torch.no_grad():
+            emb.model.positional_embedding.mul_(10.0)
+            emb.model.token_embedding.weight.mul_(10.0)
+        out = emb.encode_with_transformer(tokens)
+        assert record(f"text_tower_vs_reference_{layer}", rel_l2(out, g[layer])) < 1e-3
+    # a text prompt: toy merge table in open_clip's gzip format, located through $MGLD_BPE_VOCAB
+    merges = [("t", "h"), ("th", "e</w>"), ("a", "n"), ("an", "d</w>"), ("h", "e")]
+    path = tmp_path / tokenizer.VOCAB_FILE
+    with gzip.open(path, "wt", encoding="utf-8") as fh:
+        fh.write('"bpe_simple_vocab_16e6.txt#version: 0.2\n' + "\n".join(" ".join(m) for m in merges) + "\n")
+    monkeypatch.setenv("MGLD_BPE_VOCAB", str(path))
+    vs = 512 + len(merges) + 2
+    emb = FrozenOpenCLIPEmbedder(layer="penultimate", context_dim=128, build_tower=True, heads=2, layers=4, vocab_size=vs)
+    synth.fill_module_(emb, "clip")
+    with torch.no_grad():
+        emb.model.positional_embedding.mul_(10.0)
+        emb.model.token_embedding.weight.mul_(10.0)
+    toks = emb.tokenize(["the cat and the hat", ""])
+    assert toks[0, 0] == vs - 2 and int((toks[0] == vs - 1).nonzero()[0]) > 3 and toks[1, :3].tolist() == [vs - 2, vs - 1, 0]
+    out = emb(["the cat and the hat", ""])
+    ref = otext.encode_with_transformer(emb.state_dict(), toks, heads=2, layer_idx=1)
+    assert record("text_tower_text_prompt", rel_l2(out, ref)) < 1e-3
 
 
 def test_two_segments_in_flight_match_sequential(hip):

@@ -184,6 +184,23 @@ def test_text_tower_golden():
 
 
 
+def test_text_tower_openclip_golden():
+    """oracle/text.py == the REFERENCE's own FrozenOpenCLIPEmbedder.encode_with_transformer / text_transformer_forward
+    (modules.py:179-199), executed on a stand-in for the open_clip model object (g_text_openclip.npz, make_golden.py::gen_text_openclip):
+    same state-dict names as the checkpoint's `cond_stage_model.model.*`, both layer choices, the empty prompt, a 40-token and a
+    full-length prompt"""
+    from oracle import text as otext
+    g = G("g_text_openclip")
+    sd = sd_from(g, "names_shapes", "clip")
+    sd["model.positional_embedding"] = sd["model.positional_embedding"] * 10.0         # as gen_text_openclip scales them
+    sd["model.token_embedding.weight"] = sd["model.token_embedding.weight"] * 10.0
+    tokens = g["tokens"].long()
+    with torch.no_grad():
+        assert rel_l2(otext.encode_with_transformer(sd, tokens, heads=2, layer_idx=0), g["last"]) < 1e-5
+        assert rel_l2(otext.encode_with_transformer(sd, tokens, heads=2, layer_idx=1), g["penultimate"]) < 1e-5
+    assert float((g["last"] - g["penultimate"]).abs().max()) > 1e-3               # the layer choice matters on this fixture
+
+
 def test_single_step_and_image_decode_golden():
     """oracle vs the reference's single-step API (p_mean_variance / p_sample / the canvas variants) and decode_first_stage (g_pstep.npz)"""
     g, gu, gf = G("g_pstep"), G("g_unet"), G("g_first_stage")
@@ -373,6 +390,9 @@ def _regen_and_compare(tmp_path, what, names, timeout):
     (["harness"], ["g_harness.npz"], 3600),                                     # recorded run of the tiled entry script's main()
     (["harness_old"], ["g_harness_old.npz"], 3600),                             # recorded runs of the _old / _w_latent scripts
     (["text_hf"], ["g_text_hf.npz"], 1200),                                     # text tower vs transformers' CLIPTextModel
+    (["text_openclip"], ["g_text_openclip.npz"], 1200),                         # text tower through the reference's own embedder class
+    (["workload:c2s:4"], ["g_work_c2s_S4.npz"], 3600),                          # smooth translating frames, active guidance, 4 steps
+    (["workload:c2s:50"], ["g_work_c2s_S50.npz"], 14400),                       # the same at the production schedule
     (["sample_opts_canvas"], ["g_sample_opts_canvas.npz"], 1200),               # start_T on the canvas loop
     (["harness_old_full"], ["g_harness_old_full.npz"], 7200),                   # old.py::main() at production width / schedule
     (["harness_full"], ["g_harness_full.npz"], 21600),                          # oldcanvas_tile.py::main() at production width / schedule (80 CPU-minutes)

@@ -71,5 +71,31 @@ case "$recipe" in
     done
     for c in "$@"; do timeout 600 python tools/x0_probe.py $c 50 "default" 2>&1 | grep -v amdgpu.ids | tail -4 | tee -a gpurun_out/r5a_probe.log; done
     ;;
+  r5b)        # round 5: smooth-workload error decomposition, more clips x in-flight combinations, per-kernel table at clips = 2, text tower
+    timeout 900 python tools/x0_probe.py c2s 50 "default;all" 2>&1 | grep -v amdgpu.ids | tail -4 | tee gpurun_out/r5b_probe.log
+    timeout 600 python -m pytest tests/test_nets_gpu.py tests/test_workloads_gpu.py -q -k "text_tower or c2s or clips" 2>&1 | tail -15 | tee gpurun_out/r5b_tests.log
+    for cfg in "--clips 3 --inflight 2" "--clips 2 --inflight 3" "--clips 4 --inflight 2"; do
+      tag=$(echo "$cfg" | tr -d ' -')
+      timeout 500 python bench.py $cfg --steps 6 --warmup 2 --no-roofline --no-cpu-baseline --no-one-at-a-time 2> gpurun_out/r5b_bench_$tag.err | tail -1 > gpurun_out/r5b_bench_$tag.json
+      python -c "import json;d=json.load(open('gpurun_out/r5b_bench_$tag.json'));print('$cfg:',d['value'],'fps',d['ms_per_step'],'ms/step')" 2>&1 | tee -a gpurun_out/r5b_bench.log
+    done
+    timeout 600 python bench.py --clips 2 --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --dump-shapes gpurun_out/r5b_shapes_clips2.json 2> gpurun_out/r5b_roof.err | tail -1 > gpurun_out/r5b_roof_clips2.json
+    python -c "
+import json;d=json.load(open('gpurun_out/r5b_roof_clips2.json'))
+print(d['value'],d['ms_per_step'])
+for e in d['roofline']['by_kernel']: print(e['kernel'][:70],e['ms_per_segment'],e['launches'],e['frac'])
+print({k:(v['ms_per_segment'],v['launches'],v['frac_of_peak']) for k,v in d['roofline']['hbm']['kernels'].items()})" 2>&1 | tee gpurun_out/r5b_roof.log
+    ;;
+  r5c)        # round 5: the high-precision first-stage encoder: kernel tests, encoder vs oracle, smooth workload, the production-schedule harness runs
+    timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_nets_gpu.py -q -x -k "hp_ or vae_small or conv_f32" 2>&1 | tail -15 | tee gpurun_out/r5c_tests.log
+    timeout 900 python tools/x0_probe.py c2s 50 "default" 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/r5c_probe.log
+    timeout 1200 python -m pytest tests/test_workloads_gpu.py -q -k "c2s or c2-50 or c2-4" 2>&1 | tail -15 | tee gpurun_out/r5c_work.log
+    timeout 900 python -m pytest tests/test_cli_gpu.py -q -k "production_schedule" 2>&1 | tail -15 | tee gpurun_out/r5c_cli.log
+    for cfg in "--inflight 1" "--clips 2 --inflight 2"; do
+      tag=$(echo "$cfg" | tr -d ' -')
+      timeout 400 python bench.py $cfg --steps 6 --warmup 2 --no-roofline --no-cpu-baseline --no-one-at-a-time 2> gpurun_out/r5c_bench_$tag.err | tail -1 > gpurun_out/r5c_bench_$tag.json
+      python -c "import json;d=json.load(open('gpurun_out/r5c_bench_$tag.json'));print('$cfg:',d['value'],'fps',d['ms_per_step'],'ms/step')" 2>&1 | tee -a gpurun_out/r5c_bench.log
+    done
+    ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac
