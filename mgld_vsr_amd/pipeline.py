@@ -274,7 +274,7 @@ class VSRPipeline:
             post = None
         else:
             if init_from_vq:
-                post, enc_fea = vq.encode(x)
+                post, enc_fea = vq.encode(x, hp=True)
             else:
                 post = m.encode_first_stage(x)
             init_latent = None

@@ -247,15 +247,18 @@ class Encoder(nn.Module):
         hip.nchw_to_nhwc_f32(x, xa.v)
         eng.launches += 1
         h = _f32_conv(eng, self.conv_in, xa, (3, 3), (1, 1))
+        fea = []
         for lvl in range(self.num_resolutions):
             for blk in self.down[lvl].block:
                 h = blk.run_hp(eng, h)
+            if lvl in (1, 2):
+                fea.append(h)                                   # (fp32; the video VAE's decoder features when it encodes this way)
             if lvl != self.num_resolutions - 1:
                 h = self.down[lvl].downsample.run_hp(eng, h)
         h = self.mid.block_1.run_hp(eng, h)
         h = self.mid.attn_1.run_hp(eng, h)
         h = self.mid.block_2.run_hp(eng, h)
-        return _f32_conv(eng, self.conv_out, _hp_split(eng, h, self.norm_out, True, out_f32=True), (3, 3), (1, 1))
+        return _f32_conv(eng, self.conv_out, _hp_split(eng, h, self.norm_out, True, out_f32=True), (3, 3), (1, 1)), fea
 
 
 class Decoder(nn.Module):
@@ -508,6 +511,15 @@ class _AutoencoderBase(nn.Module):
             eng.linear(h, wq, eng.f32("b", self.quant_conv.bias), out=m, w2=wq2)
         return eng.to_nchw(m, 2 * self.embed_dim), fea
 
+    def _moments_hp(self, eng, x):
+        """the moments through the high-precision encoder + quant_conv on the f32-input MFMA -> (NCHW fp32, [fp32 feature Acts])"""
+        h, fea = self.encoder.run_hp(eng, x.contiguous())
+        m = _f32_conv(eng, self.quant_conv, h)
+        out = torch.empty(m.n, m.C, m.h, m.w, dtype=torch.float32, device=eng.device)
+        hip.nhwc_to_nchw(m.v, out)
+        eng.launches += 1
+        return out, fea
+
     def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
         """autoencoder.py:1652-1672: accepts full-model checkpoints by stripping the `first_stage_model.` prefix."""
         from .util import load_trusted_checkpoint
@@ -556,22 +568,13 @@ class AutoencoderKL(_AutoencoderBase):
             out = self.decoder.run(eng, zq)
         return eng.to_nchw(out, self.decoder.out_ch)
 
-    def _moments_hp(self, eng, x):
-        """the moments through the high-precision encoder + quant_conv on the f32-input MFMA -> NCHW fp32"""
-        h = self.encoder.run_hp(eng, x.contiguous())
-        m = _f32_conv(eng, self.quant_conv, h)
-        out = torch.empty(m.n, m.C, m.h, m.w, dtype=torch.float32, device=eng.device)
-        hip.nhwc_to_nchw(m.v, out)
-        eng.launches += 1
-        return out
-
     @torch.no_grad()
     def encode(self, x, return_encfea=False):
         """autoencoder.py:347-353: the posterior, plus the moments tensor it was built from when `return_encfea`"""
         eng = self.engine()
         eng.reset()
         if HP_ENCODER:
-            m = self._moments_hp(eng, x.to(eng.device, torch.float32))
+            m, _ = self._moments_hp(eng, x.to(eng.device, torch.float32))
         else:
             m, _ = self._moments(eng, x.to(eng.device, torch.float32))
         posterior = DiagonalGaussianDistribution(m)
@@ -599,11 +602,17 @@ class VideoAutoencoderKLResi(_AutoencoderBase):
             self.init_from_ckpt(ckpt_path, ignore_keys)
 
     @torch.no_grad()
-    def encode(self, x):
-        """-> (DiagonalGaussianDistribution, [fea1, fea2]); features stay on the device as NHWC fp16 Acts."""
+    def encode(self, x, hp=False):
+        """-> (DiagonalGaussianDistribution, [fea1, fea2]); features stay on the device as NHWC fp16 Acts.
+        hp: the posterior of this call becomes the sampler's struct-cond latent (the `_old` / `_w_latent` scripts take it from the video
+        VAE, old.py:328-329): run the encoder in high precision like the first-stage one (the features are its fp32 ones, rounded once)."""
         eng = self.engine()
         eng.reset()
-        m, fea = self._moments(eng, x.to(eng.device, torch.float32))
+        if hp and HP_ENCODER:
+            m, f32s = self._moments_hp(eng, x.to(eng.device, torch.float32))
+            fea = [_hp_split(eng, f).cols(0, f.C) for f in f32s]        # first block of the split = fp16(f)
+        else:
+            m, fea = self._moments(eng, x.to(eng.device, torch.float32))
         # features outlive the arena pass: move them to owned storage
         keep = []
         for f in fea:

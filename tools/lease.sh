@@ -97,5 +97,12 @@ print({k:(v['ms_per_segment'],v['launches'],v['frac_of_peak']) for k,v in d['roo
       python -c "import json;d=json.load(open('gpurun_out/r5c_bench_$tag.json'));print('$cfg:',d['value'],'fps',d['ms_per_step'],'ms/step')" 2>&1 | tee -a gpurun_out/r5c_bench.log
     done
     ;;
+  hpprof)     # the high-precision first-stage encode: time vs the fp16 encoder, per-kernel split under rocprofv3
+    for hp in 1 0; do MGLD_HP_ENCODER=$hp timeout 300 python tools/hp_bench.py 8 16 2>&1 | grep HP_ENCODER | tee -a gpurun_out/hp_bench.log; done
+    R=$GRAFT_REPO_ROOT; rm -rf $R/gpurun_out/hpprof; mkdir -p $R/gpurun_out/hpprof
+    ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/hpprof -o hp -- python $R/tools/hp_bench.py 8 > /dev/null 2>&1 )
+    python tools/kstats.py gpurun_out/hpprof 2>/dev/null | head -30 | cut -c1-200 | tee gpurun_out/hp_kstats.txt
+    find gpurun_out/hpprof -name "*.csv" -size +1M -delete
+    ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac
