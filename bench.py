@@ -56,11 +56,12 @@ def parse():
                          "latency-bound stretches of the others: same result per segment (tested bit for bit), higher frames/s, "
                          "proportionally longer per-segment latency.  0 (default) = 3 up to 8 x 512^2 frames per segment, 2 up to twice "
                          "that, else 1 (arena memory)")
-    ap.add_argument("--clips", type=int, default=1,
+    ap.add_argument("--clips", type=int, default=0,
                     help="independent segments batched as CLIPS of one pass (round 5): a step runs `clips` segments of --frames frames through "
                          "ONE encode / sampling / decode pass (the UNet sees clips x frames frames per launch, each clip with its own temporal "
                          "windows, flows and noise), so the low-resolution levels and the projections get clips x the rows per launch.  The "
-                         "result of every clip is what it produces alone (tested).  Default scheduling: see --inflight")
+                         "result of every clip is what it produces alone (tested).  0 (default) = 2 for segments up to 8 x 512^2 frames in the plain "
+                         "segment-parallel mode (measured best with two such passes in flight: profiles/r05_clips_inflight.txt), else 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-one-at-a-time", action="store_true", help="skip the second scheduling leg (profiling runs of the segments in flight)")
@@ -390,6 +391,9 @@ def main():
         raise SystemExit(spawn_ranks(args))      # plain `python bench.py --gpus N`: launch the N ranks, rank 0 prints the line
     TILE = (64, 32) if args.tile else None
     GRAPH = not args.no_graph
+    if args.clips <= 0:     # default scheduling (measured, profiles/r05_clips_inflight.txt): two segments per pass, two passes in flight
+        small = args.frames * args.size * args.size <= 8 * 512 * 512
+        args.clips = 2 if (small and not (args.tile or args.frame_shard or args.tile_shard or args.spawn_selftest) and args.steps >= 2) else 1
     if args.spawn_selftest:
         from mgld_vsr_amd import parallel
         backend = "gloo" if not torch.cuda.is_available() else args.backend
@@ -459,6 +463,8 @@ def main():
     else:
         px = args.clips * args.frames * args.size * args.size
         inflight = 3 if px <= 8 * 512 * 512 else (2 if px <= 16 * 512 * 512 else 1)
+        if args.clips > 1:
+            inflight = 2 if px <= 16 * 512 * 512 else 1
     if shard is not None:
         inflight = 1                          # the sharded modes spread ONE segment over the ranks
     inflight = max(1, min(inflight, args.steps))
@@ -491,20 +497,32 @@ def main():
                    "how": "hipEvent pair around each segment on its own stream, all timed segments"}
         # the OTHER scheduling, outside the contract's timed region: the same K segments one at a time on this rank's first
         # instance (the reference's loop); reported next to `value`, never instead of it
+        # (with clips > 1 this leg runs ONE clip per pass: single segments, as the reference's loop does)
+        T1 = args.frames
+        one = (frames[:T1], {"posterior": noise["posterior"][:T1], "x_T": noise["x_T"][:T1], "steps": noise["steps"][:, :T1]},
+               None if flows is None else tuple(f[:1] for f in flows), None if masks is None else tuple(m_[:1] for m_ in masks))
+
+        def step1():
+            fl, mk = one[2], one[3]
+            if args.raft and args.guidance:
+                fl, mk = pipe.estimate_flows(one[0])
+            return pipe.run_segment(one[0], flows=fl, masks=mk, noise=one[1], tile=TILE, use_graph=GRAPH)
+        if not args.no_one_at_a_time:
+            step1()                                 # (the single-clip launch list has its own graph: capture it outside the timed leg)
         parallel.barrier()
         t1 = time.perf_counter()
         e_lat = []
         for j in range(0 if args.no_one_at_a_time else args.steps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            step()
+            step1()
             b.record()
             e_lat.append((a, b))
         parallel.barrier()
         dt1 = parallel.max_over_ranks(time.perf_counter() - t1)
         l1 = sorted(a.elapsed_time(b) for a, b in e_lat)
         pool.close()
-        one_at_a_time = None if args.no_one_at_a_time else {"value": round((1 if shard is not None else world) * args.clips * args.frames * args.steps / dt1, 4), "ms_per_step": round(1e3 * dt1 / args.steps, 2),
+        one_at_a_time = None if args.no_one_at_a_time else {"value": round((1 if shard is not None else world) * args.frames * args.steps / dt1, 4), "ms_per_step": round(1e3 * dt1 / args.steps, 2),
                          "segment_latency_ms": round(l1[len(l1) // 2], 1), "steps": args.steps}
     else:
         for _ in range(args.warmup):

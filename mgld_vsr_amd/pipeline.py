@@ -363,6 +363,7 @@ class SegmentPool:
         self.stagger_ms = float(os.environ.get("MGLD_STAGGER_MS", "20"))
         self.last_latency_ms = {}     # slot -> GPU-side latency of that job in the last _drive call (hipEvent pair on the worker's stream)
         self.closed = False
+        self.broken = False           # a worker thread died: no more jobs, close() still joins the others
         for t in self._threads:
             t.start()
 
@@ -411,6 +412,8 @@ class SegmentPool:
                 self._sem.release()
 
     def close(self):
+        """stop and join the workers.  Also after a worker died (`_drive` marks the pool broken, not closed): the SURVIVING workers
+        still get their sentinel and are joined, so their threads, pipeline instances and split-K scratch go away with the pool."""
         if self.closed:
             return
         self.closed = True
@@ -430,8 +433,8 @@ class SegmentPool:
     def _drive(self, plan):
         """plan[i] = list of (slot, call) for worker i, call(pipeline instance) -> result; returns {slot: result}.  The GPU-side latency
         of every job (first launch .. last kernel, measured with a hipEvent pair on the worker's stream) lands in last_latency_ms."""
-        if self.closed:
-            raise RuntimeError("SegmentPool is closed")
+        if self.closed or self.broken:
+            raise RuntimeError("SegmentPool is closed" if self.closed else "SegmentPool is broken (a worker thread died): close() it")
         out, lat, errs = {}, {}, []
         ready = torch.cuda.Event()
         ready.record()                     # whatever the caller enqueued for the jobs (inputs, pre-drawn noise) on ITS stream ...
@@ -443,7 +446,7 @@ class SegmentPool:
         for _ in range(n):
             while not self._sem.acquire(timeout=5.0):      # a worker that died outside its try block would never release: notice it
                 if not all(t.is_alive() for t in self._threads):
-                    self.closed = True
+                    self.broken = True                     # (not `closed`: close() must still shut the surviving workers down)
                     raise RuntimeError("SegmentPool: a worker thread died" + (f": {errs[0]!r}" if errs else ""))
         self.last_latency_ms = lat
         if errs:

@@ -511,14 +511,31 @@ class _AutoencoderBase(nn.Module):
             eng.linear(h, wq, eng.f32("b", self.quant_conv.bias), out=m, w2=wq2)
         return eng.to_nchw(m, 2 * self.embed_dim), fea
 
-    def _moments_hp(self, eng, x):
-        """the moments through the high-precision encoder + quant_conv on the f32-input MFMA -> (NCHW fp32, [fp32 feature Acts])"""
-        h, fea = self.encoder.run_hp(eng, x.contiguous())
-        m = _f32_conv(eng, self.quant_conv, h)
-        out = torch.empty(m.n, m.C, m.h, m.w, dtype=torch.float32, device=eng.device)
-        hip.nhwc_to_nchw(m.v, out)
-        eng.launches += 1
-        return out, fea
+    HP_FRAMES = 4      # frames per pass of the high-precision encoder (every op of it is per frame): bounds its fp32 arena to ~17 GiB at 512^2
+
+    def _moments_hp(self, eng, x, want_fea=False):
+        """the moments through the high-precision encoder + quant_conv on the f32-input MFMA -> (NCHW fp32, [fp16 feature Acts in
+        owned storage] when want_fea).  Runs HP_FRAMES frames at a time and rewinds the arena between the passes (stream-ordered
+        reuse): the fp32 / split tensors of the 512^2 level are 1-1.6 GB per 8 frames each."""
+        x = x.contiguous()
+        n, _, H, W = x.shape
+        out = torch.empty(n, 2 * self.embed_dim, H // 8, W // 8, dtype=torch.float32, device=eng.device)
+        keep = None
+        mark = (eng.arena.ci, eng.arena.off)
+        for c0 in range(0, n, self.HP_FRAMES):
+            c1 = min(n, c0 + self.HP_FRAMES)
+            eng.arena.ci, eng.arena.off = mark
+            h, fea = self.encoder.run_hp(eng, x[c0:c1])
+            m = _f32_conv(eng, self.quant_conv, h)
+            hip.nhwc_to_nchw(m.v, out[c0:c1])
+            eng.launches += 1
+            if want_fea:
+                if keep is None:
+                    keep = [Act(torch.empty(n * f.hw, f.C, dtype=torch.float16, device=eng.device), n, f.h, f.w) for f in fea]
+                for k, f in zip(keep, fea):
+                    hip.copy2d(_hp_split(eng, f).v[:, :f.C], k.v[c0 * f.hw:c1 * f.hw])      # first block of the split = fp16(f)
+                    eng.launches += 1
+        return out, keep
 
     def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
         """autoencoder.py:1652-1672: accepts full-model checkpoints by stripping the `first_stage_model.` prefix."""
@@ -609,10 +626,9 @@ class VideoAutoencoderKLResi(_AutoencoderBase):
         eng = self.engine()
         eng.reset()
         if hp and HP_ENCODER:
-            m, f32s = self._moments_hp(eng, x.to(eng.device, torch.float32))
-            fea = [_hp_split(eng, f).cols(0, f.C) for f in f32s]        # first block of the split = fp16(f)
-        else:
-            m, fea = self._moments(eng, x.to(eng.device, torch.float32))
+            m, keep = self._moments_hp(eng, x.to(eng.device, torch.float32), want_fea=True)
+            return DiagonalGaussianDistribution(m), keep
+        m, fea = self._moments(eng, x.to(eng.device, torch.float32))
         # features outlive the arena pass: move them to owned storage
         keep = []
         for f in fea:

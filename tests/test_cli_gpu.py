@@ -331,7 +331,8 @@ def test_fixed_size_cli_reproduces_the_reference_script_at_the_production_schedu
 def test_bench_json_line_contract(steps):
     """bench.py prints exactly ONE JSON line with the driver's keys, the roofline object of the dominant kernel and (when
     asked) the CPU baseline; run here on the reduced-width nets (a plumbing check — `config.reduced_width` says so).  steps = 1 is
-    the one-segment-at-a-time loop, steps = 4 the default scheduling: up to three segments in flight on the GPU (threads + streams)."""
+    the one-segment-at-a-time loop, steps = 4 the default scheduling (round 5): two segments batched as clips of each pass, two passes in
+    flight on the GPU (threads + streams)."""
     import json
     env = dict(os.environ, PYTHONPATH=ROOT)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--frames", "2", "--size", "128", "--ddpm-steps", "3",
@@ -341,7 +342,8 @@ def test_bench_json_line_contract(steps):
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["config"]["segments_in_flight"] == min(3, steps)
+    assert d["config"]["segments_in_flight"] == min(2, steps) and d["config"]["clips_per_pass"] == (2 if steps > 1 else 1)
+    assert d["config"]["frames_per_step"] == d["config"]["clips_per_pass"] * 2
     # the latency is MEASURED (hipEvent pair around every segment on its stream), not ms_per_step x segments in flight; both schedulings
     # are in the line: `value` = the default one, `value_one_at_a_time` = the reference's loop
     lat = d["config"]["segment_latency"]

@@ -261,3 +261,70 @@ def test_comm_plan_figures():
     assert len(halos) == 5 and halos[-1][3] == 2 * 3 * 512 * 512 * 128 * 2            # 1 + 4 x 3 = 13 temporal convolutions
     assert p["bytes_per_segment"] == 50 * p["bytes_per_step"] + sum(e[2] * e[3] for e in p["per_segment"])
     assert parallel.comm_plan("segment", world=8)["bytes_per_segment"] == 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the frame-split video decode at world 8: exchanged bytes LOGGED by DistComm.report() == comm_plan()'s prediction
+# ----------------------------------------------------------------------------------------------------------------------
+def _decode_comm_worker(rank, world, port, ret):
+    """walks the REAL decoder module (VideoDecoder_Mix at the shipped width, meta parameters) the way its run() does — conv_in, mid
+    block + temporal_mixing, per level the res-blocks each followed by a temporal_mixing, upsample — and performs the one-frame halo
+    exchange of every SpatialTemporalConv with tensors of the real shape through FrameShard.halo / DistComm (gloo), one frame per rank"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mgld_vsr_amd import parallel
+    from mgld_vsr_amd.pipeline import model_configs
+    from mgld_vsr_amd.unet import SpatialTemporalConv
+    from mgld_vsr_amd.vae import VideoDecoder_Mix
+    parallel.init(backend="gloo")
+    T, H = world, 64
+    dd = dict(model_configs(T)[1]["params"]["ddconfig"], resolution=H)
+    dec = VideoDecoder_Mix(**dd)
+    sh = parallel.FrameShard(T, rank, world)
+    parallel.DistComm.measure = True
+    parallel.DistComm.report()
+    n_tconv = 0
+
+    def halo(mod, h, w):
+        nonlocal n_tconv
+        assert isinstance(mod, SpatialTemporalConv)
+        C = mod.temporal_conv.weight.shape[0]
+        x = torch.full((sh.F * h * w, C), float(rank), dtype=torch.float16)
+        left, right = torch.empty(h * w, C, dtype=torch.float16), torch.empty(h * w, C, dtype=torch.float16)
+        sh.halo(x, h * w, left, right)
+        assert float(left[0, 0]) == (rank - 1 if rank > 0 else 0.0) and float(right[0, 0]) == (rank + 1 if rank < world - 1 else 0.0)
+        n_tconv += 1
+    h = w = H // 8
+    halo(dec.temporal_mixing, h, w)
+    for lvl in reversed(range(dec.num_resolutions)):
+        for b in range(dec.num_res_blocks + 1):
+            halo(dec.up[lvl].temporal_mixing[b], h, w)
+        if lvl != 0:
+            h, w = 2 * h, 2 * w
+    rep = parallel.DistComm.report()
+    parallel.DistComm.measure = False
+    ret[rank] = (n_tconv, rep, dd["ch"], tuple(dd["ch_mult"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharded_decode_comm_bytes_match_the_plan_at_world_8():
+    """the halo bytes of the frame-split video decode, logged exchange by exchange at world 8 (gloo), equal what
+    parallel.comm_plan() predicts for the same geometry: middle ranks send to both neighbours, the two end ranks to one"""
+    sys.path.insert(0, ROOT)
+    from mgld_vsr_amd import parallel
+    world = 8
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_decode_comm_worker, args=(world, port, ret), nprocs=world, join=True)
+    n_tconv, _, ch, ch_mult = ret[0]
+    plan = parallel.comm_plan("frame", T=world, H=64, W=64, world=world, steps=50, ch=ch, ch_mult=ch_mult)
+    halos = [(c, b) for what, kind, c, b in plan["per_segment"] if kind == "p2p"]
+    assert n_tconv == 1 + sum(3 for _ in ch_mult) == 13
+    want_mid = sum(c * b for c, b in halos)                 # both neighbours
+    for r in range(world):
+        nt, rep, _, _ = ret[r]
+        assert nt == n_tconv and rep["calls"] == n_tconv
+        assert rep["bytes"] == (want_mid if 0 < r < world - 1 else want_mid // 2), (r, rep, want_mid)
