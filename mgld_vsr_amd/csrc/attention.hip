@@ -56,10 +56,18 @@ __device__ __forceinline__ at_u64 at_tr_read(const unsigned lds_addr) {
   return r;
 }
 
-template <int D, bool VRM = false, bool DMA = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 2, D == 64 ? 3 : 2)))
+// QH (round 5): 32-row query tiles per wave.  QH = 2: a wave owns 64 query rows, every K / V fragment it reads from LDS feeds two
+// MFMAs (the four waves of a block all stream the same K / V tile: with 32 rows per wave the CU's LDS moves 16 KB per wave and tile,
+// 128 cycles against the 512 matrix cycles of that tile — on twelve resident waves as much LDS time as matrix time), and the two
+// accumulator chains of a k step interleave.  Costs registers: 214 VGPRs, two waves per SIMD instead of three.  MEASURED SLOWER
+// (profiles/r05_attn_qh.txt: 64^2 self-attention 280.8 -> 298.7 us, 32^2 45.6 -> 50.4 us; end to end 13.60 vs 13.57 frames/s): halving the
+// LDS traffic per MFMA buys less than the third wave per SIMD hides — LDS bandwidth is not what bounds this kernel.  Kept as an
+// opt-in (MGLD_ATTN_QH=2, covered by test_flash_attention_production_shapes), default QH = 1.
+template <int D, bool VRM = false, bool DMA = false, int QH = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? (QH == 2 ? 2 : 3) : 2, D == 64 ? (QH == 2 ? 2 : 3) : 2)))
 void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   static_assert(!DMA || (VRM && D == 64), "DMA staging: head_dim 64, row-major V");
+  static_assert(QH == 1 || (QH == 2 && DMA), "64 query rows per wave: the DMA form only");
   constexpr int KT = 64;             // keys per tile
   constexpr int KS = DMA ? D : D + 8;  // K LDS row stride (halves): padded rows -> conflict-free ds_read_b128; DMA: swizzled 128-byte rows
   constexpr int VS = KT + 4;         // V^T LDS row stride (halves): 34 banks -> conflict-free ds_read_b64
@@ -88,7 +96,7 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
     b = g / (int)gridDim.y;
     h = g - b * (int)gridDim.y;
   }
-  const int q0 = bx * 128 + wave * 32;
+  const int q0 = bx * (128 * QH) + wave * (32 * QH);
   const int Nq = p.Nq, Nkv = p.Nkv;
 
   const f16* __restrict__ Qp = (const f16*)p.Q + b * p.q_sb + h * p.q_sh;
@@ -98,20 +106,25 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0+l31][ks*16 + lhi*8 .. +8]
-  f16x8 qf[DK];
-  {
-    const int q = q0 + l31;
+  f16x8 qf[QH][DK];
+#pragma unroll
+  for (int qh = 0; qh < QH; ++qh) {
+    const int q = q0 + qh * 32 + l31;
 #pragma unroll
     for (int ks = 0; ks < DK; ++ks)
-      qf[ks] = (q < Nq) ? *(const f16x8*)(Qp + (int64_t)q * p.q_si + ks * 16 + lhi * 8) : zero8;
+      qf[qh][ks] = (q < Nq) ? *(const f16x8*)(Qp + (int64_t)q * p.q_si + ks * 16 + lhi * 8) : zero8;
   }
 
-  f32x16 o[DT];
+  f32x16 o[QH][DT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
+  for (int qh = 0; qh < QH; ++qh)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qh][dt][r] = 0.f;
+  float m_run[QH], l_run[QH];
+#pragma unroll
+  for (int qh = 0; qh < QH; ++qh) { m_run[qh] = -1e30f; l_run[qh] = 0.f; }
   const float sc = p.scale * 1.44269504088896340736f;  // fold log2(e): softmax via exp2
 
   // ---- DMA staging: a tile is 8 K pieces (8 keys x 128 B) + 8 V pieces (16 keys x 64 B of one d half); wave w moves pieces w, w + 4
@@ -231,16 +244,19 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
     const f16* const sV = sVb + cur * VBUF;
 
     // ---- S^T = K Q^T for 2 key tiles of 32 ----
-    f32x16 st[2];
+    f32x16 st[QH][2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[k2][r] = 0.f;
+      for (int qh = 0; qh < QH; ++qh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[qh][k2][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
         const f16x8 kf = DMA ? *(const f16x8*)((const char*)sK + k_rd[ks] + k2 * 4096)
                              : *(const f16x8*)(sK + (k2 * 32 + l31) * KS + ks * 16 + lhi * 8);
-        st[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[k2], 0, 0, 0);
+#pragma unroll
+        for (int qh = 0; qh < QH; ++qh) st[qh][k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qh][ks], st[qh][k2], 0, 0, 0);
       }
     }
     // ---- online softmax (lane: query q0+l31; keys (r&3)+8*(r>>2)+4*lhi of each 32-key tile) ----
@@ -248,41 +264,46 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
     // element, p = exp2(s*sc - m*sc).  Keys past Nkv exist only in the last tile (wave-uniform branch).
     if (kbase + KT > Nkv) {
 #pragma unroll
+      for (int qh = 0; qh < QH; ++qh)
+#pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kbase + k2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (key >= Nkv) st[k2][r] = -1e30f;
+          if (key >= Nkv) st[qh][k2][r] = -1e30f;
         }
     }
+#pragma unroll
+    for (int qh = 0; qh < QH; ++qh) {
     float mx = -1e30f;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[k2][r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[qh][k2][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run[qh], mx);
     const float mneg = -m_new * sc;
     float rs = 0.f;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[k2][r], sc, mneg));
-        st[k2][r] = e;
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qh][k2][r], sc, mneg));
+        st[qh][k2][r] = e;
         rs += e;
       }
     rs += __shfl_xor(rs, 32, 64);
-    if (__any(m_new != m_run)) {  // rescale only when some row's max moved (rare after the first tiles)
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-      l_run *= alpha;
+    if (__any(m_new != m_run[qh])) {  // rescale only when some row's max moved (rare after the first tiles)
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qh] - m_new) * sc);
+      l_run[qh] *= alpha;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[qh][dt][r] *= alpha;
     }
-    l_run += rs;
-    m_run = m_new;
+    l_run[qh] += rs;
+    m_run[qh] = m_new;
+    }
 
     // ---- O^T += V^T P^T : 4 chunks of 16 keys; slot jj of chunk c <-> register 8*(c&1)+jj of tile c>>1 ----
     at_u64 vlo[4][2], vhi[4][2];
@@ -299,9 +320,11 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int k2 = c >> 1, c2 = c & 1;
-      f16x8 pf;
+      f16x8 pf[QH];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) pf[jj] = (f16)st[k2][c2 * 8 + jj];
+      for (int qh = 0; qh < QH; ++qh)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf[qh][jj] = (f16)st[qh][k2][c2 * 8 + jj];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         f16x8 vf;
@@ -323,7 +346,8 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
           const f16x4 v1 = *(const f16x4*)(vrow + 8);
           vf = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         }
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+#pragma unroll
+        for (int qh = 0; qh < QH; ++qh) o[qh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qh], o[qh][dt], 0, 0, 0);
       }
     }
     if constexpr (DMA) {
@@ -335,18 +359,21 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ----
-  const int q = q0 + l31;
+#pragma unroll
+  for (int qh = 0; qh < QH; ++qh) {
+  const int q = q0 + qh * 32 + l31;
   if (q < Nq) {
-    const float inv = 1.f / l_run;
+    const float inv = 1.f / l_run[qh];
     f16* Op = (f16*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_si;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int d = dt * 32 + rg * 8 + lhi * 4;
-        *(f16x4*)(Op + d) = f16x4{(f16)(o[dt][rg * 4 + 0] * inv), (f16)(o[dt][rg * 4 + 1] * inv),
-                                  (f16)(o[dt][rg * 4 + 2] * inv), (f16)(o[dt][rg * 4 + 3] * inv)};
+        *(f16x4*)(Op + d) = f16x4{(f16)(o[qh][dt][rg * 4 + 0] * inv), (f16)(o[qh][dt][rg * 4 + 1] * inv),
+                                  (f16)(o[qh][dt][rg * 4 + 2] * inv), (f16)(o[qh][dt][rg * 4 + 3] * inv)};
       }
+  }
   }
 }
 
@@ -381,6 +408,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }  // namespace
 
 // does the launcher stage K / V by LDS-DMA for this problem (flash_attn_kernel<64, true, true>)?  env MGLD_ATTN_DMA = 0: never (A/B)
+// 64 query rows per wave (flash_attn_kernel<64, true, true, 2>): env MGLD_ATTN_QH = 2 selects it (A/B; measured slower, see the kernel)
+static int attn_qh(const MgldAttn* p);
 static bool attn_takes_dma(const MgldAttn* p) {
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("MGLD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
@@ -388,12 +417,20 @@ static bool attn_takes_dma(const MgldAttn* p) {
          ((int64_t)p->Nkv * p->vt_sd * 2 < 0x7fffffffLL);
 }
 
+static int attn_qh(const MgldAttn* p) {
+  static int qh = -1;
+  if (qh < 0) { const char* e = getenv("MGLD_ATTN_QH"); qh = e ? atoi(e) : 1; }
+  // enough 256-row query blocks to fill the chip (the 64^2 / 32^2 self-attention levels); shorter sequences keep the 128-row blocks
+  return (qh == 2 && attn_takes_dma(p) && (p->Nq % 256) == 0 && (int64_t)(p->Nq / 256) * p->heads * p->batch >= 256) ? 2 : 1;
+}
+
 // name of the kernel instantiation mgld_attention launches for this problem, as rocprofv3 --kernel-trace prints it
 extern "C" int mgld_attention_kernel_name(const MgldAttn* p, char* buf, int buflen) {
   MGLD_REQUIRE(p && buf && buflen > 0, "attention_kernel_name: null");
   MGLD_REQUIRE(p->head_dim == 64 || p->head_dim == 128, "attention: head_dim must be 64 or 128");
-  if (p->v_rowmajor) snprintf(buf, buflen, "flash_attn_kernel<%d, true, %s>", p->head_dim, attn_takes_dma(p) ? "true" : "false");
-  else snprintf(buf, buflen, "flash_attn_kernel<%d, false, false>", p->head_dim);
+  if (p->v_rowmajor && attn_qh(p) == 2) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 2>");
+  else if (p->v_rowmajor) snprintf(buf, buflen, "flash_attn_kernel<%d, true, %s, 1>", p->head_dim, attn_takes_dma(p) ? "true" : "false");
+  else snprintf(buf, buflen, "flash_attn_kernel<%d, false, false, 1>", p->head_dim);
   return 0;
 }
 
@@ -425,7 +462,10 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
       (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
       attr_done2 = true;
     }
-    if (attn_takes_dma(p))
+    if (attn_qh(p) == 2) {
+      const dim3 grid2(p->Nq / 256, p->heads, p->batch);
+      hipLaunchKernelGGL((flash_attn_kernel<64, true, true, 2>), grid2, dim3(256), LDS64, (hipStream_t)stream, *p, order);
+    } else if (attn_takes_dma(p))
       hipLaunchKernelGGL((flash_attn_kernel<64, true, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
     else if (p->head_dim == 64)
       hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);

@@ -300,6 +300,25 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
     }
     return;
   }
+  if (p.out_f32) {                                 // fp32 rows + fp32 residual: lane = one output row, 4 consecutive channels per fragment
+    float* Cf = (float*)p.C;
+    const float* Rf = p.r_f32 ? (const float*)p.R : nullptr;
+    const int nb = bn0 + wn * WN + 4 * g;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = row_of(mi);
+      if (m < 0) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = nb + ni * 16;
+        f32x4 v = acc[ni][mi];
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (Rf) v += p.beta * *(const f32x4*)(Rf + (int64_t)m * p.ldr + n);
+        *(f32x4*)(Cf + (int64_t)m * p.ldc + n) = v;
+      }
+    }
+    return;
+  }
   if (p.gn_part) {
     // GroupNorm statistics of the output (MgldIGemm.gn_part): every wave's per-channel sums of its stored rows meet in LDS (the stages
     // are dead: both wave groups are past their last fragment read), one row of part[] per tile.  A tile lies in one frame.
@@ -382,8 +401,12 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
   if (!knob || p->mode != MGLD_MODE_CONV3X3 || p->tap_inner != 2) return false;
   if (p->tune != 0 && (p->tune < 30 || p->tune > 30 + R3_NCFG) && (p->tune < 50 || p->tune >= 50 + R3_NCFG)) return false;
   if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
-  if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->out_f32 || p->bias_m || (p->Cin & 31)) return false;
+  if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->bias_m || (p->Cin & 31)) return false;
   if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU)) return false;
+  // fp32 output (+ fp32 residual): the plain form only — bias, no activation / row vector / statistics (the split-fp16 convolutions of
+  // the high-precision encoder, hpenc.hip)
+  if (p->out_f32 && (p->act != MGLD_ACT_NONE || p->rowvec || p->gn_part || p->alpha != 1.f || (p->R && !p->r_f32) || (p->N & 3))) return false;
+  if (p->r_f32 && !p->out_f32) return false;
   const bool w8 = (p->Hout == 8 && p->Wout == 8);     // the 8^2 level: frame-stacked tiles (configurations 9, 10), K split only
   if (p->Hout != p->Hin || p->Wout != p->Win || (!w8 && (p->Wout < 16 || p->Hout < 8)) || (p->M % (p->Hout * p->Wout))) return false;
   if (w8 && p->W2) return false;

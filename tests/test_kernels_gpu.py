@@ -1105,7 +1105,12 @@ def test_flash_attention_production_shapes(hip, B, H, Nq, Nkv, D, rowmajor):
     scale = D ** -0.5
     g = torch.Generator().manual_seed(77)
     if rowmajor:
-        qkv = (torch.randn(B * Nq, 3 * C_, generator=g) * 0.8).half().to(DEV)
+        qkv = (torch.randn(B * Nq, 3 * C_, generator=g) * 0.8).half()
+        # spikes: keys that match one query far better than the rest, late in the key axis — the online-softmax rescale path of a row in
+        # the FIRST and of a row in the SECOND 32-row half of a wave's 64 query rows (flash_attn_kernel<64, true, true, 2>), frame 0 head 0
+        for qrow, krow in ((7, Nkv - 100), (40, Nkv - 37)):
+            qkv[krow, C_:C_ + D] = qkv[qrow, :D] * 4
+        qkv = qkv.to(DEV)
         q2, k2, v2 = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
         st = (Nq * 3 * C_, 3 * C_, D)
         o = torch.empty(B * Nq, C_, dtype=torch.half, device=DEV)
@@ -1258,7 +1263,7 @@ def test_hp_softmax_rows(hip):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,stride", [(2, 32, 32, 128, 128, 1), (1, 64, 48, 128, 256, 1), (2, 16, 16, 512, 512, 1), (2, 32, 32, 128, 128, 2),
-                                                    (1, 8, 8, 64, 32, 1)])
+                                                    (1, 8, 8, 64, 32, 1), (4, 256, 256, 128, 128, 1)])    # the last: enough tiles for the ping-pong kernel's fp32 epilogue
 def test_hp_split_convolution(hip, n, h, w, cin, cout, stride):
     """the split-fp16 contraction end to end: fp32 input -> mgld_hp_gn_split (identity) -> mgld_igemm over 3 Cin channels against
     engine.pack_hp weights, fp32 output + fp32 residual (MgldIGemm.r_f32) vs F.conv2d in fp64: ~1e-6 where the plain fp16 kernels
@@ -1280,6 +1285,13 @@ def test_hp_split_convolution(hip, n, h, w, cin, cout, stride):
     hip.hp_gn_split(xa, None, 0.0, None, None, False, a3, n, h * w, 1)
     wp = pack_conv3x3(pack_hp(wt), 3 * cin).half().to(DEV)
     kw = dict(stride=2, pad=(0, 0), hw_out=(ho, wo)) if stride == 2 else {}
-    out = eng.conv3x3(Act(a3, n, h, w), wp, b.to(DEV), cout, resid=Act(skip.to(DEV), n, ho, wo), out_dtype=torch.float32, **kw)
+    hip.IGEMM_LOG = []
+    try:
+        out = eng.conv3x3(Act(a3, n, h, w), wp, b.to(DEV), cout, resid=Act(skip.to(DEV), n, ho, wo), out_dtype=torch.float32, **kw)
+        log = hip.IGEMM_LOG
+    finally:
+        hip.IGEMM_LOG = None
     assert out.v.dtype == torch.float32
+    if n * h * w >= 1 << 18:
+        assert "conv3r" in hip.igemm_kernel_name(log[-1])[0]
     assert rel_l2(out.v.cpu().double(), ref) < 3e-6

@@ -104,5 +104,14 @@ print({k:(v['ms_per_segment'],v['launches'],v['frac_of_peak']) for k,v in d['roo
     python tools/kstats.py gpurun_out/hpprof 2>/dev/null | head -30 | cut -c1-200 | tee gpurun_out/hp_kstats.txt
     find gpurun_out/hpprof -name "*.csv" -size +1M -delete
     ;;
+  r5e)        # round 5: 64-query-row attention waves + the ping-pong kernel's fp32 epilogue: tests, microbenches, end to end
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "flash or attention or hp_" 2>&1 | tail -8 | tee gpurun_out/r5e_tests.log
+    for qh in 1 2; do echo "== MGLD_ATTN_QH=$qh"; MGLD_ATTN_QH=$qh timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r5e_attn.log
+    timeout 300 python tools/hp_bench.py 8 2>&1 | grep HP_ENCODER | tee gpurun_out/r5e_hp.log
+    for envs in "MGLD_ATTN_QH=1" "MGLD_ATTN_QH=2"; do
+      env $envs timeout 400 python bench.py --steps 6 --warmup 2 --no-roofline --no-cpu-baseline --no-one-at-a-time 2>/dev/null | tail -1 > gpurun_out/r5e_bench_$envs.json
+      python -c "import json;d=json.load(open('gpurun_out/r5e_bench_$envs.json'));print('$envs:',d['value'],'fps',d['ms_per_step'],'ms/step')" 2>&1 | tee -a gpurun_out/r5e_bench.log
+    done
+    ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac
