@@ -21,7 +21,7 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-# the sources whose sha keys profiles/r04_pmc_traffic.json (tools/pmc_traffic.sh imports this list)
+# the sources whose sha keys profiles/r05_pmc_traffic.json (tools/pmc_traffic.sh imports this list)
 GEMM_FAMILY_SOURCES = ("igemm_common.h", "pp_common.h", "igemm.hip", "conv3q.hip", "conv3r.hip", "ppgemm.hip", "pptconv.hip", "attention.hip")
 sys.path.insert(0, ROOT)
 
@@ -174,7 +174,7 @@ def _pmc_traffic(kernel):
         sha = hashlib.sha256(src).hexdigest()[:16]
     except OSError:
         return None
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 pm = json.load(fh)
@@ -192,9 +192,9 @@ _pmc_traffic.source = None
 
 def _rocprof_avg(kernel):
     """average launch duration (us) of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this round's bench
-    command (profiles/r04_kernel_stats.json, written by tools/kstats.py), or None"""
+    command (profiles/r05_kernel_stats.json, written by tools/kstats.py from `bench.py --clips 2 --inflight 1 --steps 1 --warmup 1`), or None"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_kernel_stats.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r05_kernel_stats.json")) as fh:
             ks = json.load(fh)
     except (OSError, ValueError):
         return None
@@ -304,7 +304,7 @@ def roofline(pipe, args, frames, noise, flows, masks):
         "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
         # the same with the per-launch MINIMUM of the two passes (what round 3 reported), and with the average launch duration of the
-        # committed rocprofv3 --kernel-trace --stats summary of this command (profiles/r04_kernel_stats.json) when it has this kernel
+        # committed rocprofv3 --kernel-trace --stats summary of this command (profiles/r05_kernel_stats.json) when it has this kernel
         "frac_event_min": round(d["flops"] / (tmin[dom] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4),
         "frac_rocprof_avg": (round(d["flops"] / d["launches"] / (rp["avg_us"] * 1e-6) / 1e12 / PEAK_FP16_TFLOPS, 4) if rp else None),
         "rocprof_avg_us": (rp["avg_us"] if rp else None),
