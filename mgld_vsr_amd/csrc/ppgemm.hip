@@ -244,6 +244,10 @@ bool ppgemm_plan(const MgldIGemm* p, int* id) {
       if (4 * t > 3 * cus && t <= cus && a > area) { area = a; bid = i; }
     }
     if (bid < 0 && pp_cfg_fits(p, 0) && tiles_of(0) >= 2 * cus) bid = 0;
+    // round 5 (two segments batched as clips: M = 65536 at the 64^2 level): the 256 x 320 tile over WHOLE rounds — the fused q|k|v
+    // projection N = 960, K = 320 is 768 tiles = three full rounds: 87.6 -> 61.8 us (profiles/r05_pp_lin_mscale2.txt); ragged rounds of
+    // this short-K tile, and the 256 x 160 tile at K = 320 even in full rounds (46.8 vs 41.2 us at M = 32768), stay on the 128-class kernel
+    if (bid < 0 && pp_cfg_fits(p, 6) && tiles_of(6) >= 2 * cus && tiles_of(6) % cus == 0) bid = 6;
     if (bid < 0 && p->K >= 1024) {
       static const double eff[PP_NCFG] = {1.00, 0.90, 0.72, 0.85, 0.85, 0.68, 0.95};
       double best = 0.0;

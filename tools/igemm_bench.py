@@ -82,7 +82,9 @@ def main():
     e0, e1 = hip.Event(), hip.Event()
     out_rows = []
     totals = {v: 0.0 for v in allv}
+    mscale = int(os.environ.get("MGLD_BENCH_MSCALE", "1"))      # 2: the row counts of two segments batched as clips (bench.py --clips 2)
     for name, mode, M, N, K, Cin, H, W, act, up2, weight in shapes:
+        M *= mscale
         sc = 2 if up2 else 1
         frames = M // (H * W * sc * sc) if mode == 1 else 0
         a_rows = frames * H * W if mode == 1 else M
