@@ -301,6 +301,9 @@ def roofline(pipe, args, frames, noise, flows, masks):
                    "ms_per_segment": round(v["ms"], 2), "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2)}
                for n, v in hbm.items()}
     return {
+        # the pass that was timed: `clips` segments batched as clips of ONE pass (the default scheduling's launch shapes); every
+        # "..._per_segment" figure below is per such PASS, launches likewise — frac / achieved do not depend on that
+        "segments_per_pass": int(args.clips),
         "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
         # the same with the per-launch MINIMUM of the two passes (what round 3 reported), and with the average launch duration of the
