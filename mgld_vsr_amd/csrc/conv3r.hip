@@ -414,6 +414,7 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
   if (p->W2 && ((((uintptr_t)p->W2) & 15) || !(p->w2_scale > 0.f))) return false;
   if ((p->bias && (((uintptr_t)p->bias) & 15)) || (p->rowvec && ((((uintptr_t)p->rowvec) & 15) || (p->ld_rowvec & 3)))) return false;
   if ((int64_t)p->Hin * p->Win * p->lda * 2 >= 0x7fffffffLL) return false;      // a frame must fit the descriptor's 31-bit range
+  if ((int64_t)((p->N + 63) / 64 * 64) * 9 * p->Cin * 2 >= 0xffffffffLL) return false;   // the weight image is addressed with 32-bit byte offsets
   auto fits = [&](int i) { return p->N % R3_CFG[i].bn == 0 && (R3_CFG[i].tx == 8) == w8; };
   const int frames = p->M / (p->Hout * p->Wout), cus = num_cus();
   auto tiles_of = [&](int i) {

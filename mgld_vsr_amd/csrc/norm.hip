@@ -110,24 +110,26 @@ __device__ __forceinline__ void gn_group_stats(const double* __restrict__ gs, in
 // ---- the same from per-CHANNEL fp32 tile sums (kind 1: written by the ping-pong GEMM family's epilogue, MgldIGemm.gn_part):
 // part[frame * chunks + chunk][2][C] floats (sum row, sumsq row).  Only the groups of the caller's channel window [c_off, c_off + Cw) are
 // computed: threads run along channels (coalesced rows of part[], the chunk loads independent), the per-channel totals meet in LDS
-// (chs[2][Cw] floats, caller-provided) and one thread per group adds its cg channels in fp64.
+// (chs[2][Cw] DOUBLES, caller-provided) and one thread per group adds its cg channels in fp64.  The cross-chunk totals are fp64 too
+// (round 5): at the VAE's 256^2 / 512^2 planes a channel has 128-1024 tile sums, and for a channel with |mean| >> std the
+// variance q/n - mean^2 cancels — 1e-6 of relative error in the fp32 running totals was a percent of the variance.
 __device__ __forceinline__ void gn_group_stats_pc(const float* __restrict__ part, int chunks, int C, int c_off, int Cw, int rows, int cg,
-                                                  float eps, float (*st)[2], float* __restrict__ chs) {
+                                                  float eps, float (*st)[2], double* __restrict__ chs) {
   const int tid = threadIdx.x;
   for (int c = tid; c < 2 * Cw; c += 256) {
     const int which = c >= Cw, cc = c - which * Cw;
     const float* src = part + (int64_t)which * C + c_off + cc;
-    float a0 = 0.f, a1 = 0.f;
+    double a0 = 0.0, a1 = 0.0;
     int ch = 0;
-    for (; ch + 1 < chunks; ch += 2) { a0 += src[(int64_t)ch * 2 * C]; a1 += src[(int64_t)(ch + 1) * 2 * C]; }
-    if (ch < chunks) a0 += src[(int64_t)ch * 2 * C];
+    for (; ch + 1 < chunks; ch += 2) { a0 += (double)src[(int64_t)ch * 2 * C]; a1 += (double)src[(int64_t)(ch + 1) * 2 * C]; }
+    if (ch < chunks) a0 += (double)src[(int64_t)ch * 2 * C];
     chs[c] = a0 + a1;
   }
   __syncthreads();
   const int g0 = c_off / cg;
   for (int g = tid; g < Cw / cg; g += 256) {
     double s = 0.0, q = 0.0;
-    for (int i = 0; i < cg; ++i) { s += (double)chs[g * cg + i]; q += (double)chs[Cw + g * cg + i]; }
+    for (int i = 0; i < cg; ++i) { s += chs[g * cg + i]; q += chs[Cw + g * cg + i]; }
     const double nn = (double)rows * cg;
     const double mean = s / nn;
     double var = q / nn - mean * mean;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   // grid (row chunks, frames).  A thread owns ONE 8-channel vector column for all its rows, so the per-channel scale /
   // shift (rstd*gamma, beta - mean*rstd*gamma) are computed once into registers and the row loop is load-fma-store.
   __shared__ float st[GN_MAX_GROUPS][2];
-  extern __shared__ float sred[];               // STATS: [rpi][Cw][2]; statistics of kind 1: [2][Cw] in the prologue
+  extern __shared__ __attribute__((aligned(16))) float sred[];   // STATS: [rpi][Cw][2] floats; statistics of kind 1: [2][Cw] doubles in the prologue
   if (SPADE && step_idx) gb += (int64_t)step_idx[0] * gb_step_stride;   // gamma/beta table hoisted out of the step (see ddpm.py)
   const int c_off = blockIdx.z * Cb;            // this block's channel window [c_off, c_off + Cb)
   const int Cw = min(Cb, C - c_off);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   const int cg = C / groups;
   const int frame = blockIdx.y;
   if (kind == 1)
-    gn_group_stats_pc((const float*)sums + (int64_t)frame * chunks * 2 * C, chunks, C, c_off, Cw, rows_per_frame, cg, eps, st, sred);
+    gn_group_stats_pc((const float*)sums + (int64_t)frame * chunks * 2 * C, chunks, C, c_off, Cw, rows_per_frame, cg, eps, st, (double*)sred);
   else
     gn_group_stats((const double*)sums + (int64_t)frame * chunks * groups * 2, chunks, groups, rows_per_frame, cg, eps, st);
   const int rows_per_chunk = (rows_per_frame + gridDim.x - 1) / gridDim.x;
@@ -484,7 +486,7 @@ static dim3 apply_grid(int frames, int rows, int C, int groups, int* Cb) {
 // dynamic LDS of the STATS variants: [rows per pass][channel window][2] floats (largest over the windows of the launch)
 // + the prologue's per-channel table when the input statistics are per-channel tile sums
 static size_t apply_lds(const MgldGnStats* st, int C, int Cb, bool stats_out) {
-  const size_t a = stats_out ? row_slots_lds(C, Cb) : 0, b = st->kind == MGLD_GN_CHANNEL_SUMS ? (size_t)2 * Cb * sizeof(float) : 0;
+  const size_t a = stats_out ? row_slots_lds(C, Cb) : 0, b = st->kind == MGLD_GN_CHANNEL_SUMS ? (size_t)2 * Cb * sizeof(double) : 0;
   return a > b ? a : b;
 }
 
