@@ -249,6 +249,10 @@ int mgld_timestep_embedding(const float* tvals, int t_stride, float* out, int M,
 int mgld_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int cpad, int ld, void* stream);
 /* fp16/fp32 NHWC [n*h*w, ld] (first c channels) -> fp32 NCHW */
 int mgld_nhwc_to_nchw(const void* x, int in_f32, int ld, float* y, int n, int c, int h, int w, void* stream);
+/* packed 3x3 conv weights fp16 [N, 9*Cin] (K order (tap, Cin); tap_inner = 1: (64-channel block, tap, channel)) -> the tiled image the patch
+ * convolutions take (MgldIGemm.tap_inner = 2): fp16 [(N rounded up to 64) * 9 * Cin / 32, 32], zero rows past N.  The one-off re-layout
+ * of a convolution's weights on first use (round 5: a kernel instead of a torch gather). */
+int mgld_tile_conv3p(const void* wp, int N, int Cin, int tap_inner, void* out, void* stream);
 /* strided fp16 2-D copy: dst[r, 0:cols] = src[r, 0:cols]; cols % 8 == 0 */
 int mgld_copy2d(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols, void* stream);
 /* y = a*x + b*y (fp16, strided) */

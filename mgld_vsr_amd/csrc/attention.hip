@@ -63,11 +63,20 @@ __device__ __forceinline__ at_u64 at_tr_read(const unsigned lds_addr) {
 // (profiles/r05_attn_qh.txt: 64^2 self-attention 280.8 -> 298.7 us, 32^2 45.6 -> 50.4 us; end to end 13.60 vs 13.57 frames/s): halving the
 // LDS traffic per MFMA buys less than the third wave per SIMD hides — LDS bandwidth is not what bounds this kernel.  Kept as an
 // opt-in (MGLD_ATTN_QH=2, covered by test_flash_attention_production_shapes), default QH = 1.
-template <int D, bool VRM = false, bool DMA = false, int QH = 1>
+// PS (round 5): the queries arrive PRE-SCALED by scale * log2(e) (folded into the q rows of the projection weights on the host: no extra
+// rounding) and the running max enters the scores through the CONTRACTION: one more k step with K'[key][64] = 1 (a constant fragment, no
+// LDS) and Q'[q][64] = -m (fp16; m is kept fp16-representable, and being the same for every key of the row and for l it cancels
+// exactly), so S' = s - m comes out of the matrix pipe and the probability is ONE v_exp_f32 per element: the fma of every element, the
+// per-tile max bookkeeping of rows whose max did not move and the rescale test are gone — 16 + 2 MFMAs (576 matrix cycles) against ~125
+// VALU issue units (was 16 MFMAs against ~180).  The max is deferred (guide T13): m moves only when a tile's scores exceed it by more
+// than PS_THR (probabilities up to 2^PS_THR, well inside fp16), then o, l AND this tile's scores take the same exp2(-delta).
+constexpr float PS_THR = 6.f;
+template <int D, bool VRM = false, bool DMA = false, int QH = 1, bool PS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? (QH == 2 ? 2 : 3) : 2, D == 64 ? (QH == 2 ? 2 : 3) : 2)))
 void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   static_assert(!DMA || (VRM && D == 64), "DMA staging: head_dim 64, row-major V");
   static_assert(QH == 1 || (QH == 2 && DMA), "64 query rows per wave: the DMA form only");
+  static_assert(!PS || DMA, "pre-scaled queries: the DMA form only");
   constexpr int KT = 64;             // keys per tile
   constexpr int KS = DMA ? D : D + 8;  // K LDS row stride (halves): padded rows -> conflict-free ds_read_b128; DMA: swizzled 128-byte rows
   constexpr int VS = KT + 4;         // V^T LDS row stride (halves): 34 banks -> conflict-free ds_read_b64
@@ -124,7 +133,9 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
       for (int r = 0; r < 16; ++r) o[qh][dt][r] = 0.f;
   float m_run[QH], l_run[QH];
 #pragma unroll
-  for (int qh = 0; qh < QH; ++qh) { m_run[qh] = -1e30f; l_run[qh] = 0.f; }
+  for (int qh = 0; qh < QH; ++qh) { m_run[qh] = PS ? 0.f : -1e30f; l_run[qh] = 0.f; }
+  f16x8 kx = zero8;                   // PS: the extra k step's K' fragment: column 64 = 1 (lane half 0 holds k slots 64..71)
+  if (PS && lhi == 0) kx[0] = (f16)1.f;
   const float sc = p.scale * 1.44269504088896340736f;  // fold log2(e): softmax via exp2
 
   // ---- DMA staging: a tile is 8 K pieces (8 keys x 128 B) + 8 V pieces (16 keys x 64 B of one d half); wave w moves pieces w, w + 4
@@ -251,6 +262,14 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
       for (int qh = 0; qh < QH; ++qh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[qh][k2][r] = 0.f;
+      if constexpr (PS) {             // S' starts at -m: K'[.][64] * Q'[.][64]
+#pragma unroll
+        for (int qh = 0; qh < QH; ++qh) {
+          f16x8 qx = zero8;
+          if (lhi == 0) qx[0] = (f16)(-m_run[qh]);
+          st[qh][k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kx, qx, st[qh][k2], 0, 0, 0);
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
         const f16x8 kf = DMA ? *(const f16x8*)((const char*)sK + k_rd[ks] + k2 * 4096)
@@ -281,6 +300,47 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[qh][k2][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if constexpr (PS) {
+      // scores are already s - m in log2 units.  The first tile anchors m at its row max; later m moves only past PS_THR.
+      const bool need = (t == 0) || (mx > PS_THR);
+      float rs = 0.f;
+      if (__any(need)) {                             // (wave-uniform branch; rare after the first tile)
+        float delta = 0.f;
+        if (need) {
+          const float mn = (float)(f16)(m_run[qh] + mx);   // fp16-representable: it is an operand of the next tile's extra k step
+          delta = mn - m_run[qh];
+          m_run[qh] = mn;
+        }
+        if (t > 0) {                                 // (at t == 0 o and l are zero, and exp2(-delta) may overflow for very negative rows)
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run[qh] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qh][dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[qh][k2][r] - delta);
+            st[qh][k2][r] = e;
+            rs += e;
+          }
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[qh][k2][r]);
+            st[qh][k2][r] = e;
+            rs += e;
+          }
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[qh] += rs;
+      continue;
+    }
     const float m_new = fmaxf(m_run[qh], mx);
     const float mneg = -m_new * sc;
     float rs = 0.f;
@@ -417,6 +477,12 @@ static bool attn_takes_dma(const MgldAttn* p) {
          ((int64_t)p->Nkv * p->vt_sd * 2 < 0x7fffffffLL);
 }
 
+// queries pre-scaled by scale * log2(e) (the caller folded it into the q projection and passes scale = 1 / log2(e))
+static bool attn_prescaled(const MgldAttn* p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MGLD_ATTN_PS"); on = e ? atoi(e) : 1; }
+  return on && attn_takes_dma(p) && fabsf(p->scale * 1.44269504088896340736f - 1.f) < 1e-6f;
+}
 static int attn_qh(const MgldAttn* p) {
   static int qh = -1;
   if (qh < 0) { const char* e = getenv("MGLD_ATTN_QH"); qh = e ? atoi(e) : 1; }
@@ -428,9 +494,10 @@ static int attn_qh(const MgldAttn* p) {
 extern "C" int mgld_attention_kernel_name(const MgldAttn* p, char* buf, int buflen) {
   MGLD_REQUIRE(p && buf && buflen > 0, "attention_kernel_name: null");
   MGLD_REQUIRE(p->head_dim == 64 || p->head_dim == 128, "attention: head_dim must be 64 or 128");
-  if (p->v_rowmajor && attn_qh(p) == 2) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 2>");
-  else if (p->v_rowmajor) snprintf(buf, buflen, "flash_attn_kernel<%d, true, %s, 1>", p->head_dim, attn_takes_dma(p) ? "true" : "false");
-  else snprintf(buf, buflen, "flash_attn_kernel<%d, false, false, 1>", p->head_dim);
+  if (p->v_rowmajor && attn_qh(p) == 2) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 2, false>");
+  else if (p->v_rowmajor && attn_prescaled(p)) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 1, true>");
+  else if (p->v_rowmajor) snprintf(buf, buflen, "flash_attn_kernel<%d, true, %s, 1, false>", p->head_dim, attn_takes_dma(p) ? "true" : "false");
+  else snprintf(buf, buflen, "flash_attn_kernel<%d, false, false, 1, false>", p->head_dim);
   return 0;
 }
 
@@ -465,7 +532,9 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
     if (attn_qh(p) == 2) {
       const dim3 grid2(p->Nq / 256, p->heads, p->batch);
       hipLaunchKernelGGL((flash_attn_kernel<64, true, true, 2>), grid2, dim3(256), LDS64, (hipStream_t)stream, *p, order);
-    } else if (attn_takes_dma(p))
+    } else if (attn_prescaled(p))
+      hipLaunchKernelGGL((flash_attn_kernel<64, true, true, 1, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
+    else if (attn_takes_dma(p))
       hipLaunchKernelGGL((flash_attn_kernel<64, true, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);
     else if (p->head_dim == 64)
       hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), LDS64, (hipStream_t)stream, *p, order);

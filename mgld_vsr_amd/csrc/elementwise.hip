@@ -598,6 +598,40 @@ extern "C" int mgld_nhwc_to_nchw(const void* x, int in_f32, int ld, float* y, in
   return mgld_check_launch("nhwc_to_nchw");
 }
 
+// packed 3x3 conv weights [N, 9*Cin] (K order (tap, Cin), or (64-channel block, tap, channel) when tap_inner) -> the patch kernels' tiled
+// image [N64/64][Cin/32][3 dy][4 row groups][3 dx][16 rows][4 chunks][8] (MgldIGemm.tap_inner = 2; the 16-byte slot c of tile row r holds
+// logical chunk c ^ ((r >> 2) & 3), the kernels' bank swizzle; rows >= N are zero).  One thread per 16-byte chunk.
+__global__ __launch_bounds__(256) void tile_conv3p_kernel(const f16* __restrict__ wp, int N, int Cin, int tap_inner, f16* __restrict__ out,
+                                                          int64_t chunks) {
+  const int nsl = Cin >> 5;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < chunks; o += (int64_t)gridDim.x * 256) {
+    const int c = (int)(o & 3), row = (int)((o >> 2) & 15);
+    int64_t r = o >> 6;
+    const int dx = (int)(r % 3); r /= 3;
+    const int rb = (int)(r & 3); r >>= 2;
+    const int dy = (int)(r % 3); r /= 3;
+    const int sl = (int)(r % nsl);
+    const int g64 = (int)(r / nsl);
+    const int n = g64 * 64 + rb * 16 + row, tap = dy * 3 + dx;
+    const int ch = sl * 32 + ((c ^ ((row >> 2) & 3)) << 3);
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n < N) {
+      const int64_t k = tap_inner ? ((int64_t)(ch >> 6) * 9 + tap) * 64 + (ch & 63) : (int64_t)tap * Cin + ch;
+      v = *(const f16x8*)(wp + (int64_t)n * 9 * Cin + k);
+    }
+    *(f16x8*)(out + o * 8) = v;
+  }
+}
+
+extern "C" int mgld_tile_conv3p(const void* wp, int N, int Cin, int tap_inner, void* out, void* stream) {
+  MGLD_REQUIRE(wp && out && N > 0 && Cin > 0 && (Cin & 31) == 0 && (!tap_inner || (Cin & 63) == 0), "tile_conv3p: Cin % 32 (64 with tap_inner)");
+  MGLD_REQUIRE(((((uintptr_t)wp) | ((uintptr_t)out)) & 15) == 0, "tile_conv3p: alignment");
+  const int64_t chunks = (int64_t)((N + 63) / 64 * 64) * 9 * Cin / 8;
+  hipLaunchKernelGGL(tile_conv3p_kernel, dim3(egrid(chunks)), dim3(256), 0, S_(stream), (const f16*)wp, N, Cin, tap_inner ? 1 : 0, (f16*)out,
+                     chunks);
+  return mgld_check_launch("tile_conv3p");
+}
+
 extern "C" int mgld_copy2d(const void* src, int lds_, void* dst, int ldd, int64_t rows, int cols, void* stream) {
   MGLD_REQUIRE(src && dst && rows > 0 && cols > 0, "copy2d: bad args");
   MGLD_REQUIRE((cols & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0, "copy2d: cols/ld % 8");

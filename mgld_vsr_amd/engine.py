@@ -38,7 +38,8 @@ def pack_conv3x3(w, cin_pad=None, tap_inner=None):
 
 
 def tile_conv3p(wp, cin, tap_inner):
-    """[N, 9*Cin] packed conv weights (either K order of pack_conv3x3) -> the patch kernel's tiled layout
+    """(host / test form; the engine re-lays weights on the device with the kernel of the same layout, hip.tile_conv3p)
+    [N, 9*Cin] packed conv weights (either K order of pack_conv3x3) -> the patch kernel's tiled layout
     [N64/64][Cin/32][3 dy][4 row groups][3 dx][16 rows][32 ch] as a [., 32] tensor (include/mgld_hip.h, tap_inner = 2); rows
     padded with zeros to a multiple of 64."""
     n = wp.shape[0]
@@ -418,7 +419,7 @@ class Engine:
         if hit is None:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            hit = self._c3p_w[key] = (tile_conv3p(wp, cin, tap_inner), wp)     # (keeps wp alive: the key is its address)
+            hit = self._c3p_w[key] = (hip.tile_conv3p(wp, cin, tap_inner), wp)     # mgld_tile_conv3p (keeps wp alive: the key is its address)
         return hit[0]
 
     def conv2d(self, x, wp, bias, cout, ksize, stride=1, pad=(0, 0), out=None, act=hip.ACT_NONE, alpha=1.0,

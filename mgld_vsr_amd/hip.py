@@ -58,7 +58,7 @@ EXPORTS = [
     "mgld_gn_apply_chunks", "mgld_gn_apply2", "mgld_spade_apply2", "mgld_gn_fused_applies", "mgld_gn_fused", "mgld_layernorm",
     "mgld_attention", "mgld_attention_kernel_name", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
     "mgld_linear_small", "mgld_timestep_embedding",
-    "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby",
+    "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby", "mgld_tile_conv3p",
     "mgld_ddpm_step", "mgld_flow_warp", "mgld_guidance", "mgld_guidance_loss", "mgld_step_advance",
     "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
     "mgld_adain", "mgld_wavelet_reconstruction", "mgld_init_latent", "mgld_to01",
@@ -416,6 +416,16 @@ def nhwc_to_nchw(x, y):
     _chk(lib().mgld_nhwc_to_nchw(_p(x), 1 if x.dtype == torch.float32 else 0, _ld(x), _p(y), n, c, h, w, stream_ptr()),
          "nhwc_to_nchw")
     return y
+
+
+def tile_conv3p(wp, cin, tap_inner):
+    """device form of engine.tile_conv3p: packed fp16 [N, 9*cin] -> the tiled [., 32] image (MgldIGemm.tap_inner = 2)"""
+    _req_cuda(wp)
+    assert wp.dtype == torch.float16 and wp.is_contiguous() and wp.shape[1] == 9 * cin
+    n = wp.shape[0]
+    out = torch.empty(((n + 63) // 64 * 64) * 9 * cin // 32, 32, dtype=torch.float16, device=wp.device)
+    _chk(lib().mgld_tile_conv3p(_p(wp), n, cin, 1 if tap_inner else 0, _p(out), stream_ptr()), "tile_conv3p")
+    return out
 
 
 def copy2d(src, dst):

@@ -244,6 +244,7 @@ MemoryEfficientSelfAttention = MemoryEfficientCrossAttention
 
 
 QKV_FUSED = os.environ.get("MGLD_QKV_FUSED", "1") != "0"    # q|k|v as ONE projection, V consumed row-major by the attention kernel
+LOG2E = 1.4426950408889634
 
 
 def _self_attention(eng, attn, xn, frames, N, resid, out=None):
@@ -252,12 +253,16 @@ def _self_attention(eng, attn, xn, frames, N, resid, out=None):
     if QKV_FUSED:
         # to_q | to_k | to_v (attention.py:323-330) as one GEMM with N = 3C: the normalised tokens are read once, and the attention
         # kernel takes V as it lies (row-major, transposing LDS reads) — no transposed V^T projection, one launch less per block
-        wqkv = eng.weight("qkv", (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight), lambda q, k, v: torch.cat([q, k, v], 0))
+        # round 5: the softmax scale and log2(e) are folded into the q rows of the fused weight (fp32, before the one rounding to fp16), so
+        # the scores leave the matrix pipe in log2 units and the attention kernel's probability is a bare exp2 (`scale` = ln 2 tells the
+        # launcher: flash_attn_kernel<64, true, true, 1, true>, csrc/attention.hip); every other kernel variant computes the same softmax
+        f = d ** -0.5 * LOG2E
+        wqkv = eng.weight("qkvps", (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight), lambda q, k, v: torch.cat([q * f, k, v], 0))
         qkv = eng.linear(xn, wqkv, None)
         o = eng.empty(frames * N, C)
         hip.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], o, batch=frames, heads=H, Nq=N, Nkv=N, head_dim=d,
                       q_strides=(N * 3 * C, 3 * C, d), k_strides=(N * 3 * C, 3 * C, d), vt_strides=(N * 3 * C, 3 * C, d),
-                      o_strides=(N * C, C, d), scale=d ** -0.5, v_rowmajor=True)
+                      o_strides=(N * C, C, d), scale=1.0 / LOG2E, v_rowmajor=True)
         eng.launches += 1
         wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
         return eng.linear(o, wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid)

@@ -1295,3 +1295,54 @@ def test_hp_split_convolution(hip, n, h, w, cin, cout, stride):
     if n * h * w >= 1 << 18:
         assert "conv3r" in hip.igemm_kernel_name(log[-1])[0]
     assert rel_l2(out.v.cpu().double(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("n,cin,ti", [(320, 320, False), (640, 128, True), (100, 64, True), (160, 96, False)])
+def test_tile_conv3p_kernel_matches_the_host_layout(hip, n, cin, ti):
+    """mgld_tile_conv3p == engine.tile_conv3p (the torch statement of MgldIGemm.tap_inner = 2's layout, pinned by tests/test_host_cpu.py) bit for bit,
+    for both K orders of the packed weights and an N that is not a multiple of 64 (zero rows)"""
+    from mgld_vsr_amd.engine import pack_conv3x3, tile_conv3p
+    w = rnd(n, cin, 3, 3, seed=600)
+    wp = pack_conv3x3(w, cin, tap_inner=ti).half().to(DEV)
+    assert torch.equal(hip.tile_conv3p(wp, cin, ti), tile_conv3p(wp, cin, ti))
+
+
+@pytest.mark.parametrize("B,H,N", [(8, 5, 4096), (8, 10, 1024), (3, 5, 256), (1, 2, 64)])
+def test_flash_attention_prescaled_queries(hip, B, H, N):
+    """flash_attn_kernel<64, true, true, 1, true>: queries pre-scaled by d^-1/2 log2(e) (scale = ln 2 selects it), the running max carried
+    into the scores by an extra k step, deferred rescale.  Rows with spikes late in the key axis (the rescale path), a row whose FIRST
+    key tile is far below the rest (the anchor at t = 0 and a large later jump) and rows whose scores are all very negative."""
+    D = 64
+    C_ = H * D
+    f = D ** -0.5 * 1.4426950408889634
+    g = torch.Generator().manual_seed(78)
+    q = torch.randn(B * N, C_, generator=g) * 0.8
+    k = torch.randn(B * N, C_, generator=g) * 0.8
+    v = torch.randn(B * N, C_, generator=g) * 0.8
+    if N >= 256:
+        k[N - 100, :D] = q[7, :D] * 4                   # late spikes (frame 0, head 0)
+        k[N - 37, :D] = q[40, :D] * 4
+        k[:64, :D] = -q[9, :D] * 3                      # query 9: its first key tile scores ~ -3 |q|^2, far below the later ones
+        q[11, :D] = 0.0                                 # flat row
+        k[:, D:2 * D] -= 2.5 * torch.sign(q[13, D:2 * D])     # head 1, query 13: every score strongly negative
+    qkv = torch.cat([(q * f), k, v], 1).half().to(DEV)
+    o = torch.empty(B * N, C_, dtype=torch.half, device=DEV)
+    st = (N * 3 * C_, 3 * C_, D)
+    hip.TIMED = []
+    try:
+        hip.attention(qkv, qkv[:, C_:], qkv[:, 2 * C_:], o, batch=B, heads=H, Nq=N, Nkv=N, head_dim=D, q_strides=st, k_strides=st, vt_strides=st,
+                      o_strides=(N * C_, C_, D), scale=1.0 / 1.4426950408889634, v_rowmajor=True)
+        assert hip.TIMED[0][1]["kernel"] == "flash_attn_kernel<64, true, true, 1, true>", hip.TIMED[0][1]["kernel"]
+    finally:
+        hip.TIMED = None
+    kq = lambda t: t.float().reshape(B, N, H, D).permute(0, 2, 1, 3)
+    qf, kf, vf = kq(qkv[:, :C_]), kq(qkv[:, C_:2 * C_]), kq(qkv[:, 2 * C_:])
+    got = o.float().reshape(B, N, H, D).permute(0, 2, 1, 3)
+    num = den = 0.0
+    worst = 0.0
+    for b in range(B):
+        ref = torch.softmax(qf[b] @ kf[b].transpose(-1, -2) * 0.6931471805599453, dim=-1) @ vf[b]      # 2^(q' k) = e^(ln 2 q' k)
+        num += float(((got[b] - ref).double() ** 2).sum())
+        den += float((ref.double() ** 2).sum())
+        worst = max(worst, float((got[b] - ref).abs().max()))
+    assert torch.isfinite(o).all() and (num / den) ** 0.5 < 1e-3 and worst < 2e-2, ((num / den) ** 0.5, worst)

@@ -28,17 +28,20 @@ def main():
     for name, B, H, Nq, Nkv, D, weight in SHAPES:
         C = H * D
         Np = (Nkv + 7) // 8 * 8
-        q = torch.randn(B * Nq, C, device=dev).half()
+        q = (torch.randn(B * Nq, C, device=dev) * (D ** -0.5 * 1.4426950408889634 if (Nkv == Nq and os.environ.get("ATTN_BENCH_PS", "1") != "0") else 1.0)).half()
         k = torch.randn(B * Nkv, C, device=dev).half()
         vt = torch.randn(B * C, Np, device=dev).half()
         v = torch.randn(B * Nkv, C, device=dev).half()
         o = torch.empty_like(q)
         vrm = Nkv == Nq          # self-attention: V row-major out of the fused q|k|v projection; cross-attention: cached V^T
 
+        ps = os.environ.get("ATTN_BENCH_PS", "1") != "0"      # self-attention as the UNet launches it since round 5: pre-scaled queries
+
         def launch():
             if vrm:
                 hip.attention(q, k, v, o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=(Nq * C, C, D),
-                              k_strides=(Nkv * C, C, D), vt_strides=(Nkv * C, C, D), o_strides=(Nq * C, C, D), scale=D ** -0.5, v_rowmajor=True)
+                              k_strides=(Nkv * C, C, D), vt_strides=(Nkv * C, C, D), o_strides=(Nq * C, C, D),
+                              scale=(1.0 / 1.4426950408889634) if ps else D ** -0.5, v_rowmajor=True)
             else:
                 hip.attention(q, k, vt, o, batch=B, heads=H, Nq=Nq, Nkv=Nkv, head_dim=D, q_strides=(Nq * C, C, D),
                               k_strides=(Nkv * C, C, D), vt_strides=(C * Np, D * Np, Np), o_strides=(Nq * C, C, D), scale=D ** -0.5)

@@ -113,5 +113,14 @@ print({k:(v['ms_per_segment'],v['launches'],v['frac_of_peak']) for k,v in d['roo
       python -c "import json;d=json.load(open('gpurun_out/r5e_bench_$envs.json'));print('$envs:',d['value'],'fps',d['ms_per_step'],'ms/step')" 2>&1 | tee -a gpurun_out/r5e_bench.log
     done
     ;;
+  r5g)        # round 5: pre-scaled-query attention (max carried by the contraction): tests, microbench A/B, end-to-end A/B, parity of the workloads
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "flash or attention or tile_conv3p" 2>&1 | tail -8 | tee gpurun_out/r5g_tests.log
+    for ps in 0 1; do echo "== ATTN_BENCH_PS=$ps"; ATTN_BENCH_PS=$ps timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r5g_attn.log
+    timeout 1200 python -m pytest tests/test_workloads_gpu.py tests/test_nets_gpu.py -q -k "c2-50 or c2s-50 or c2-4 or unet_full or c1 or e2e_full" 2>&1 | tail -8 | tee gpurun_out/r5g_work.log
+    for envs in "MGLD_ATTN_PS=0" "MGLD_ATTN_PS=1"; do
+      env $envs timeout 400 python bench.py --steps 6 --warmup 2 --no-roofline --no-cpu-baseline --no-one-at-a-time 2>/dev/null | tail -1 > gpurun_out/r5g_bench_$envs.json
+      python -c "import json;d=json.load(open('gpurun_out/r5g_bench_$envs.json'));print('$envs:',d['value'],'fps',d['ms_per_step'],'ms/step')" 2>&1 | tee -a gpurun_out/r5g_bench.log
+    done
+    ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac
