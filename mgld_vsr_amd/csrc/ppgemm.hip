@@ -221,8 +221,9 @@ bool ppgemm_plan(const MgldIGemm* p, int* id) {
   if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU || p->act == MGLD_ACT_GEGLU)) return false;
   // operands go through unbounded buffer descriptors with 32-bit byte offsets relative to a tile's first row: a 256-row tile of either
   // operand must stay inside that range, and rows must hold K elements
-  if (p->lda < p->K || p->ldw < p->K || (int64_t)320 * p->lda * 2 + (int64_t)p->K * 2 >= 0x7fffffffLL ||
-      (int64_t)320 * p->ldw * 2 + (int64_t)p->K * 2 >= 0x7fffffffLL) return false;
+  // (planner queries may leave the leading dimensions unset = 0: dense rows are assumed then)
+  const int64_t lda_ = p->lda > 0 ? p->lda : p->K, ldw_ = p->ldw > 0 ? p->ldw : p->K;
+  if (lda_ < p->K || ldw_ < p->K || 320 * lda_ * 2 + (int64_t)p->K * 2 >= 0x7fffffffLL || 320 * ldw_ * 2 + (int64_t)p->K * 2 >= 0x7fffffffLL) return false;
   if ((p->ldc & 7) || (((uintptr_t)p->C) & 15) || (p->R && ((p->ldr & 7) || (((uintptr_t)p->R) & 15)))) return false;
   if ((p->bias && (((uintptr_t)p->bias) & 15)) || (p->rowvec && ((((uintptr_t)p->rowvec) & 15) || (p->ld_rowvec & 3)))) return false;
   if (p->tune > 20) {
