@@ -89,6 +89,7 @@ def dry(monkeypatch):
                  "timestep_embedding", "nchw_to_nhwc", "nhwc_to_nchw", "copy2d", "axpby"]:
         monkeypatch.setattr(hip, name, generic(name))
     monkeypatch.setattr(hip, "conv3p_applies", lambda *a: False)   # (a planner query into the library: keep the [N, K] weights)
+    monkeypatch.setattr(hip, "tile_conv3p", E.tile_conv3p)         # (the device re-layout kernel -> the host statement of the same layout)
     monkeypatch.setattr(hip, "lib", lambda: None)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     eng = E.Engine(device="cpu", chunk_bytes=64 << 20)
