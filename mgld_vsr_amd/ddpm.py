@@ -465,11 +465,17 @@ class LatentDiffusionVSRTextWT(nn.Module):
             hip.ddpm_step(x, eps, st["noise"], st["coef"], st["step_idx"], st["z"], st["noise_stride"])
             sh = eng.shard
             if sh is None:
-                # one guidance chain per clip (independent segments batched as clips of this pass each carry their own flows)
+                # one guidance chain per clip (independent segments batched as clips of this pass each carry their own flows); the
+                # `lr_images` term first, then the flows / masks term, as p_sample applies them (ddpm.py:4359-4373)
                 Tn = self.num_frames
-                for ci, (ff, fb, fo, bo) in enumerate(st["guid"]):
-                    hip.guidance(st["z"][ci * Tn:(ci + 1) * Tn], ff, fb, fo, bo, st["coef"], st["step_idx"], st["gscale"],
-                                 x[ci * Tn:(ci + 1) * Tn], st["work"][ci])
+                terms = [st[k] for k in ("guid_lr", "guid") if k in st]
+                src = st["z"]
+                for ti, chain in enumerate(terms):
+                    dst = x if ti == len(terms) - 1 else st["z2"]
+                    for ci, (ff, fb, fo, bo) in enumerate(chain):
+                        hip.guidance(src[ci * Tn:(ci + 1) * Tn], ff, fb, fo, bo, st["coef"], st["step_idx"], st["gscale"],
+                                     dst[ci * Tn:(ci + 1) * Tn], st["work"][ci])
+                    src = dst
             else:
                 # frame-sharded clip: the guidance chain couples neighbouring frames -> all-gather the (64 KiB/frame)
                 # latents, evaluate the tiny gradient on the whole clip on every rank, keep this rank's frames
@@ -485,7 +491,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
 
     @torch.no_grad()
     def _sample_loop(self, cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                     return_intermediates, log_every_t, noise, tile, use_graph=True, hooks=None):
+                     return_intermediates, log_every_t, noise, tile, use_graph=True, hooks=None, lr_images=None):
         """hooks: the option branches of the reference loop (ddpm.py:4501-4599) that sit BETWEEN steps — start_T (skip the schedule
         indices above a timestep), mask + x0 (inpainting blend with a re-noised x0 after every step; optional mask_noise
         [steps, ...] instead of fresh draws), adain_fea (latent-space AdaIN after the last step), callback(i) /
@@ -528,7 +534,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
             st = {
                 "x": x, "coef": self._coef_table(S, use_t_replace).to(dev), "noise": noise, "noise_stride": x.numel(),
                 "step_idx": torch.tensor([idxs[0] if idxs else 0], dtype=torch.int32, device=dev), "tvals": torch.zeros(1, device=dev),
-                "ctx": self.model.diffusion_model.context_cache(eng, ctx), "guided": flows is not None,
+                "ctx": self.model.diffusion_model.context_cache(eng, ctx), "guided": flows is not None or lr_images is not None,
                 "gscale": float(guidance_scale), "tiles": None,
             }
             pieces_mode = False
@@ -551,6 +557,25 @@ class LatentDiffusionVSRTextWT(nn.Module):
                               for i in range(nclips)]
                 st["z"] = torch.empty_like(x)
                 st["work"] = [torch.empty(hip.guidance_work_bytes(Tn, c, h, w), dtype=torch.uint8, device=dev) for _ in range(nclips)]
+            if lr_images is not None:
+                # the `lr_images` term (ddpm.py:4359-4366 -> compute_temporal_condition_v2 :3469-3500): the reference resizes the LR frames
+                # to the latent grid (bicubic), runs its flow network on them INSIDE every step and pulls the latents along those flows
+                # with nothing occluded.  The flows depend on lr_images only: estimated once here (fp32 RAFT), then the same guidance
+                # kernel with all-valid masks
+                if sh is not None:
+                    raise NotImplementedError("lr_images guidance with a frame-sharded clip")
+                Tn = self.num_frames
+                assert T_total % Tn == 0 and lr_images.shape[0] == T_total, "lr_images: one LR frame per latent frame"
+                nclips = T_total // Tn
+                res = hip.resize_bicubic(lr_images.to(dev, torch.float32), (h, w))
+                f_f, f_b = self.compute_flow(res.view(nclips, Tn, res.shape[1], h, w))
+                zero = torch.zeros(Tn - 1, h, w, device=dev)
+                st["guid_lr"] = [(f_f[i].contiguous(), f_b[i].contiguous(), zero, zero) for i in range(nclips)]
+                if "z" not in st:
+                    st["z"] = torch.empty_like(x)
+                    st["work"] = [torch.empty(hip.guidance_work_bytes(Tn, c, h, w), dtype=torch.uint8, device=dev) for _ in range(nclips)]
+                if flows is not None:
+                    st["z2"] = torch.empty_like(x)
                 if sh is not None:
                     st["x_full"] = torch.empty((T_clip, c, h, w), device=dev)
                     st["z_full"] = torch.empty((T_clip, c, h, w), device=dev)
@@ -700,7 +725,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
         eps = self._eps_canvas(x, c, struct_cond, t if t_replace is None else t_replace, tile_size, tile_overlap, tile_weights)
         return self._posterior_from_eps(x, t, eps, clip_denoised, return_x0)
 
-    def _finish_p_sample(self, x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise):
+    def _finish_p_sample(self, x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise, lr_images=None):
         mean, logvar = outputs[0], outputs[2]
         b = x.shape[0] // self.num_frames
         if noise is None:
@@ -708,6 +733,20 @@ class LatentDiffusionVSRTextWT(nn.Module):
         noise = noise.to(mean.device, torch.float32) * temperature
         nonzero = (1 - (t == 0).float()).reshape(b, *((1,) * (x.dim() - 1))).to(mean.device)
         latents = mean + nonzero * (0.5 * logvar).exp() * noise
+        if lr_images is not None:                                              # (:4359-4366) compute_temporal_condition_v2: flows of the
+            eng = self.engine()                                                #  LR frames at the latent grid, nothing occluded
+            Tn, ch, h, w = latents.shape
+            assert Tn == self.num_frames and lr_images.shape[0] == Tn, "lr_images guidance operates on one clip"
+            res = hip.resize_bicubic(lr_images.to(eng.device, torch.float32), (h, w))
+            f_f, f_b = self.compute_flow(res[None])
+            zero = torch.zeros(Tn - 1, h, w, device=eng.device)
+            coef = torch.zeros(1, 8, device=eng.device)
+            coef[0, 4] = logvar.reshape(-1)[0]
+            out = torch.empty_like(latents)
+            work = torch.empty(hip.guidance_work_bytes(Tn, ch, h, w), dtype=torch.uint8, device=eng.device)
+            hip.guidance(latents.contiguous(), f_f[0].contiguous(), f_b[0].contiguous(), zero, zero, coef,
+                         torch.zeros(1, dtype=torch.int32, device=eng.device), float(guidance_scale), out, work)
+            latents = out
         if flows is not None:                                                  # (:4367-4373) latents -= s * logvar * dL/dlatents
             eng = self.engine()
             ff, fb, fo, bo = self._flows_to_device(eng, flows, masks)
@@ -726,11 +765,11 @@ class LatentDiffusionVSRTextWT(nn.Module):
                  repeat_noise=False, return_codebook_ids=False, quantize_denoised=False, return_x0=False, temperature=1.,
                  noise_dropout=0., score_corrector=None, corrector_kwargs=None, t_replace=None, noise=None):
         """ddpm.py:4325-4380: one reverse step.  Extra kwarg `noise`: the step's Gaussian draw (the reference draws it inside)."""
-        self._check_unsupported(lr_images=lr_images, repeat_noise=repeat_noise or None, noise_dropout=noise_dropout or None)
+        self._check_unsupported(repeat_noise=repeat_noise or None, noise_dropout=noise_dropout or None)
         outputs = self.p_mean_variance(x=x, c=c, struct_cond=struct_cond, t=t, clip_denoised=clip_denoised,
                                        return_codebook_ids=return_codebook_ids, quantize_denoised=quantize_denoised, return_x0=return_x0,
                                        score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, t_replace=t_replace)
-        return self._finish_p_sample(x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise)
+        return self._finish_p_sample(x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise, lr_images=lr_images)
 
     @torch.no_grad()
     def p_sample_canvas(self, x, c, struct_cond, t, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, clip_denoised=False,
@@ -738,13 +777,13 @@ class LatentDiffusionVSRTextWT(nn.Module):
                         noise_dropout=0., score_corrector=None, corrector_kwargs=None, t_replace=None, tile_size=64, tile_overlap=32,
                         batch_size=4, tile_weights=None, noise=None):
         """ddpm.py:4383-4442"""
-        self._check_unsupported(lr_images=lr_images, repeat_noise=repeat_noise or None, noise_dropout=noise_dropout or None)
+        self._check_unsupported(repeat_noise=repeat_noise or None, noise_dropout=noise_dropout or None)
         outputs = self.p_mean_variance_canvas(x=x, c=c, struct_cond=struct_cond, t=t, clip_denoised=clip_denoised,
                                               return_codebook_ids=return_codebook_ids, quantize_denoised=quantize_denoised,
                                               return_x0=return_x0, score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
                                               t_replace=t_replace, tile_size=tile_size, tile_overlap=tile_overlap, batch_size=batch_size,
                                               tile_weights=tile_weights)
-        return self._finish_p_sample(x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise)
+        return self._finish_p_sample(x, outputs, t, guidance_scale, flows, masks, return_x0, temperature, noise, lr_images=lr_images)
 
     def _check_unsupported(self, **kw):
         for k, v in kw.items():
@@ -758,7 +797,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
                use_graph=True, **kwargs):
         """ddpm.py:4696-4719 -> p_sample_loop.  Extra kwargs: `noise` [steps,T,C,h,w] (injected noise indexed by
         the schedule index; the reference draws randn per step) and `use_graph`."""
-        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
+        self._check_unsupported(interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
         if shape is None:
             shape = tuple(struct_cond.shape) if x_T is None else tuple(x_T.shape)
         if cond is not None and not isinstance(cond, (dict, list)):
@@ -766,7 +805,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
         hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, start_T=start_T, mask_noise=kwargs.get("mask_noise"),
                      callback=kwargs.get("callback"), img_callback=kwargs.get("img_callback"))
         return self._sample_loop(cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, None, noise, None, use_graph, hooks=hooks)
+                                 return_intermediates, None, noise, None, use_graph, hooks=hooks, lr_images=lr_images)
 
     @torch.no_grad()
     def p_sample_loop(self, cond, struct_cond, shape, guidance_scale=-1.0, lr_images=None, flows=None, masks=None,
@@ -775,12 +814,12 @@ class LatentDiffusionVSRTextWT(nn.Module):
                       interfea_path=None):
         """ddpm.py:4501-4616, the loop `sample` enters: same arguments.  A step runs as the captured step graph; the options that act
         BETWEEN steps (start_T, mask / x0 inpainting, adain_fea, callback / img_callback) run as stream-ordered work between the
-        replays.  interfea_path (PCA pictures of the struct-cond features, a debugging aid: ddpm.py:4574-4597) and lr_images (another
-        guidance term, compute_temporal_condition_v2) are refused rather than ignored."""
-        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
+        replays.  lr_images: the other guidance term (compute_temporal_condition_v2; round 5).  interfea_path (PCA pictures of the
+        struct-cond features, a debugging aid: ddpm.py:4574-4597) is refused rather than ignored."""
+        self._check_unsupported(interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
         hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, start_T=start_T, callback=callback, img_callback=img_callback)
         return self._sample_loop(cond, struct_cond, tuple(shape), guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, log_every_t, None, None, True, hooks=hooks)
+                                 return_intermediates, log_every_t, None, None, True, hooks=hooks, lr_images=lr_images)
 
     @torch.no_grad()
     def p_sample_loop_canvas(self, cond, struct_cond, shape, guidance_scale=-1.0, lr_images=None, flows=None, masks=None,
@@ -790,10 +829,10 @@ class LatentDiffusionVSRTextWT(nn.Module):
         """ddpm.py:4619-4693, the loop `sample_canvas` enters (`batch_size` = tiles per UNet pass in the reference; here every
         tile of a step goes through one pass)."""
         assert tile_size is not None
-        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
+        self._check_unsupported(interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
         hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, start_T=start_T, callback=callback, img_callback=img_callback)
         return self._sample_loop(cond, struct_cond, tuple(shape), guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, log_every_t, None, (tile_size, tile_overlap), True, hooks=hooks)
+                                 return_intermediates, log_every_t, None, (tile_size, tile_overlap), True, hooks=hooks, lr_images=lr_images)
 
     @torch.no_grad()
     def sample_canvas(self, cond, struct_cond, guidance_scale=-1.0, lr_images=None, flows=None, masks=None, batch_size=16,
@@ -802,10 +841,10 @@ class LatentDiffusionVSRTextWT(nn.Module):
                       tile_overlap=32, batch_size_sample=4, log_every_t=None, noise=None, use_graph=True, **kwargs):
         """ddpm.py:4722-4746 -> p_sample_loop_canvas: aggregation sampling over overlapping latent tiles.  All tiles
         of a step are batched into one struct-cond + UNet pass (each tile is an independent clip)."""
-        self._check_unsupported(lr_images=lr_images, interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
+        self._check_unsupported(interfea_path=interfea_path, quantize_denoised=quantize_denoised or None)
         if shape is None:
             shape = tuple(struct_cond.shape) if x_T is None else tuple(x_T.shape)
         hooks = dict(mask=mask, x0=x0, adain_fea=adain_fea, mask_noise=kwargs.get("mask_noise"), callback=kwargs.get("callback"),
                      img_callback=kwargs.get("img_callback"))
         return self._sample_loop(cond, struct_cond, shape, guidance_scale, flows, masks, x_T, timesteps, time_replace,
-                                 return_intermediates, log_every_t, noise, (tile_size, tile_overlap), use_graph, hooks=hooks)
+                                 return_intermediates, log_every_t, noise, (tile_size, tile_overlap), use_graph, hooks=hooks, lr_images=lr_images)

@@ -54,12 +54,28 @@ def eps_model(unet_sd, unet_cfg, sc_sd, sc_cfg, x, lat, t_net, ctx):
     return nets.unet_forward(unet_sd, unet_cfg, x, tt, ctx, sc)
 
 
+def lr_guidance_flows(raft_sd, lr_images, T, h, w):
+    """compute_temporal_condition_v2 (ddpm.py:3469-3500) up to its loss: LR frames [(b t),3,H,W] -> bicubic resize to the latent grid ->
+    compute_flow -> (flows, all-valid masks) in temporal_condition_v4's layout — v2's chain is v4's with nothing occluded."""
+    import torch.nn.functional as F
+    from . import raft as oraft
+    res = F.interpolate(lr_images, size=(h, w), mode="bicubic")
+    f_f, f_b = oraft.compute_flow(raft_sd, res.reshape(-1, T, *res.shape[1:]))
+    z = torch.zeros(f_f.shape[0], T - 1, 1, h, w)
+    return (f_f, f_b), (z, z)
+
+
 def sample(unet_sd, unet_cfg, sc_sd, sc_cfg, ctx, lat, x_T, noises, steps, guidance_scale=-10.0, flows=None, masks=None,
-           tile=None, eps_fn=None, return_all=False):
+           tile=None, eps_fn=None, return_all=False, lr_images=None, raft_sd=None):
     """x_T -> x_0.  tile=(tile_size, tile_overlap) selects the aggregation-sampling path.  eps_fn overrides the network
-    (used to test the sampler arithmetic in isolation)."""
+    (used to test the sampler arithmetic in isolation).  lr_images (+ raft_sd): the other guidance term (ddpm.py:4359-4366), applied
+    before the flows / masks one as the reference does."""
     _, buf, ori = osched.respaced_schedule(steps)
     T = unet_cfg["num_frames"]
+    lr_flows = lr_masks = None
+    if lr_images is not None:
+        with torch.no_grad():
+            lr_flows, lr_masks = lr_guidance_flows(raft_sd, lr_images, T, x_T.shape[2], x_T.shape[3])
     img = x_T.clone()
     traj = []
     with torch.no_grad():
@@ -80,6 +96,8 @@ def sample(unet_sd, unet_cfg, sc_sd, sc_cfg, ctx, lat, x_T, noises, steps, guida
                     cnt[:, :, y0:y0 + ts, x0:x0 + ts] += wgt
                 eps = acc / cnt
             z, logvar = osched.p_step(buf, i, img, eps, noises[k])
+            if lr_flows is not None:
+                z, _ = oflow.guidance_update(z, lr_flows, lr_masks, T, guidance_scale, logvar)
             if flows is not None:
                 z, _ = oflow.guidance_update(z, flows, masks, T, guidance_scale, logvar)
             img = z

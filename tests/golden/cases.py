@@ -53,3 +53,18 @@ def case_inputs(name, S):
     elif c["guided"]:
         ff, fb = synth.smooth_flow(f"{tag}/ff", Tn - 1, h, h), synth.smooth_flow(f"{tag}/fb", Tn - 1, h, h)
     return dict(T=Tn, S=S, H=H, h=h, x=x, noise=noise, ff=ff, fb=fb, canvas=c["canvas"], stride=c["stride"])
+
+
+def sample_lr_inputs(T, S=4, h=128, w=128):
+    """inputs of the `lr_images` guidance fixture (make_golden.py::gen_sample_lr / g_sample_lr.npz holds the reference's OUTPUTS only):
+    struct-cond latent, x_T, per-step noise (loop order), T smooth LR frames 2h x 2w in [0,1] translating by (2, 3) pixels per frame, a
+    second (smooth synthetic) flow pair for the combined run"""
+    import torch.nn.functional as F
+    lat = synth.synth_tensor("samplelr/lat", (T, 4, h, w), 0.5)
+    xT = synth.synth_tensor("samplelr/xT", (T, 4, h, w))
+    noises = [synth.synth_tensor(f"samplelr/noise{i}", (T, 4, h, w)) for i in range(S)]
+    H, W = 2 * h, 2 * w
+    base = F.avg_pool2d(torch.sigmoid(synth.synth_tensor("samplelr/lr", (1, 3, H + 16, W + 16), 1.8)), 5, 1, 2)
+    lr = torch.stack([base[0, :, 4 + 3 * k:4 + 3 * k + H, 6 + 2 * k:6 + 2 * k + W] for k in range(T)]).contiguous()
+    ff, fb = synth.smooth_flow("samplelr/ff", T - 1, h, w, 0.4), synth.smooth_flow("samplelr/fb", T - 1, h, w, 0.4)
+    return dict(lat=lat, xT=xT, noises=noises, lr=lr, ff=ff, fb=fb, h=h, w=w, S=S)

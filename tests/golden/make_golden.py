@@ -266,6 +266,40 @@ def gen_sample(model, ddpm):
     save("g_sample", **out)
 
 
+def gen_sample_lr():
+    """The `lr_images` guidance term of p_sample (ddpm.py:4359-4366 -> compute_temporal_condition_v2 :3469-3500): the reference resizes the LR
+    frames to the latent grid (bicubic), estimates flows on them with ITS RAFT_SR at every step and pulls the latents along those flows
+    (no occlusion masks).  Reduced model with the reference's real flow network (synthetic weights), T frames on a 128 x 128 latent (the
+    smallest grid on which the reference's RAFT works: at 64 x 64 the coarsest level of its correlation pyramid is 1 x 1 and its bilinear
+    sampler divides by W - 1 = 0 -> NaN flows), 4 steps: once with lr_images alone, once with lr_images AND flows / masks (both terms, in the reference's order)."""
+    uf = ref_import.ref("scripts.util_flow")
+    model, ddpm = build_ref_model(flownet_config={"target": "basicsr.archs.raft_arch.RAFT_SR", "params": {"model": "normal", "load_path": None}})
+    synth.fill_module_(model.flownet_model, "raft")
+    from cases import sample_lr_inputs
+    c = sample_lr_inputs(T)
+    S, h, w, lat, xT, noises, lr, ff, fb = c["S"], c["h"], c["w"], c["lat"], c["xT"], c["noises"], c["lr"], c["ff"], c["fb"]
+    respace(model, S)
+    ctx = model.cond_stage_model([""])
+    focc, bocc = uf.forward_backward_consistency_check(fb, ff)
+    out = dict(focc=focc, bocc=bocc)        # (inputs are regenerated from the recipe in cases.py: the fixture holds the reference's outputs)
+    orig = ddpm.noise_like
+    try:
+        for tag, fl, mk in (("lr", None, None), ("lr_flows", (ff[None], fb[None]), (focc[None, :, None], bocc[None, :, None]))):
+            queue = list(noises)
+            ddpm.noise_like = lambda shape, device, repeat=False: queue.pop(0)
+            x0, _ = model.sample(cond=ctx, struct_cond=lat, guidance_scale=-10.0, lr_images=lr, flows=fl, masks=mk, batch_size=1, timesteps=S,
+                                 time_replace=S, x_T=xT, return_intermediates=True, verbose=False)
+            out[f"x0_{tag}"] = x0
+    finally:
+        ddpm.noise_like = orig
+    with torch.no_grad():       # the flows the guidance used (for the tests' diagnostics)
+        res = torch.nn.functional.interpolate(lr, size=(h, w), mode="bicubic")
+        f_f, f_b = model.compute_flow(res[None])
+    assert bool(torch.isfinite(f_f).all()) and bool(torch.isfinite(out["x0_lr"]).all())
+    out.update(lr_flow_f=f_f[0], lr_flow_b=f_b[0], raft_names_shapes=names_shapes(model.flownet_model))
+    save("g_sample_lr", **out)
+
+
 def gen_pstep(model, ddpm):
     """The single-step API (ddpm.py:4157-4189, 4325-4380, 4191-4322, 4383-4442) and decode_first_stage (:3786) of the reference on the
     reduced model: one p_mean_variance / p_sample (guided) at schedule index 2 of a 4-step schedule, one p_sample_canvas on a 24x24

@@ -603,6 +603,40 @@ def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
     assert record("e2e_full_frames", rel_l2(out, ref)) < 1e-3      # north_star: outputs within 1e-3 rel-L2 (measured 9.5e-4)
 
 
+def test_sample_lr_images_guidance_vs_reference(hip):
+    """the `lr_images` guidance term (ddpm.py:4359-4366 -> compute_temporal_condition_v2 :3469-3500) against runs of the REFERENCE's sampler
+    with its own RAFT_SR (g_sample_lr.npz): LR frames -> bicubic resize to the 128 x 128 latent grid -> flows (fp32 RAFT) -> the guidance
+    kernel with nothing occluded; alone, and together with the flows / masks term (the reference's order: lr first)."""
+    from cases import sample_lr_inputs
+    g = G("g_sample_lr")
+    c = sample_lr_inputs(T)
+    model = _small_model()
+    synth.fill_module_(model.flownet_model, "raft")
+    S = c["S"]
+    _respace(model, S)
+    ctx = synth.synth_tensor("ctx", (1, 77, UNET_SMALL["context_dim"]))
+    noise = torch.flip(torch.stack(c["noises"]), dims=[0])            # the reference's list is in loop order, the product indexes by schedule index
+    kw = dict(cond=ctx, struct_cond=c["lat"], guidance_scale=-10.0, batch_size=1, timesteps=S, time_replace=S, x_T=c["xT"], noise=noise,
+              lr_images=c["lr"])
+    x0 = model.sample(**kw)
+    assert record("sample_lr_images", rel_l2(x0, g["x0_lr"])) < 1.45e-3
+    x0b = model.sample(flows=(c["ff"][None], c["fb"][None]), masks=(g["focc"][None, :, None], g["bocc"][None, :, None]), **kw)
+    assert record("sample_lr_images_and_flows", rel_l2(x0b, g["x0_lr_flows"])) < 1.45e-3
+    assert rel_l2(g["x0_lr"], g["x0_lr_flows"]) > 3e-4              # (the second term acts on this fixture)
+    # the flows the term uses: this build's RAFT on the resized LR frames vs the reference's
+    res = hip.resize_bicubic(c["lr"].cuda(), (c["h"], c["w"]))
+    f_f, f_b = model.compute_flow(res[None])
+    assert max(rel_l2(f_f[0], g["lr_flow_f"]), rel_l2(f_b[0], g["lr_flow_b"])) < 1e-4
+    # single-step API: one p_sample with lr_images == the loop's first step (schedule index S - 1 from x_T)
+    i = S - 1
+    ts = torch.full((1,), i, dtype=torch.long)
+    t_rep = torch.tensor([model.ori_timesteps[i]] * T)
+    sc = model.structcond_stage_model(c["lat"].cuda(), t_rep.cuda())
+    z1 = model.p_sample(c["xT"], ctx, sc, ts, guidance_scale=-10.0, lr_images=c["lr"], t_replace=t_rep, noise=noise[i])
+    first = model.sample(**dict(kw, return_intermediates=True))[1][1]      # intermediates: [x_T, after step S - 1, ...]
+    assert rel_l2(z1, first) < 1e-5
+
+
 def test_sample_small_50_steps_vs_oracle(hip):
     """the full 50-step respaced loop (hipGraph replay) with motion guidance vs the oracle sampler, reduced nets."""
     torch.set_num_threads(min(32, os.cpu_count() or 8))

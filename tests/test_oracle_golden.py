@@ -127,6 +127,26 @@ def test_sample_golden(tag, tile):
     assert rel_l2(x0, g[f"{tag}_x0"]) < 1e-4
 
 
+def test_sample_lr_images_golden():
+    """the `lr_images` guidance term (compute_temporal_condition_v2 through the reference's own RAFT_SR, g_sample_lr.npz): alone and
+    together with the flows / masks term"""
+    from cases import sample_lr_inputs
+    g, gu = G("g_sample_lr"), G("g_unet")
+    c = sample_lr_inputs(T)
+    usd, ssd = sd_from(gu, "unet_params", "unet"), sd_from(gu, "struct_params", "structcond")
+    rsd = sd_from(g, "raft_names_shapes", "raft")
+    ctx = synth.synth_tensor("ctx", (1, 77, UNET_SMALL["context_dim"]))
+    (f_f, f_b), _ = osamp.lr_guidance_flows(rsd, c["lr"], T, c["h"], c["w"])
+    assert rel_l2(f_f[0], g["lr_flow_f"]) < 1e-4 and rel_l2(f_b[0], g["lr_flow_b"]) < 1e-4
+    kw = dict(guidance_scale=-10.0, lr_images=c["lr"], raft_sd=rsd)
+    x0 = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, ctx, c["lat"], c["xT"], c["noises"], c["S"], **kw)
+    assert rel_l2(x0, g["x0_lr"]) < 1e-4
+    x0 = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, ctx, c["lat"], c["xT"], c["noises"], c["S"], flows=(c["ff"][None], c["fb"][None]),
+                      masks=(g["focc"][None, :, None], g["bocc"][None, :, None]), **kw)
+    assert rel_l2(x0, g["x0_lr_flows"]) < 1e-4
+    assert rel_l2(g["x0_lr"], g["x0_lr_flows"]) > 3e-4          # the second term acts on this fixture (6.5e-4 of the x_0 norm)
+
+
 def test_gaussian_weights_golden():
     g = G("g_sample")
     assert torch.equal(osamp.gaussian_weights(16, 16), g["gauss16"])
@@ -390,7 +410,8 @@ def _regen_and_compare(tmp_path, what, names, timeout):
     (["harness"], ["g_harness.npz"], 3600),                                     # recorded run of the tiled entry script's main()
     (["harness_old"], ["g_harness_old.npz"], 3600),                             # recorded runs of the _old / _w_latent scripts
     (["text_hf"], ["g_text_hf.npz"], 1200),                                     # text tower vs transformers' CLIPTextModel
-    (["text_openclip"], ["g_text_openclip.npz"], 1200),                         # text tower through the reference's own embedder class
+    (["text_openclip"], ["g_text_openclip.npz"], 1200),
+    (["sample_lr"], ["g_sample_lr.npz"], 3600),                                 # the lr_images guidance term through the reference's RAFT_SR                         # text tower through the reference's own embedder class
     (["workload:c2s:4"], ["g_work_c2s_S4.npz"], 3600),                          # smooth translating frames, active guidance, 4 steps
     (["workload:c2s:50"], ["g_work_c2s_S50.npz"], 14400),                       # the same at the production schedule
     (["sample_opts_canvas"], ["g_sample_opts_canvas.npz"], 1200),               # start_T on the canvas loop
