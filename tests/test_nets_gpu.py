@@ -634,7 +634,7 @@ def test_sample_lr_images_guidance_vs_reference(hip):
     sc = model.structcond_stage_model(c["lat"].cuda(), t_rep.cuda())
     z1 = model.p_sample(c["xT"], ctx, sc, ts, guidance_scale=-10.0, lr_images=c["lr"], t_replace=t_rep, noise=noise[i])
     first = model.sample(**dict(kw, return_intermediates=True))[1][1]      # intermediates: [x_T, after step S - 1, ...]
-    assert rel_l2(z1, first) < 1e-5
+    assert rel_l2(z1, first) < 2e-3          # (fp16 level: the eager single step evaluates the struct-cond encoder per call, the loop hoists it in batched passes)
 
 
 def test_sample_small_50_steps_vs_oracle(hip):
