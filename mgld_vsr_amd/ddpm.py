@@ -557,6 +557,9 @@ class LatentDiffusionVSRTextWT(nn.Module):
                               for i in range(nclips)]
                 st["z"] = torch.empty_like(x)
                 st["work"] = [torch.empty(hip.guidance_work_bytes(Tn, c, h, w), dtype=torch.uint8, device=dev) for _ in range(nclips)]
+                if sh is not None:
+                    st["x_full"] = torch.empty((T_clip, c, h, w), device=dev)
+                    st["z_full"] = torch.empty((T_clip, c, h, w), device=dev)
             if lr_images is not None:
                 # the `lr_images` term (ddpm.py:4359-4366 -> compute_temporal_condition_v2 :3469-3500): the reference resizes the LR frames
                 # to the latent grid (bicubic), runs its flow network on them INSIDE every step and pulls the latents along those flows
@@ -576,9 +579,6 @@ class LatentDiffusionVSRTextWT(nn.Module):
                     st["work"] = [torch.empty(hip.guidance_work_bytes(Tn, c, h, w), dtype=torch.uint8, device=dev) for _ in range(nclips)]
                 if flows is not None:
                     st["z2"] = torch.empty_like(x)
-                if sh is not None:
-                    st["x_full"] = torch.empty((T_clip, c, h, w), device=dev)
-                    st["z_full"] = torch.empty((T_clip, c, h, w), device=dev)
             # persistent (non-arena) conditioning buffers
             if tile is None:
                 la = torch.empty(T_total * h * w, 8, dtype=torch.float16, device=dev)

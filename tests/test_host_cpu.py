@@ -197,10 +197,10 @@ def test_ddpm_helper_surface():
     sig = lambda f: [k for k in inspect.signature(f).parameters if k != "self"]
     assert sig(model.p_sample_loop) == ref_loop                                          # ddpm.py:4501-4505
     assert sig(model.p_sample_loop_canvas) == ref_loop + ["tile_size", "tile_overlap", "batch_size"]   # ddpm.py:4619-4623
-    with pytest.raises(NotImplementedError):      # still refused, never ignored: the PCA feature dump and the lr_images guidance term
-        model.p_sample_loop(None, None, (3, 4, 8, 8), interfea_path="/tmp/fea")
+    with pytest.raises(NotImplementedError):      # still refused, never ignored: the PCA feature dump (lr_images is implemented since round 5:
+        model.p_sample_loop(None, None, (3, 4, 8, 8), interfea_path="/tmp/fea")      # tests/test_nets_gpu.py::test_sample_lr_images_guidance_vs_reference)
     with pytest.raises(NotImplementedError):
-        model.p_sample_loop(None, None, (3, 4, 8, 8), lr_images=torch.zeros(1))
+        model.p_sample_loop(None, None, (3, 4, 8, 8), quantize_denoised=True)
 
 
 def test_drop_in_signatures():
