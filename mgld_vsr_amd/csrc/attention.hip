@@ -437,6 +437,586 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   }
 }
 
+// SP (round 6): the SOFTWARE-PIPELINED body for the d = 64 self-attention (pre-scaled queries, row-major V, Nkv % 64 == 0).
+//
+// The PMC anatomy of the round-5 kernel (profiles/r05_pmc_attention.txt): per wave and 64-key tile the VALU port is busy ~800 cycles (167
+// instructions: v_exp 8 cycles, everything else 4), the matrix pipe 544, and a tile takes ~1630 — the two pipes take turns instead of
+// overlapping, because inside a wave the chain QK^T -> max3 chain -> ds_bpermute -> exp -> cvt -> PV is serial and an in-order wave stalls
+// on its next MFMA while VALU work of the same tile waits behind it.  This body changes three things:
+//  1. PIPELINE: iteration t issues the QK^T MFMAs of tile t+1 (into the second score set) INTERLEAVED, in program order, with the
+//     softmax of tile t (whose scores are complete since the previous iteration): ~10 independent VALU instructions sit in every MFMA
+//     gap (sched_group_barrier), so one wave alone keeps both pipes busy; then the PV MFMAs of tile t beside the transposing V reads.
+//  2. NO EXCHANGE, NO MAX CHAIN on the common path: the probabilities are computed speculatively against the current running max
+//     (p = exp2(s'), one v_exp each — the scores leave the matrix pipe as s - m because -m is the C operand of the first MFMA of the
+//     chain: no extra k step, 16 MFMAs per tile instead of 18); the row-sum partials double as the overflow test: a lane whose 32
+//     probabilities of the tile sum to more than 2^11 (or to inf / NaN) raises the rare branch, which works on the kept raw scores:
+//     exact row max (with the lane^32 exchange), m += delta for rows more than PS_THR above it, o, l, the new probabilities and the
+//     already accumulated scores of tile t+1 all take the same delta.  Without the branch every p <= 2^11 (fp16-safe); the two half-row
+//     partial sums of l meet only in the epilogue.  VALU per wave-tile: 32 v_exp + 32 v_add + 16 v_cvt_pk (+ ~8 address) = ~480 port
+//     cycles against 512 matrix cycles.
+//  3. RING: K / V tiles go through a three-slot LDS ring of "shifted tiles" {K(j+1), V(j)} (what iteration j reads), issued TWO
+//     iterations ahead with a counted vmcnt(4) — the newest tile's four pieces stay in flight across the barrier.
+// Registers ~200: two blocks (eight waves) per CU.
+template <int WPE, int OPT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void flash_attn_sp_kernel(const MgldAttn p, const int xcd_order) {
+  constexpr int KT = 64;
+  constexpr unsigned SLOT = 16384, VOFF = 8192;        // a slot: K image (64 keys x 128 B, chunk-swizzled) + V image [2][64 keys][32 d]
+  constexpr float BIG = 2048.f;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // 3 slots
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int bx = blockIdx.x, b = blockIdx.z, h = blockIdx.y;
+  if (xcd_order) {                    // (batch, head) pairs per XCD, all their query blocks back to back (see flash_attn_kernel)
+    const int nqb = gridDim.x;
+    const int lin = bx + nqb * (h + (int)gridDim.y * b);
+    const int j = lin >> 3, jq = j / nqb;
+    const int g = (lin & 7) + 8 * jq;
+    bx = j - jq * nqb;
+    b = g / (int)gridDim.y;
+    h = g - b * (int)gridDim.y;
+  }
+  const int q0 = bx * 128 + wave * 32;
+  const int Nq = p.Nq, nt = p.Nkv / KT;
+
+  const f16* __restrict__ Qp = (const f16*)p.Q + b * p.q_sb + h * p.q_sh;
+  const f16* __restrict__ Kp = (const f16*)p.K + b * p.k_sb + h * p.k_sh;
+  const f16* __restrict__ Vp = (const f16*)p.Vt + b * p.vt_sb + h * p.vt_sh;
+
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 qf[4];
+  {
+    const int q = q0 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = (q < Nq) ? *(const f16x8*)(Qp + (int64_t)q * p.q_si + ks * 16 + lhi * 8) : zero8;
+  }
+
+  // ---- DMA addressing (the piece layout of flash_attn_kernel<DMA>): wave w moves K pieces w, w + 4 and V pieces w, w + 4 of a tile
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const at_rsrc_t rsK = at_make_rsrc(Kp), rsV = at_make_rsrc(Vp);
+  const uint32_t ksi2 = (uint32_t)p.k_si * 2u, vsd2 = (uint32_t)p.vt_sd * 2u;
+  uint32_t dvK[2], dvV[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pc = wave_u + 4 * j;
+    const int row = pc * 8 + (lane >> 3);
+    dvK[j] = (uint32_t)row * ksi2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    const int key = (pc & 3) * 16 + (lane >> 2);
+    dvV[j] = (uint32_t)key * vsd2 + (pc >> 2) * 64 + (lane & 3) * 16;
+  }
+  auto dma_K = [&](const int ktile, const unsigned slot_off) __attribute__((always_inline)) {
+    char* dk = smem_raw + slot_off + wave_u * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) at_dma16(rsK, dk + j * 4096, dvK[j], (uint32_t)(ktile * KT) * ksi2);
+  };
+  auto dma_V = [&](const int ktile, const unsigned slot_off) __attribute__((always_inline)) {
+    char* dv = smem_raw + slot_off + VOFF + wave_u * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) at_dma16(rsV, dv + j * 4096, dvV[j], (uint32_t)(ktile * KT) * vsd2);
+  };
+  unsigned k_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_rd[ks] = l31 * 128 + (((ks * 2 + lhi) ^ ((l31 >> 1) & 7)) << 4);
+  const unsigned v_rd = ((((l31 & 15) >> 2) + lhi * 4) * 32 + (l31 & 16) + (l31 & 3) * 4) * 2;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  f32x16 negm;                         // -m of the lane's query row in every element: the C operand that starts a score chain
+  float l_run = 0.f;                   // partial row sum: this lane's keys only (the lane^32 half is added in the epilogue)
+
+  // S'^T = K Q^T - m for the 64 keys of the K image at `koff`
+  auto qk = [&](f32x16 (&s)[2], const f32x16& c0, const unsigned koff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 kf = *(const f16x8*)(smem_raw + koff + k_rd[ks] + k2 * 4096);
+        s[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? c0 : s[k2], 0, 0, 0);
+      }
+  };
+  // p = exp2(s' - delta), kept fp32 until the PV phase packs them: e[8 * c + jj] <-> slot jj of chunk c <-> register 8 * (c & 1) + jj of half c >> 1
+  auto probs = [&](const f32x16 (&s)[2], float (&e)[32], const float delta, const bool sub) __attribute__((always_inline)) -> float {
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float x = s[i >> 4][i & 15];
+      e[i] = __builtin_amdgcn_exp2f(sub ? x - delta : x);
+      rs[i & 3] += e[i];
+    }
+    return (rs[0] + rs[1]) + (rs[2] + rs[3]);
+  };
+  auto row_max = [&](const f32x16 (&s)[2]) __attribute__((always_inline)) -> float {
+    float mx = -1e30f;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
+  auto pack8 = [&](const float (&e)[32], const int c) __attribute__((always_inline)) -> f16x8 {
+    f16x8 r;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) r[jj] = (f16)e[c * 8 + jj];
+    return r;
+  };
+  // the sixteen transposing V reads of a tile, in consumption order: i = 4 * c + 2 * dt + hi (chunk c of 16 keys, d half dt, keys +0..3 / +8..11)
+  at_u64 vq[16];
+#define MGLD_SP_VRD(i) vq[i] = at_tr_read<(((i) >> 1 & 1) * KT + ((i) >> 3) * 32 + ((i) >> 2 & 1) * 16) * 64 + ((i) & 1) * 512>(va);
+  auto pv_mma = [&](const float (&e)[32]) __attribute__((always_inline)) {
+    typedef unsigned at_u128 __attribute__((ext_vector_type(4)));
+    f16x8 pf = pack8(e, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {      // the reads return in order: chunk c's four are the oldest outstanding
+      if (c == 0) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      if (c == 1) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      if (c == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      if (c == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      f16x8 pn = pf;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const at_u128 w = {vq[c * 4 + dt * 2][0], vq[c * 4 + dt * 2][1], vq[c * 4 + dt * 2 + 1][0], vq[c * 4 + dt * 2 + 1][1]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), pf, o[dt], 0, 0, 0);
+        if (dt == 0 && c < 3) pn = pack8(e, c + 1);
+      }
+      pf = pn;
+    }
+  };
+
+  // ---- prologue: K(0) into slot 2's K image (free until iteration 0 issues shifted tile 2), shifted tiles 0 and 1
+  dma_K(0, 2 * SLOT);
+  dma_K(min(1, nt - 1), 0);
+  dma_V(0, 0);
+  if (nt > 1) {
+    dma_K(min(2, nt - 1), SLOT);
+    dma_V(1, SLOT);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  f32x16 sA[2], sB[2];
+  {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    qk(sA, z, 2 * SLOT);
+    const float m0 = row_max(sA);      // anchor: the running max starts at tile 0's row max
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = -m0;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[k2][r] -= m0;
+  }
+
+  unsigned off_t = 0, off_t1 = SLOT, off_t2 = 2 * SLOT;
+  // iteration t: scores of tile t complete in `sa`; QK^T of tile t+1 into `sb` beside the softmax of tile t; PV of tile t
+  auto iter = [&](auto last_tag, f32x16 (&sa)[2], f32x16 (&sb)[2], const int t) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's pieces of shifted tile t have landed (tile t+1's may be in flight)
+    __builtin_amdgcn_s_barrier();                               // ... everyone's have; everyone is done with slot (t - 1) % 3
+    if (t + 2 < nt) {
+      dma_K(min(t + 3, nt - 1), off_t2);
+      dma_V(t + 2, off_t2);
+    }
+    float e[32];
+    float rs;
+    const unsigned va = lds0 + off_t + VOFF + v_rd;    // this lane's part of the V reads' address (the rest are immediates)
+    if constexpr ((OPT & 1) && !LAST) {
+      // eight gaps, each its own scheduling region: one MFMA of QK^T(t+1) + four probabilities of tile t and their row-sum adds
+      // (inline asm: left to the compiler the adds are SLP-packed into v_pk_add_f32 and sunk behind the last MFMA)
+      f16x8 kf[2][4];
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[k2][ks] = *(const f16x8*)(smem_raw + off_t + k_rd[ks] + k2 * 4096);
+      float rsp[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x2 rsq[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#define MGLD_SP_VRD2(g) MGLD_SP_VRD(2 * (g)) MGLD_SP_VRD(2 * (g) + 1)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int k2 = g >> 2, ks = g & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        sb[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[k2][ks], qf[ks], ks == 0 ? negm : sb[k2], 0, 0, 0);
+        if constexpr (OPT & 2) {       // two of the PV phase's sixteen V reads ride in every gap (all K reads are older: in-order return)
+          if (g == 0) { MGLD_SP_VRD2(0) } else if (g == 1) { MGLD_SP_VRD2(1) } else if (g == 2) { MGLD_SP_VRD2(2) } else if (g == 3) { MGLD_SP_VRD2(3) }
+          else if (g == 4) { MGLD_SP_VRD2(4) } else if (g == 5) { MGLD_SP_VRD2(5) } else if (g == 6) { MGLD_SP_VRD2(6) } else { MGLD_SP_VRD2(7) }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = g * 4 + j;
+          e[i] = __builtin_amdgcn_exp2f(sa[i >> 4][i & 15]);
+          if constexpr (!(OPT & 4)) {
+            if (g == 0) rsp[j] = e[i];
+            else asm("v_add_f32_e32 %0, %1, %0" : "+v"(rsp[j]) : "v"(e[i]));
+          }
+        }
+        if constexpr (OPT & 4) {       // row sums as two packed adds per gap
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const f32x2 ep = {e[g * 4 + 2 * j], e[g * 4 + 2 * j + 1]};
+            if (g == 0) rsq[j] = ep;
+            else asm("v_pk_add_f32 %0, %1, %0" : "+v"(rsq[j]) : "v"(ep));
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (OPT & 4) rs = (rsq[0][0] + rsq[0][1]) + (rsq[1][0] + rsq[1][1]);
+      else rs = (rsp[0] + rsp[1]) + (rsp[2] + rsp[3]);
+    } else {
+      if constexpr (!LAST) qk(sb, negm, off_t);
+      rs = probs(sa, e, 0.f, false);
+    }
+    if (__any(!(rs <= BIG))) {         // rare: some row's probabilities outgrew fp16 headroom (or tile 0's anchor was far too low)
+      const float mx = row_max(sa);
+      const float delta = mx > PS_THR ? mx : 0.f;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] -= delta;
+      rs = probs(sa, e, delta, true);
+      if constexpr (!LAST) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sb[k2][r] -= delta;
+      }
+    }
+    l_run += rs;
+    if constexpr (OPT & 8) __builtin_amdgcn_s_setprio(1);      // the PV phase is matrix-bound: its MFMAs go first, the partner's softmax fills the gaps
+    if constexpr (!((OPT & 1) && (OPT & 2) && !LAST)) {
+      MGLD_SP_VRD(0) MGLD_SP_VRD(1) MGLD_SP_VRD(2) MGLD_SP_VRD(3) MGLD_SP_VRD(4) MGLD_SP_VRD(5) MGLD_SP_VRD(6) MGLD_SP_VRD(7)
+      MGLD_SP_VRD(8) MGLD_SP_VRD(9) MGLD_SP_VRD(10) MGLD_SP_VRD(11) MGLD_SP_VRD(12) MGLD_SP_VRD(13) MGLD_SP_VRD(14) MGLD_SP_VRD(15)
+    }
+    pv_mma(e);
+    if constexpr (OPT & 8) __builtin_amdgcn_s_setprio(0);
+    const unsigned tmp = off_t;
+    off_t = off_t1;
+    off_t1 = off_t2;
+    off_t2 = tmp;
+  };
+  {
+    const std::integral_constant<bool, false> more;
+    const std::integral_constant<bool, true> last;
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+      iter(more, sA, sB, t);
+      iter(more, sB, sA, t + 1);
+    }
+    if (nt - t == 2) {
+      iter(more, sA, sB, t);
+      iter(last, sB, sA, t + 1);
+    } else {
+      iter(last, sA, sB, t);
+    }
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l
+  l_run += __shfl_xor(l_run, 32, 64);
+  const int q = q0 + l31;
+  if (q < Nq) {
+    const float inv = 1.f / l_run;
+    f16* Op = (f16*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_si;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = dt * 32 + rg * 8 + lhi * 4;
+        *(f16x4*)(Op + d) = f16x4{(f16)(o[dt][rg * 4 + 0] * inv), (f16)(o[dt][rg * 4 + 1] * inv),
+                                  (f16)(o[dt][rg * 4 + 2] * inv), (f16)(o[dt][rg * 4 + 3] * inv)};
+      }
+  }
+}
+
+// SP2 (round 6): the same pipeline with the remaining per-iteration bubbles taken off a wave's critical path.  One wave alone on its SIMD
+// needed ~1400 cycles per tile for ~700 cycles of MFMA / softmax phases (tools/attn_occ.py): the DMA issue burst at the top of the
+// iteration (~60 cycles per piece), the K fragment reads in front of the first MFMA, the V fragment reads in front of the PV phase.
+//  * FOUR ring slots and the barrier in the MIDDLE of the iteration: iteration t = [QK^T(t+1) || softmax(t) || V(t) fragment reads]
+//    -> trigger test -> vmcnt + barrier (shifted tile t+1 has landed everywhere; everyone is done with slot (t-1) % 4) ->
+//    [PV(t) || packing || the four DMA pieces of shifted tile t+3, one per chunk || the K(t+2) fragment reads of the NEXT QK^T].
+//    So the first MFMA of every phase finds its operands in registers.
+//  * nt even and >= 4 (the 64^2 / 32^2 / 16^2 levels); other key counts take flash_attn_sp_kernel.
+template <int OPT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void flash_attn_sp2_kernel(const MgldAttn p, const int xcd_order) {
+  constexpr int KT = 64;
+  constexpr unsigned SLOT = 16384, VOFF = 8192;
+  constexpr float BIG = 2048.f;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // 4 slots
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int bx = blockIdx.x, b = blockIdx.z, h = blockIdx.y;
+  if (xcd_order) {
+    const int nqb = gridDim.x;
+    const int lin = bx + nqb * (h + (int)gridDim.y * b);
+    const int j = lin >> 3, jq = j / nqb;
+    const int g = (lin & 7) + 8 * jq;
+    bx = j - jq * nqb;
+    b = g / (int)gridDim.y;
+    h = g - b * (int)gridDim.y;
+  }
+  const int q0 = bx * 128 + wave * 32;
+  const int Nq = p.Nq, nt = p.Nkv / KT;
+
+  const f16* __restrict__ Qp = (const f16*)p.Q + b * p.q_sb + h * p.q_sh;
+  const f16* __restrict__ Kp = (const f16*)p.K + b * p.k_sb + h * p.k_sh;
+  const f16* __restrict__ Vp = (const f16*)p.Vt + b * p.vt_sb + h * p.vt_sh;
+
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 qf[4];
+  {
+    const int q = q0 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = (q < Nq) ? *(const f16x8*)(Qp + (int64_t)q * p.q_si + ks * 16 + lhi * 8) : zero8;
+  }
+
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const at_rsrc_t rsK = at_make_rsrc(Kp), rsV = at_make_rsrc(Vp);
+  const uint32_t ksi2 = (uint32_t)p.k_si * 2u, vsd2 = (uint32_t)p.vt_sd * 2u;
+  uint32_t dvK[2], dvV[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pc = wave_u + 4 * j;
+    const int row = pc * 8 + (lane >> 3);
+    dvK[j] = (uint32_t)row * ksi2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    const int key = (pc & 3) * 16 + (lane >> 2);
+    dvV[j] = (uint32_t)key * vsd2 + (pc >> 2) * 64 + (lane & 3) * 16;
+  }
+  // piece i of a shifted tile {K(kt), V(vt)} -> slot at `slot_off`: i = 0, 1 the wave's two K pieces, i = 2, 3 its two V pieces
+  auto dma_piece = [&](const int i, const int kt, const int vt, const unsigned slot_off) __attribute__((always_inline)) {
+    if (i < 2) at_dma16(rsK, smem_raw + slot_off + wave_u * 1024 + i * 4096, dvK[i], (uint32_t)(kt * KT) * ksi2);
+    else at_dma16(rsV, smem_raw + slot_off + VOFF + wave_u * 1024 + (i - 2) * 4096, dvV[i - 2], (uint32_t)(vt * KT) * vsd2);
+  };
+  unsigned k_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_rd[ks] = l31 * 128 + (((ks * 2 + lhi) ^ ((l31 >> 1) & 7)) << 4);
+  const unsigned v_rd = ((((l31 & 15) >> 2) + lhi * 4) * 32 + (l31 & 16) + (l31 & 3) * 4) * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  f32x16 negm;
+  float l_run = 0.f;
+  f16x8 kf[2][4];                      // K fragments of the NEXT QK^T (read during the PV phase)
+  at_u64 vq[16];                       // V fragments of this tile's PV (read during the QK^T phase)
+
+  auto load_kf = [&](const unsigned koff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[k2][ks] = *(const f16x8*)(smem_raw + koff + k_rd[ks] + k2 * 4096);
+  };
+  auto probs = [&](const f32x16 (&s)[2], float (&e)[32], const float delta, const bool sub) __attribute__((always_inline)) -> float {
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float x = s[i >> 4][i & 15];
+      e[i] = __builtin_amdgcn_exp2f(sub ? x - delta : x);
+      rs[i & 3] += e[i];
+    }
+    return (rs[0] + rs[1]) + (rs[2] + rs[3]);
+  };
+  auto row_max = [&](const f32x16 (&s)[2]) __attribute__((always_inline)) -> float {
+    float mx = -1e30f;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+  auto pack8 = [&](const float (&e)[32], const int c) __attribute__((always_inline)) -> f16x8 {
+    f16x8 r;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) r[jj] = (f16)e[c * 8 + jj];
+    return r;
+  };
+  // the rare branch (see flash_attn_sp_kernel)
+  auto rescale = [&](const f32x16 (&sa)[2], f32x16 (*sb)[2], float (&e)[32]) __attribute__((always_inline)) -> float {
+    const float mx = row_max(sa);
+    const float delta = mx > PS_THR ? mx : 0.f;
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    l_run *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] -= delta;
+    if (sb) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (*sb)[k2][r] -= delta;
+    }
+    return probs(sa, e, delta, true);
+  };
+
+  // ---- prologue: K(0) into slot 3's K image (slot 3 is first written by shifted tile 3, behind iteration 0's barrier), shifted tiles 0, 1, 2
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dma_piece(i, 0, 0, 3 * SLOT);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_piece(i, 1, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_piece(i, 2, 1, SLOT);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_piece(i, 3, 2, 2 * SLOT);       // (nt >= 4)
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f32x16 sA[2], sB[2];
+  {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    load_kf(3 * SLOT);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sA[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[k2][ks], qf[ks], ks == 0 ? z : sA[k2], 0, 0, 0);
+    const float m0 = row_max(sA);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = -m0;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[k2][r] -= m0;
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // shifted tile 0 = {K(1), V(0)}
+  __builtin_amdgcn_s_barrier();
+  load_kf(0);
+
+#define MGLD_SP_VRD(i) vq[i] = at_tr_read<(((i) >> 1 & 1) * KT + ((i) >> 3) * 32 + ((i) >> 2 & 1) * 16) * 64 + ((i) & 1) * 512>(va);
+#define MGLD_SP_VRD2(g) MGLD_SP_VRD(2 * (g)) MGLD_SP_VRD(2 * (g) + 1)
+  // KIND 0: a full iteration (DMA of shifted tile t+3, K(t+2) prefetch); 1: no DMA left (t + 3 == nt); 2: nothing to prefetch (t + 2 == nt);
+  // 3: the last tile (no QK^T)
+  auto iter = [&](auto kind_tag, f32x16 (&sa)[2], f32x16 (&sb)[2], const int t) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    const unsigned slot_t = (unsigned)(t & 3) * SLOT;
+    const unsigned va = lds0 + slot_t + VOFF + v_rd;
+    float e[32];
+    float rs;
+    if constexpr (KIND < 3) {
+      f32x2 rsq[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int k2 = g >> 2, ks = g & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        sb[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[k2][ks], qf[ks], ks == 0 ? negm : sb[k2], 0, 0, 0);
+        if (g == 0) { MGLD_SP_VRD2(0) } else if (g == 1) { MGLD_SP_VRD2(1) } else if (g == 2) { MGLD_SP_VRD2(2) } else if (g == 3) { MGLD_SP_VRD2(3) }
+        else if (g == 4) { MGLD_SP_VRD2(4) } else if (g == 5) { MGLD_SP_VRD2(5) } else if (g == 6) { MGLD_SP_VRD2(6) } else { MGLD_SP_VRD2(7) }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[g * 4 + j] = __builtin_amdgcn_exp2f(sa[g >> 2][(g & 3) * 4 + j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x2 ep = {e[g * 4 + 2 * j], e[g * 4 + 2 * j + 1]};
+          if (g == 0) rsq[j] = ep;
+          else asm("v_pk_add_f32 %0, %1, %0" : "+v"(rsq[j]) : "v"(ep));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      rs = (rsq[0][0] + rsq[0][1]) + (rsq[1][0] + rsq[1][1]);
+    } else {
+      MGLD_SP_VRD2(0) MGLD_SP_VRD2(1) MGLD_SP_VRD2(2) MGLD_SP_VRD2(3) MGLD_SP_VRD2(4) MGLD_SP_VRD2(5) MGLD_SP_VRD2(6) MGLD_SP_VRD2(7)
+      rs = probs(sa, e, 0.f, false);
+    }
+    if (__any(!(rs <= BIG))) rs = rescale(sa, KIND < 3 ? &sb : nullptr, e);
+    l_run += rs;
+    if constexpr (KIND < 3) {
+      // shifted tile t+1 = {K(t+2), V(t+1)} has landed for this wave (tile t+2's four pieces may still fly) ... for everyone; and everyone
+      // is past the QK^T phase of iteration t, i.e. done with slot (t - 1) % 4
+      if constexpr (KIND == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // ---- PV(t): chunk c's four V fragments are the oldest outstanding LDS reads; behind them the K(t+2) fragment reads issued here, two per chunk
+    typedef unsigned at_u128 __attribute__((ext_vector_type(4)));
+    const unsigned slot_n = (unsigned)((t + 1) & 3) * SLOT, slot_d = (unsigned)((t + 3) & 3) * SLOT;
+    f16x8 pf = pack8(e, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      constexpr bool PRE = KIND < 2;
+      // (all eight K reads go out in chunks 0 and 1, four each: they have two chunks of MFMAs to land before the next QK^T phase)
+      if (c == 0) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      if (c == 1) { if constexpr (PRE) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
+      if (c == 2) { if constexpr (PRE) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
+      if (c == 3) { if constexpr (PRE) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      __builtin_amdgcn_sched_barrier(0);
+      f16x8 pn = pf;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const at_u128 w = {vq[c * 4 + dt * 2][0], vq[c * 4 + dt * 2][1], vq[c * 4 + dt * 2 + 1][0], vq[c * 4 + dt * 2 + 1][1]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), pf, o[dt], 0, 0, 0);
+        if (dt == 0) {
+          if (c < 3) pn = pack8(e, c + 1);
+          if constexpr (KIND == 0) dma_piece(c, min(t + 4, nt - 1), t + 3, slot_d);
+          if constexpr (PRE) {
+            if (c < 2) {
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) kf[c][ks] = *(const f16x8*)(smem_raw + slot_n + k_rd[ks] + c * 4096);
+            }
+          }
+        }
+      }
+      pf = pn;
+    }
+    if constexpr (KIND < 2) {
+      // the prefetched K fragments are "used" here, so the compiler's own s_waitcnt for them lands HERE (nothing else is outstanding) and
+      // not in the next QK^T phase, where its count would not know of the V reads (inline asm) and would drain them gap by gap
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(kf[k2][ks]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    const std::integral_constant<int, 0> full;
+    const std::integral_constant<int, 1> tail2;
+    const std::integral_constant<int, 2> tail1;
+    const std::integral_constant<int, 3> last;
+    int t = 0;
+    for (; t + 5 < nt; t += 2) {       // nt even: full iterations t = 0 .. nt - 4, an odd count
+      iter(full, sA, sB, t);
+      iter(full, sB, sA, t + 1);
+    }
+    iter(full, sA, sB, t);
+    iter(tail2, sB, sA, t + 1);
+    iter(tail1, sA, sB, t + 2);
+    iter(last, sB, sA, t + 3);
+  }
+#undef MGLD_SP_VRD2
+#undef MGLD_SP_VRD
+
+  l_run += __shfl_xor(l_run, 32, 64);
+  const int q = q0 + l31;
+  if (q < Nq) {
+    const float inv = 1.f / l_run;
+    f16* Op = (f16*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_si;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = dt * 32 + rg * 8 + lhi * 4;
+        *(f16x4*)(Op + d) = f16x4{(f16)(o[dt][rg * 4 + 0] * inv), (f16)(o[dt][rg * 4 + 1] * inv),
+                                  (f16)(o[dt][rg * 4 + 2] * inv), (f16)(o[dt][rg * 4 + 3] * inv)};
+      }
+  }
+}
+
 // one block per row: fp32 logits -> fp16 probabilities.  period > 0: causal mask inside blocks of `period` rows (column c
 // of row r is kept iff c <= r % period: the text transformer's attn_mask); columns [cols, cols_pad) are written as zeros so
 // the probabilities can feed a GEMM whose K is padded to a multiple of 8.
@@ -470,6 +1050,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // does the launcher stage K / V by LDS-DMA for this problem (flash_attn_kernel<64, true, true>)?  env MGLD_ATTN_DMA = 0: never (A/B)
 // 64 query rows per wave (flash_attn_kernel<64, true, true, 2>): env MGLD_ATTN_QH = 2 selects it (A/B; measured slower, see the kernel)
 static int attn_qh(const MgldAttn* p);
+static bool attn_prescaled(const MgldAttn* p);
 static bool attn_takes_dma(const MgldAttn* p) {
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("MGLD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
@@ -483,6 +1064,13 @@ static bool attn_prescaled(const MgldAttn* p) {
   if (on < 0) { const char* e = getenv("MGLD_ATTN_PS"); on = e ? atoi(e) : 1; }
   return on && attn_takes_dma(p) && fabsf(p->scale * 1.44269504088896340736f - 1.f) < 1e-6f;
 }
+// software-pipelined body (flash_attn_sp_kernel): env MGLD_ATTN_SP = 0 off / variant code (A/B), default 1
+static int attn_sp(const MgldAttn* p) {
+  static int sp = -1, dyn = -1;
+  if (dyn < 0) dyn = getenv("MGLD_DEBUG_DYNENV") ? 1 : 0;     // kernel A/B inside one process (tools/): re-read the knob at every launch
+  if (sp < 0 || dyn) { const char* e = getenv("MGLD_ATTN_SP"); sp = e ? atoi(e) : 38; }   // 32: SP2 where it applies + 6: SP <2, 5> elsewhere
+  return (sp && attn_prescaled(p) && attn_qh(p) == 1) ? sp : 0;
+}
 static int attn_qh(const MgldAttn* p) {
   static int qh = -1;
   if (qh < 0) { const char* e = getenv("MGLD_ATTN_QH"); qh = e ? atoi(e) : 1; }
@@ -494,7 +1082,9 @@ static int attn_qh(const MgldAttn* p) {
 extern "C" int mgld_attention_kernel_name(const MgldAttn* p, char* buf, int buflen) {
   MGLD_REQUIRE(p && buf && buflen > 0, "attention_kernel_name: null");
   MGLD_REQUIRE(p->head_dim == 64 || p->head_dim == 128, "attention: head_dim must be 64 or 128");
-  if (p->v_rowmajor && attn_qh(p) == 2) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 2, false>");
+  if (p->v_rowmajor && attn_sp(p) >= 32 && (p->Nkv % 128) == 0 && p->Nkv >= 256) snprintf(buf, buflen, "flash_attn_sp2_kernel<0>");
+  else if (p->v_rowmajor && (attn_sp(p) & 31)) snprintf(buf, buflen, "flash_attn_sp_kernel<2, %d>", (attn_sp(p) & 31) - 1);
+  else if (p->v_rowmajor && attn_qh(p) == 2) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 2, false>");
   else if (p->v_rowmajor && attn_prescaled(p)) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 1, true>");
   else if (p->v_rowmajor) snprintf(buf, buflen, "flash_attn_kernel<%d, true, %s, 1, false>", p->head_dim, attn_takes_dma(p) ? "true" : "false");
   else snprintf(buf, buflen, "flash_attn_kernel<%d, false, false, 1, false>", p->head_dim);
@@ -529,7 +1119,33 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
       (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
       attr_done2 = true;
     }
-    if (attn_qh(p) == 2) {
+    if (attn_sp(p) >= 32 && (p->Nkv % 128) == 0 && p->Nkv >= 256) {     // flash_attn_sp2_kernel: an even tile count >= 4
+      int lds = 4 * 16384;
+      if (getenv("MGLD_DEBUG_DYNENV") && getenv("MGLD_ATTN_SP_LDS")) lds = atoi(getenv("MGLD_ATTN_SP_LDS"));   // occupancy experiments (tools/)
+      if (lds > 65536) (void)hipFuncSetAttribute((const void*)flash_attn_sp2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((flash_attn_sp2_kernel<0>), grid, dim3(256), lds, (hipStream_t)stream, *p, order);
+    } else if (const int sp = attn_sp(p) & 31) {
+      int LDS_SP = 3 * 16384;
+      if (getenv("MGLD_DEBUG_DYNENV") && getenv("MGLD_ATTN_SP_LDS")) LDS_SP = atoi(getenv("MGLD_ATTN_SP_LDS"));   // occupancy experiments (tools/)
+#define MGLD_SP_LAUNCH(W, O)                                                                                                             \
+  do {                                                                                                                                   \
+    if (LDS_SP > 65536) (void)hipFuncSetAttribute((const void*)flash_attn_sp_kernel<W, O>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SP); \
+    hipLaunchKernelGGL((flash_attn_sp_kernel<W, O>), grid, dim3(256), LDS_SP, (hipStream_t)stream, *p, order);                          \
+  } while (0)
+      switch (sp) {               // MGLD_ATTN_SP = 1 + OPT
+        case 1: MGLD_SP_LAUNCH(2, 0); break;
+        case 2: MGLD_SP_LAUNCH(2, 1); break;
+        case 4: MGLD_SP_LAUNCH(2, 3); break;
+        case 6: MGLD_SP_LAUNCH(2, 5); break;
+        case 8: MGLD_SP_LAUNCH(2, 7); break;
+        case 10: MGLD_SP_LAUNCH(2, 9); break;
+        case 12: MGLD_SP_LAUNCH(2, 11); break;
+        case 14: MGLD_SP_LAUNCH(2, 13); break;
+        case 16: MGLD_SP_LAUNCH(2, 15); break;
+        default: MGLD_REQUIRE(false, "attention: unknown MGLD_ATTN_SP variant");
+      }
+#undef MGLD_SP_LAUNCH
+    } else if (attn_qh(p) == 2) {
       const dim3 grid2(p->Nq / 256, p->heads, p->batch);
       hipLaunchKernelGGL((flash_attn_kernel<64, true, true, 2>), grid2, dim3(256), LDS64, (hipStream_t)stream, *p, order);
     } else if (attn_prescaled(p))

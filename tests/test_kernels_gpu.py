@@ -1307,11 +1307,14 @@ def test_tile_conv3p_kernel_matches_the_host_layout(hip, n, cin, ti):
     assert torch.equal(hip.tile_conv3p(wp, cin, ti), tile_conv3p(wp, cin, ti))
 
 
-@pytest.mark.parametrize("B,H,N", [(8, 5, 4096), (8, 10, 1024), (3, 5, 256), (1, 2, 64)])
+@pytest.mark.parametrize("B,H,N", [(8, 5, 4096), (8, 10, 1024), (3, 5, 256), (1, 2, 64), (2, 3, 192), (2, 2, 320), (1, 1, 128), (16, 20, 256)])
 def test_flash_attention_prescaled_queries(hip, B, H, N):
-    """flash_attn_kernel<64, true, true, 1, true>: queries pre-scaled by d^-1/2 log2(e) (scale = ln 2 selects it), the running max carried
-    into the scores by an extra k step, deferred rescale.  Rows with spikes late in the key axis (the rescale path), a row whose FIRST
-    key tile is far below the rest (the anchor at t = 0 and a large later jump) and rows whose scores are all very negative."""
+    """the software-pipelined d = 64 self-attention (flash_attn_sp2_kernel / flash_attn_sp_kernel, round 6): queries pre-scaled by
+    d^-1/2 log2(e) (scale = ln 2 selects it), the running max carried into the scores as the C operand of the score chain, probabilities
+    computed speculatively with the row-sum partials as the overflow trigger.  Rows with spikes late in the key axis (the rescale path), a
+    spike far past exp2's range (inf in the speculative pass), a whole tile moderately above the running max (the row-sum trigger without
+    one large probability), rows whose FIRST key tile is far / hundreds below the rest (the anchor at t = 0 and a large later jump) and
+    rows whose scores are all very negative."""
     D = 64
     C_ = H * D
     f = D ** -0.5 * 1.4426950408889634
@@ -1325,6 +1328,10 @@ def test_flash_attention_prescaled_queries(hip, B, H, N):
         k[:64, :D] = -q[9, :D] * 3                      # query 9: its first key tile scores ~ -3 |q|^2, far below the later ones
         q[11, :D] = 0.0                                 # flat row
         k[:, D:2 * D] -= 2.5 * torch.sign(q[13, D:2 * D])     # head 1, query 13: every score strongly negative
+        k[N - 70, :D] = q[50, :D] * 60                  # far past exp2's range relative to the anchor
+        k[130:190, :D] += q[60, :D] * 0.9               # a whole tile moderately above query 60's running max
+        if H > 2:
+            k[:64, 2 * D:3 * D] = -q[70, 2 * D:3 * D] * 40   # head 2, query 70: anchor tile hundreds below the rest
     qkv = torch.cat([(q * f), k, v], 1).half().to(DEV)
     o = torch.empty(B * N, C_, dtype=torch.half, device=DEV)
     st = (N * 3 * C_, 3 * C_, D)
@@ -1332,7 +1339,8 @@ def test_flash_attention_prescaled_queries(hip, B, H, N):
     try:
         hip.attention(qkv, qkv[:, C_:], qkv[:, 2 * C_:], o, batch=B, heads=H, Nq=N, Nkv=N, head_dim=D, q_strides=st, k_strides=st, vt_strides=st,
                       o_strides=(N * C_, C_, D), scale=1.0 / 1.4426950408889634, v_rowmajor=True)
-        assert hip.TIMED[0][1]["kernel"] == "flash_attn_kernel<64, true, true, 1, true>", hip.TIMED[0][1]["kernel"]
+        want = "flash_attn_sp2_kernel<0>" if (N % 128 == 0 and N >= 256) else "flash_attn_sp_kernel<2, 5>"
+        assert hip.TIMED[0][1]["kernel"] == want, hip.TIMED[0][1]["kernel"]
     finally:
         hip.TIMED = None
     kq = lambda t: t.float().reshape(B, N, H, D).permute(0, 2, 1, 3)

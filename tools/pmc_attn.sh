@@ -10,4 +10,4 @@ rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_AC
 cd $R
 for x in a b c; do python tools/pmc_summary.py gpurun_out/pmc_${TAG}_$x flash_attn > gpurun_out/pmc_${TAG}_$x.txt 2>&1; done
 find gpurun_out/pmc_${TAG}_a gpurun_out/pmc_${TAG}_b gpurun_out/pmc_${TAG}_c -name "*.csv" -delete 2>/dev/null
-cat gpurun_out/pmc_${TAG}_a.txt gpurun_out/pmc_${TAG}_b.txt gpurun_out/pmc_${TAG}_c.txt | grep -A12 "grid=2621440\|grid=1310720" | head -120
+cat gpurun_out/pmc_${TAG}_a.txt gpurun_out/pmc_${TAG}_b.txt gpurun_out/pmc_${TAG}_c.txt | grep -A12 "grid=327680" | head -80
