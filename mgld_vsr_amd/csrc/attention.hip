@@ -437,28 +437,31 @@ void flash_attn_kernel(const MgldAttn p, const int xcd_order) {
   }
 }
 
-// SP (round 6): the SOFTWARE-PIPELINED body for the d = 64 self-attention (pre-scaled queries, row-major V, Nkv % 64 == 0).
+// SP (round 6): the SOFTWARE-PIPELINED body for the d = 64 self-attention (pre-scaled queries, row-major V, Nkv % 64 == 0; any tile count:
+// the 8^2 level and odd counts; the 64^2 / 32^2 / 16^2 levels take SP2 below).
 //
 // The PMC anatomy of the round-5 kernel (profiles/r05_pmc_attention.txt): per wave and 64-key tile the VALU port is busy ~800 cycles (167
 // instructions: v_exp 8 cycles, everything else 4), the matrix pipe 544, and a tile takes ~1630 — the two pipes take turns instead of
 // overlapping, because inside a wave the chain QK^T -> max3 chain -> ds_bpermute -> exp -> cvt -> PV is serial and an in-order wave stalls
 // on its next MFMA while VALU work of the same tile waits behind it.  This body changes three things:
 //  1. PIPELINE: iteration t issues the QK^T MFMAs of tile t+1 (into the second score set) INTERLEAVED, in program order, with the
-//     softmax of tile t (whose scores are complete since the previous iteration): ~10 independent VALU instructions sit in every MFMA
-//     gap (sched_group_barrier), so one wave alone keeps both pipes busy; then the PV MFMAs of tile t beside the transposing V reads.
+//     softmax of tile t (whose scores are complete since the previous iteration): every MFMA gap is its own scheduling region
+//     (sched_barrier) holding one MFMA, four v_exp and the row-sum adds; then the PV MFMAs of tile t with the packing between them.
 //  2. NO EXCHANGE, NO MAX CHAIN on the common path: the probabilities are computed speculatively against the current running max
 //     (p = exp2(s'), one v_exp each — the scores leave the matrix pipe as s - m because -m is the C operand of the first MFMA of the
 //     chain: no extra k step, 16 MFMAs per tile instead of 18); the row-sum partials double as the overflow test: a lane whose 32
 //     probabilities of the tile sum to more than 2^11 (or to inf / NaN) raises the rare branch, which works on the kept raw scores:
 //     exact row max (with the lane^32 exchange), m += delta for rows more than PS_THR above it, o, l, the new probabilities and the
 //     already accumulated scores of tile t+1 all take the same delta.  Without the branch every p <= 2^11 (fp16-safe); the two half-row
-//     partial sums of l meet only in the epilogue.  VALU per wave-tile: 32 v_exp + 32 v_add + 16 v_cvt_pk (+ ~8 address) = ~480 port
-//     cycles against 512 matrix cycles.
+//     partial sums of l meet only in the epilogue.  VALU per wave-tile: 32 v_exp + 16 v_pk_add + 16 v_cvt_pk + ~16 others: 96
+//     instructions, 512 port cycles (was 167 / ~800).
 //  3. RING: K / V tiles go through a three-slot LDS ring of "shifted tiles" {K(j+1), V(j)} (what iteration j reads), issued TWO
 //     iterations ahead with a counted vmcnt(4) — the newest tile's four pieces stay in flight across the barrier.
-// Registers ~200: two blocks (eight waves) per CU.
-template <int WPE, int OPT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+// 236 registers: two blocks (eight waves) per CU.  Measured (tools/attn_ab.py, variants interleaved in one process): 64^2 self-attention of
+// sixteen frames 408 -> 352 us (0.337 -> 0.390 of the 2.5 PF dense peak).  What did NOT matter, each A/B'd on the hardware: the order of
+// MFMA and VALU inside a gap (compiler-scheduled vs regions), packed vs plain row-sum adds, V reads inside the QK^T gaps, s_setprio
+// around the PV phase, a balanced split of the softmax over all sixteen gaps (profiles/r06_attention.md).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void flash_attn_sp_kernel(const MgldAttn p, const int xcd_order) {
   constexpr int KT = 64;
   constexpr unsigned SLOT = 16384, VOFF = 8192;        // a slot: K image (64 keys x 128 B, chunk-swizzled) + V image [2][64 keys][32 d]
@@ -629,49 +632,32 @@ void flash_attn_sp_kernel(const MgldAttn p, const int xcd_order) {
     float e[32];
     float rs;
     const unsigned va = lds0 + off_t + VOFF + v_rd;    // this lane's part of the V reads' address (the rest are immediates)
-    if constexpr ((OPT & 1) && !LAST) {
+    if constexpr (!LAST) {
       // eight gaps, each its own scheduling region: one MFMA of QK^T(t+1) + four probabilities of tile t and their row-sum adds
-      // (inline asm: left to the compiler the adds are SLP-packed into v_pk_add_f32 and sunk behind the last MFMA)
+      // (inline asm: left to the compiler the adds are sunk behind the last MFMA)
       f16x8 kf[2][4];
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) kf[k2][ks] = *(const f16x8*)(smem_raw + off_t + k_rd[ks] + k2 * 4096);
-      float rsp[4] = {0.f, 0.f, 0.f, 0.f};
       f32x2 rsq[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#define MGLD_SP_VRD2(g) MGLD_SP_VRD(2 * (g)) MGLD_SP_VRD(2 * (g) + 1)
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int k2 = g >> 2, ks = g & 3;
         __builtin_amdgcn_sched_barrier(0);
         sb[k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[k2][ks], qf[ks], ks == 0 ? negm : sb[k2], 0, 0, 0);
-        if constexpr (OPT & 2) {       // two of the PV phase's sixteen V reads ride in every gap (all K reads are older: in-order return)
-          if (g == 0) { MGLD_SP_VRD2(0) } else if (g == 1) { MGLD_SP_VRD2(1) } else if (g == 2) { MGLD_SP_VRD2(2) } else if (g == 3) { MGLD_SP_VRD2(3) }
-          else if (g == 4) { MGLD_SP_VRD2(4) } else if (g == 5) { MGLD_SP_VRD2(5) } else if (g == 6) { MGLD_SP_VRD2(6) } else { MGLD_SP_VRD2(7) }
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = g * 4 + j;
-          e[i] = __builtin_amdgcn_exp2f(sa[i >> 4][i & 15]);
-          if constexpr (!(OPT & 4)) {
-            if (g == 0) rsp[j] = e[i];
-            else asm("v_add_f32_e32 %0, %1, %0" : "+v"(rsp[j]) : "v"(e[i]));
-          }
-        }
-        if constexpr (OPT & 4) {       // row sums as two packed adds per gap
+        for (int j = 0; j < 4; ++j) e[g * 4 + j] = __builtin_amdgcn_exp2f(sa[g >> 2][(g & 3) * 4 + j]);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const f32x2 ep = {e[g * 4 + 2 * j], e[g * 4 + 2 * j + 1]};
-            if (g == 0) rsq[j] = ep;
-            else asm("v_pk_add_f32 %0, %1, %0" : "+v"(rsq[j]) : "v"(ep));
-          }
+        for (int j = 0; j < 2; ++j) {
+          const f32x2 ep = {e[g * 4 + 2 * j], e[g * 4 + 2 * j + 1]};
+          if (g == 0) rsq[j] = ep;
+          else asm("v_pk_add_f32 %0, %1, %0" : "+v"(rsq[j]) : "v"(ep));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (OPT & 4) rs = (rsq[0][0] + rsq[0][1]) + (rsq[1][0] + rsq[1][1]);
-      else rs = (rsp[0] + rsp[1]) + (rsp[2] + rsp[3]);
+      rs = (rsq[0][0] + rsq[0][1]) + (rsq[1][0] + rsq[1][1]);
     } else {
-      if constexpr (!LAST) qk(sb, negm, off_t);
       rs = probs(sa, e, 0.f, false);
     }
     if (__any(!(rs <= BIG))) {         // rare: some row's probabilities outgrew fp16 headroom (or tile 0's anchor was far too low)
@@ -694,13 +680,9 @@ void flash_attn_sp_kernel(const MgldAttn p, const int xcd_order) {
       }
     }
     l_run += rs;
-    if constexpr (OPT & 8) __builtin_amdgcn_s_setprio(1);      // the PV phase is matrix-bound: its MFMAs go first, the partner's softmax fills the gaps
-    if constexpr (!((OPT & 1) && (OPT & 2) && !LAST)) {
-      MGLD_SP_VRD(0) MGLD_SP_VRD(1) MGLD_SP_VRD(2) MGLD_SP_VRD(3) MGLD_SP_VRD(4) MGLD_SP_VRD(5) MGLD_SP_VRD(6) MGLD_SP_VRD(7)
-      MGLD_SP_VRD(8) MGLD_SP_VRD(9) MGLD_SP_VRD(10) MGLD_SP_VRD(11) MGLD_SP_VRD(12) MGLD_SP_VRD(13) MGLD_SP_VRD(14) MGLD_SP_VRD(15)
-    }
+    MGLD_SP_VRD(0) MGLD_SP_VRD(1) MGLD_SP_VRD(2) MGLD_SP_VRD(3) MGLD_SP_VRD(4) MGLD_SP_VRD(5) MGLD_SP_VRD(6) MGLD_SP_VRD(7)
+    MGLD_SP_VRD(8) MGLD_SP_VRD(9) MGLD_SP_VRD(10) MGLD_SP_VRD(11) MGLD_SP_VRD(12) MGLD_SP_VRD(13) MGLD_SP_VRD(14) MGLD_SP_VRD(15)
     pv_mma(e);
-    if constexpr (OPT & 8) __builtin_amdgcn_s_setprio(0);
     const unsigned tmp = off_t;
     off_t = off_t1;
     off_t1 = off_t2;
@@ -739,15 +721,23 @@ void flash_attn_sp_kernel(const MgldAttn p, const int xcd_order) {
   }
 }
 
-// SP2 (round 6): the same pipeline with the remaining per-iteration bubbles taken off a wave's critical path.  One wave alone on its SIMD
-// needed ~1400 cycles per tile for ~700 cycles of MFMA / softmax phases (tools/attn_occ.py): the DMA issue burst at the top of the
-// iteration (~60 cycles per piece), the K fragment reads in front of the first MFMA, the V fragment reads in front of the PV phase.
-//  * FOUR ring slots and the barrier in the MIDDLE of the iteration: iteration t = [QK^T(t+1) || softmax(t) || V(t) fragment reads]
-//    -> trigger test -> vmcnt + barrier (shifted tile t+1 has landed everywhere; everyone is done with slot (t-1) % 4) ->
-//    [PV(t) || packing || the four DMA pieces of shifted tile t+3, one per chunk || the K(t+2) fragment reads of the NEXT QK^T].
-//    So the first MFMA of every phase finds its operands in registers.
+// SP2 (round 6): the same pipeline with the per-iteration bubbles taken off a wave's critical path.  One wave alone on its SIMD needed
+// ~1400 cycles per tile for ~700 cycles of MFMA / softmax phases (tools/attn_occ.py): the DMA issue burst at the top of the iteration, the
+// K fragment reads in front of the first MFMA, the V fragment reads in front of the PV phase.
+//  * FOUR ring slots and the barrier in the MIDDLE of the iteration: iteration t = [QK^T(t+1) || softmax(t) || V(t) fragment reads, two
+//    per gap] -> trigger test -> vmcnt(4) + barrier (shifted tile t+1 has landed everywhere; everyone is done with slot (t-1) % 4) ->
+//    [PV(t) || packing || the four DMA pieces of shifted tile t+3, one per chunk || the K(t+2) fragment reads of the NEXT QK^T, all eight
+//    in the first two chunks].  The first MFMA of every phase finds its operands in registers.
+//  * The V reads are inline asm (the builtin makes hipcc drain the DMA queue in front of them), so the compiler's own lgkmcnt bookkeeping
+//    for the K fragments would over-wait by every V read issued in between: the K fragments are "used" by an empty asm at the end of the
+//    PV phase, which pins the compiler's wait there, and the V fragments are consumed behind counted lgkmcnt waits (LDS returns in order).
 //  * nt even and >= 4 (the 64^2 / 32^2 / 16^2 levels); other key counts take flash_attn_sp_kernel.
-template <int OPT>
+// Measured: sixteen frames x 5 heads x 4096^2: 352 -> 341 us, 0.403 of the 2.5 PF dense peak (round 5: 408 us, 0.337); eight frames 0.399;
+// 32^2 level 0.332 (2.5 rounds of blocks), 16^2 0.141 (four tiles per block: prologue + epilogue).  Where the rest goes (profiles/r06_attention.md):
+// the register-only instruction stream of a tile (tools/ubench/tile.hip: 16 MFMAs + 32 v_exp + row sums + 16 v_cvt_pk, two waves per SIMD)
+// takes 353-370 ns per tile and SIMD, 16 bare MFMAs 257 ns (sustained clock ~2.0 GHz under matrix load, not 2.4), the kernel 533 ns; with
+// the V reads / DMA / K reads compiled out (timing probes, wrong results) the 341 us fall by 43 / 32 / 16 us, with all memory-side
+// instructions out to 241 us = the register-only stream.  The barrier and the DMA wait cost nothing (probes): a partner wave fills them.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void flash_attn_sp2_kernel(const MgldAttn p, const int xcd_order) {
   constexpr int KT = 64;
@@ -921,7 +911,7 @@ void flash_attn_sp2_kernel(const MgldAttn p, const int xcd_order) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[g * 4 + j] = __builtin_amdgcn_exp2f(sa[g >> 2][(g & 3) * 4 + j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j) {    // (row sums as two packed adds per gap; four plain v_add_f32 measured the same)
           const f32x2 ep = {e[g * 4 + 2 * j], e[g * 4 + 2 * j + 1]};
           if (g == 0) rsq[j] = ep;
           else asm("v_pk_add_f32 %0, %1, %0" : "+v"(rsq[j]) : "v"(ep));
@@ -1064,12 +1054,14 @@ static bool attn_prescaled(const MgldAttn* p) {
   if (on < 0) { const char* e = getenv("MGLD_ATTN_PS"); on = e ? atoi(e) : 1; }
   return on && attn_takes_dma(p) && fabsf(p->scale * 1.44269504088896340736f - 1.f) < 1e-6f;
 }
-// software-pipelined body (flash_attn_sp_kernel): env MGLD_ATTN_SP = 0 off / variant code (A/B), default 1
+// software-pipelined bodies: 2 = flash_attn_sp2_kernel (an even count >= 4 of 64-key tiles), 1 = flash_attn_sp_kernel (any count), 0 = neither.
+// env MGLD_ATTN_SP = 0: the round-5 kernel (A/B); MGLD_DEBUG_DYNENV: the knob is re-read at every launch (kernel A/B inside one process, tools/)
 static int attn_sp(const MgldAttn* p) {
   static int sp = -1, dyn = -1;
-  if (dyn < 0) dyn = getenv("MGLD_DEBUG_DYNENV") ? 1 : 0;     // kernel A/B inside one process (tools/): re-read the knob at every launch
-  if (sp < 0 || dyn) { const char* e = getenv("MGLD_ATTN_SP"); sp = e ? atoi(e) : 38; }   // 32: SP2 where it applies + 6: SP <2, 5> elsewhere
-  return (sp && attn_prescaled(p) && attn_qh(p) == 1) ? sp : 0;
+  if (dyn < 0) dyn = getenv("MGLD_DEBUG_DYNENV") ? 1 : 0;
+  if (sp < 0 || dyn) { const char* e = getenv("MGLD_ATTN_SP"); sp = e ? atoi(e) : 2; }
+  if (!sp || !attn_prescaled(p) || attn_qh(p) != 1) return 0;
+  return (sp >= 2 && (p->Nkv % 128) == 0 && p->Nkv >= 256) ? 2 : 1;
 }
 static int attn_qh(const MgldAttn* p) {
   static int qh = -1;
@@ -1082,8 +1074,7 @@ static int attn_qh(const MgldAttn* p) {
 extern "C" int mgld_attention_kernel_name(const MgldAttn* p, char* buf, int buflen) {
   MGLD_REQUIRE(p && buf && buflen > 0, "attention_kernel_name: null");
   MGLD_REQUIRE(p->head_dim == 64 || p->head_dim == 128, "attention: head_dim must be 64 or 128");
-  if (p->v_rowmajor && attn_sp(p) >= 32 && (p->Nkv % 128) == 0 && p->Nkv >= 256) snprintf(buf, buflen, "flash_attn_sp2_kernel<0>");
-  else if (p->v_rowmajor && (attn_sp(p) & 31)) snprintf(buf, buflen, "flash_attn_sp_kernel<2, %d>", (attn_sp(p) & 31) - 1);
+  if (p->v_rowmajor && attn_sp(p)) snprintf(buf, buflen, attn_sp(p) == 2 ? "flash_attn_sp2_kernel" : "flash_attn_sp_kernel");
   else if (p->v_rowmajor && attn_qh(p) == 2) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 2, false>");
   else if (p->v_rowmajor && attn_prescaled(p)) snprintf(buf, buflen, "flash_attn_kernel<64, true, true, 1, true>");
   else if (p->v_rowmajor) snprintf(buf, buflen, "flash_attn_kernel<%d, true, %s, 1, false>", p->head_dim, attn_takes_dma(p) ? "true" : "false");
@@ -1119,32 +1110,10 @@ extern "C" int mgld_attention(const MgldAttn* p, void* stream) {
       (void)hipFuncSetAttribute((const void*)flash_attn_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
       attr_done2 = true;
     }
-    if (attn_sp(p) >= 32 && (p->Nkv % 128) == 0 && p->Nkv >= 256) {     // flash_attn_sp2_kernel: an even tile count >= 4
-      int lds = 4 * 16384;
-      if (getenv("MGLD_DEBUG_DYNENV") && getenv("MGLD_ATTN_SP_LDS")) lds = atoi(getenv("MGLD_ATTN_SP_LDS"));   // occupancy experiments (tools/)
-      if (lds > 65536) (void)hipFuncSetAttribute((const void*)flash_attn_sp2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL((flash_attn_sp2_kernel<0>), grid, dim3(256), lds, (hipStream_t)stream, *p, order);
-    } else if (const int sp = attn_sp(p) & 31) {
-      int LDS_SP = 3 * 16384;
-      if (getenv("MGLD_DEBUG_DYNENV") && getenv("MGLD_ATTN_SP_LDS")) LDS_SP = atoi(getenv("MGLD_ATTN_SP_LDS"));   // occupancy experiments (tools/)
-#define MGLD_SP_LAUNCH(W, O)                                                                                                             \
-  do {                                                                                                                                   \
-    if (LDS_SP > 65536) (void)hipFuncSetAttribute((const void*)flash_attn_sp_kernel<W, O>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SP); \
-    hipLaunchKernelGGL((flash_attn_sp_kernel<W, O>), grid, dim3(256), LDS_SP, (hipStream_t)stream, *p, order);                          \
-  } while (0)
-      switch (sp) {               // MGLD_ATTN_SP = 1 + OPT
-        case 1: MGLD_SP_LAUNCH(2, 0); break;
-        case 2: MGLD_SP_LAUNCH(2, 1); break;
-        case 4: MGLD_SP_LAUNCH(2, 3); break;
-        case 6: MGLD_SP_LAUNCH(2, 5); break;
-        case 8: MGLD_SP_LAUNCH(2, 7); break;
-        case 10: MGLD_SP_LAUNCH(2, 9); break;
-        case 12: MGLD_SP_LAUNCH(2, 11); break;
-        case 14: MGLD_SP_LAUNCH(2, 13); break;
-        case 16: MGLD_SP_LAUNCH(2, 15); break;
-        default: MGLD_REQUIRE(false, "attention: unknown MGLD_ATTN_SP variant");
-      }
-#undef MGLD_SP_LAUNCH
+    if (attn_sp(p) == 2) {              // an even tile count >= 4: the 64^2 / 32^2 / 16^2 levels
+      hipLaunchKernelGGL(flash_attn_sp2_kernel, grid, dim3(256), 4 * 16384, (hipStream_t)stream, *p, order);
+    } else if (attn_sp(p) == 1) {
+      hipLaunchKernelGGL(flash_attn_sp_kernel, grid, dim3(256), 3 * 16384, (hipStream_t)stream, *p, order);
     } else if (attn_qh(p) == 2) {
       const dim3 grid2(p->Nq / 256, p->heads, p->batch);
       hipLaunchKernelGGL((flash_attn_kernel<64, true, true, 2>), grid2, dim3(256), LDS64, (hipStream_t)stream, *p, order);

@@ -9,7 +9,7 @@ from mgld_vsr_amd import hip
 from tools.attn_sp_check import run, LOG2E
 DEV = "cuda"
 hip.lib()
-variants = sys.argv[1:] or ["0", "2"]
+variants = sys.argv[1:] or ["0", "1", "2"]
 shapes = [("64^2 x16", 16, 5, 4096), ("32^2 x16", 16, 10, 1024), ("16^2 x16", 16, 20, 256), ("64^2 x8", 8, 5, 4096)]
 if os.environ.get("AB_SHAPES"):
     shapes = [s for s in shapes if s[0] in os.environ["AB_SHAPES"].split(",")]
