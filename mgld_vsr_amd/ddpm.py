@@ -231,13 +231,15 @@ class LatentDiffusionVSRTextWT(nn.Module):
         mean = self._gather("posterior_mean_coef1", t, x_t) * x_start + self._gather("posterior_mean_coef2", t, x_t) * x_t
         return mean, self._gather("posterior_variance", t, x_t), self._gather("posterior_log_variance_clipped", t, x_t)
 
-    def compute_flow(self, lrs):
+    def compute_flow(self, lrs, _inside_sampler=False):
         """ddpm.py:3404-3429: lrs [n,t,3,h,w] in [0,1] -> (flows_forward, flows_backward), each [n,t-1,2,h,w].  Both
-        directions go through the flow network (RAFT_SR, mgld_vsr_amd/raft.py) as one batch of frame pairs."""
+        directions go through the flow network (RAFT_SR, mgld_vsr_amd/raft.py) as one batch of frame pairs.
+        _inside_sampler: the call sits inside sample() / p_sample() (the `lr_images` term), where the flow network runs on the sampler's
+        own engine: it must not rewind the shared arena over buffers the sampler already holds (RAFT_SR.forward keep_arena)."""
         from .raft import compute_flow
         if getattr(self.flownet_model, "_engine", None) is None and hasattr(self.flownet_model, "set_engine"):
             self.flownet_model.set_engine(self.engine())
-        return compute_flow(self.flownet_model, lrs)
+        return compute_flow(self.flownet_model, lrs, keep_arena=_inside_sampler)
 
     @torch.no_grad()
     def compute_temporal_condition_v4(self, flows, latents, masks):
@@ -571,7 +573,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 assert T_total % Tn == 0 and lr_images.shape[0] == T_total, "lr_images: one LR frame per latent frame"
                 nclips = T_total // Tn
                 res = hip.resize_bicubic(lr_images.to(dev, torch.float32), (h, w))
-                f_f, f_b = self.compute_flow(res.view(nclips, Tn, res.shape[1], h, w))
+                f_f, f_b = self.compute_flow(res.view(nclips, Tn, res.shape[1], h, w), _inside_sampler=True)
                 zero = torch.zeros(Tn - 1, h, w, device=dev)
                 st["guid_lr"] = [(f_f[i].contiguous(), f_b[i].contiguous(), zero, zero) for i in range(nclips)]
                 if "z" not in st:
@@ -738,7 +740,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
             Tn, ch, h, w = latents.shape
             assert Tn == self.num_frames and lr_images.shape[0] == Tn, "lr_images guidance operates on one clip"
             res = hip.resize_bicubic(lr_images.to(eng.device, torch.float32), (h, w))
-            f_f, f_b = self.compute_flow(res[None])
+            f_f, f_b = self.compute_flow(res[None], _inside_sampler=True)
             zero = torch.zeros(Tn - 1, h, w, device=eng.device)
             coef = torch.zeros(1, 8, device=eng.device)
             coef[0, 4] = logvar.reshape(-1)[0]

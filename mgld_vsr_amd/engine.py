@@ -185,6 +185,14 @@ class Arena:
     def reset(self):
         self.ci, self.off = 0, 0
 
+    def mark(self):
+        """the bump position, for release(): a callee that shares this arena (the flow network inside a sampler call) allocates past what its
+        caller holds and hands the space back on return, instead of rewinding to 0 over the caller's buffers"""
+        return (self.ci, self.off)
+
+    def release(self, mark):
+        self.ci, self.off = mark
+
     def alloc(self, shape, dtype):
         nbytes = int(torch.tensor([], dtype=dtype).element_size())
         for s in shape:

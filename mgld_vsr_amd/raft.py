@@ -195,11 +195,15 @@ class RAFT_SR(nn.Module):
 
     # ---- one batch of (ref, sup) pairs ----
     @torch.no_grad()
-    def forward(self, ref, sup, iters=10, flow_init=None, upsample=True):
-        """ref, sup: [N,3,H,W] in [0,1] (device or host) -> flow ref->sup [N,2,H,W] fp32 on the device."""
+    def forward(self, ref, sup, iters=10, flow_init=None, upsample=True, keep_arena=False):
+        """ref, sup: [N,3,H,W] in [0,1] (device or host) -> flow ref->sup [N,2,H,W] fp32 on the device.
+        keep_arena: called INSIDE a sampler call that shares its engine with this network (the `lr_images` guidance term): allocate past
+        what the caller holds and release on return instead of rewinding the arena over the caller's buffers (the results are torch-owned)."""
         assert ref.shape == sup.shape and flow_init is None and upsample
         eng = self.engine()
-        eng.reset()
+        mark = eng.arena.mark() if keep_arena else None
+        if mark is None:
+            eng.reset()
         dev = eng.device
         ref, sup = ref.to(dev, torch.float32), sup.to(dev, torch.float32)
         N, _, ht, wd = ref.shape
@@ -301,6 +305,8 @@ class RAFT_SR(nn.Module):
         hip.flow_update(coords1, coords0, delta[:, :2], flow)
         up = hip.convex_upsample(flow, mask.v)
         eng.launches += 2
+        if mark is not None:
+            eng.arena.release(mark)
         if pad_ht or pad_wd:                                                                             # unpad (:30-33)
             out = torch.empty(N, 2, ht, wd, dtype=torch.float32, device=dev)
             hip.crop(up, out, pad[2], pad[0])
@@ -308,10 +314,11 @@ class RAFT_SR(nn.Module):
         return up
 
 
-def compute_flow(flownet, lrs, iters=10):
+def compute_flow(flownet, lrs, iters=10, keep_arena=False):
     """ddpm.py:3404-3429 with both directions in ONE batch: lrs [n,t,3,h,w] in [0,1] -> (flows_forward, flows_backward)."""
     n, t, c, h, w = lrs.shape
     a, b = lrs[:, :-1].reshape(-1, c, h, w), lrs[:, 1:].reshape(-1, c, h, w)
-    out = flownet(torch.cat([a, b], 0), torch.cat([b, a], 0), iters=iters)
+    kw = {"keep_arena": True} if keep_arena else {}       # (a stand-in flow network of a test takes the reference's argument list)
+    out = flownet(torch.cat([a, b], 0), torch.cat([b, a], 0), iters=iters, **kw)
     k = a.shape[0]
     return out[k:].view(n, t - 1, 2, h, w), out[:k].view(n, t - 1, 2, h, w)

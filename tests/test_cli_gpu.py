@@ -95,13 +95,15 @@ def test_cli_reproduces_a_run_of_the_reference_script(tmp_path):
         import json
         with open(os.path.join(out, "harness_metrics.json"), "w") as fh:
             json.dump(m, fh, indent=1, sort_keys=True)
-    assert max(m["harness_flow_f"], m["harness_flow_b"]) < 3.4e-3 and m["harness_mask_flips"] < 2e-3, m
+    # (bounds = 1.3 x what the fp32 RAFT path measures, profiles/r06_harness_metrics.json: flows 1.3e-6, no mask pixel flips, x_0 per patch
+    #  2.8-4.7e-3, frames 1.26e-3 — the regression guard of the flow estimator; round 5 still carried the fp16 estimator's bounds here)
+    assert max(m["harness_flow_f"], m["harness_flow_b"]) < 1e-4 and m["harness_mask_flips"] == 0, m
     # (a 2-step schedule multiplies the first step's eps error by sqrt(1/abar_999 - 1) ~ 14 in the x0 prediction: the latents of
     # this run agree to ~1.5e-2, not to the ~1e-3 of the 50-step schedules; the frames — what the script writes — to 2e-3)
-    assert max(m[f"harness_x0_patch{c}"] for c in range(4)) < 2.5e-2, m
+    assert max(m[f"harness_x0_patch{c}"] for c in range(4)) < 6e-3, m
     # uint8 frames: the float images agree to ~1e-3, so a pixel differs (by one level) only where its value sits next to a
     # rounding boundary
-    assert m["harness_hr_mean_abs_lsb"] < 0.15 and m["harness_hr_rel_l2"] < 3.2e-3, m
+    assert m["harness_hr_mean_abs_lsb"] < 0.04 and m["harness_hr_max_abs_lsb"] <= 1 and m["harness_hr_rel_l2"] < 1.7e-3, m
     assert np.abs(hr.reshape(T, -1, 3).astype(np.float64).mean(1) - g["hr_mean"]).max() < 0.5
 
 
@@ -249,9 +251,10 @@ def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
         import json
         with open(os.path.join(out, f"harness_{tag}_metrics.json"), "w") as fh:
             json.dump(m, fh, indent=1, sort_keys=True)
-    assert all(m[f"{tag}_flow_s{k}"] < 3.2e-3 and m[f"{tag}_mask_flips_s{k}"] < 4e-3 and m[f"{tag}_x0_s{k}"] < 2.8e-3 for k in range(2)), m
-    assert m[f"{tag}_hr_mean_abs_lsb"] < 0.06 and m[f"{tag}_hr_rel_l2"] < 2e-3, m
-    assert tag != "wlat" or m["wlat_npy"] < 2.3e-3, m
+    # (1.3 x measured, profiles/r06_harness_old_metrics.json: flows 1.1e-6, no mask flips, x_0 1.18-1.25e-3, frames 1.2e-3)
+    assert all(m[f"{tag}_flow_s{k}"] < 1e-4 and m[f"{tag}_mask_flips_s{k}"] == 0 and m[f"{tag}_x0_s{k}"] < 1.6e-3 for k in range(2)), m
+    assert m[f"{tag}_hr_mean_abs_lsb"] < 0.035 and m[f"{tag}_hr_rel_l2"] < 1.6e-3, m
+    assert tag != "wlat" or m["wlat_npy"] < 1.6e-3, m
 
 
 @pytest.mark.gpu
@@ -361,8 +364,10 @@ def test_bench_json_line_contract(steps):
     assert d["vs_baseline"] is None and d["dtype"] == "f16" and d["data"] == "synthetic" and d["value"] > 0
     assert d["config"]["finite"] is True and d["config"]["reduced_width"] is True and "workload" in d["config"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_pick", "second"):
         assert k in rf, k
+    assert rf["second"] is None or (rf["second"]["kernel"] != rf["kernel"] and 0 < rf["second"]["frac"] < 1)
+    assert d["config"]["pending_segments_assumed_per_gpu"] == d["config"]["segments_in_flight"] * d["config"]["clips_per_pass"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
 
 

@@ -1297,6 +1297,29 @@ def test_hp_split_convolution(hip, n, h, w, cin, cout, stride):
     assert rel_l2(out.v.cpu().double(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("scale,bound", [(1e-2, 4e-6), (1e-3, 2e-5), (1e-4, 2e-4)])
+def test_hp_split_convolution_small_activations(hip, scale, bound):
+    """in the split operand [ah | 16 al | ah / 256] the two correction terms leave fp16's normal range for |a| below ~1e-2
+    (ah / 256 < 6.1e-5) and ~1e-3 (16 al): what the split contraction still delivers for activations that small (every element: the
+    worst case; a post-GroupNorm tensor is O(1) with a minority of small elements).  Measured: 1e-2 -> ~1e-6, 1e-3 -> ~6e-6, 1e-4 -> ~6e-5
+    relative — the corrections degrade gracefully through the subnormals (the MFMA does not flush them), never worse than the plain fp16
+    contraction's 3e-4."""
+    from mgld_vsr_amd.engine import Act, Engine, pack_conv3x3, pack_hp
+    eng = Engine()
+    n, h, w, cin, cout = 2, 32, 32, 128, 128
+    x = rnd(n, cin, h, w, seed=530) * scale
+    wt = rnd(cout, cin, 3, 3, seed=531) / (cin * 9) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    xa = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV)
+    a3 = torch.empty(xa.shape[0], 3 * cin, dtype=torch.half, device=DEV)
+    hip.hp_gn_split(xa, None, 0.0, None, None, False, a3, n, h * w, 1)
+    wp = pack_conv3x3(pack_hp(wt), 3 * cin).half().to(DEV)
+    out = eng.conv3x3(Act(a3, n, h, w), wp, torch.zeros(cout, device=DEV), cout, out_dtype=torch.float32)
+    err = rel_l2(out.v.cpu().double(), ref)
+    print(f"hp split conv, activations ~{scale:g}: rel. L2 {err:.2e}")
+    assert err < bound, err
+
+
 @pytest.mark.parametrize("n,cin,ti", [(320, 320, False), (640, 128, True), (100, 64, True), (160, 96, False)])
 def test_tile_conv3p_kernel_matches_the_host_layout(hip, n, cin, ti):
     """mgld_tile_conv3p == engine.tile_conv3p (the torch statement of MgldIGemm.tap_inner = 2's layout, pinned by tests/test_host_cpu.py) bit for bit,

@@ -2,7 +2,7 @@
 # SEPARATE passes (counter collection only, no trace domains) over one eager segment of the default bench workload.
 # Writes gpurun_out/pmc_traffic.json keyed by the exact kernel instantiation name + the sha256 of the GEMM family's sources
 # (bench.py: GEMM_FAMILY_SOURCES) it was taken on (bench.py uses an entry only when both match the running build);
-# copy it to profiles/r05_pmc_traffic.json.
+# copy it to profiles/r06_pmc_traffic.json.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export MGLD_HP_ENCODER=0      # (the fp32 / split passes of the first-stage encoder launch 2M-block grids: keep the counter hook off them)
@@ -21,7 +21,7 @@ def per_kernel(counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"((?:igemm|conv3p|conv3q|conv3r|ppgemm|pptconv|flash_attn|splitk_reduce|gn_\w+|layernorm)_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
+            m = re.search(r"((?:igemm|conv3p|conv3q|conv3r|ppgemm|pptconv|flash_attn(?:_sp2?)?|splitk_reduce|gn_\w+|layernorm)_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
             if not m:
                 continue
             tot[m.group(1)][0] += 1
