@@ -186,15 +186,23 @@ class AttentionBlock(nn.Module):
             return wqk, bqk, w[:, 2].reshape(C, C), b[:, 2].reshape(C)
         N = x.hw
         if QKV_FUSED:      # the conv1d qkv (per head [q | k | v] rows, openaimodel.py:515-519, 582-594) re-ordered to [q | k | v] x heads: one GEMM
+            # round 6: the softmax scale (QKVAttentionLegacy scales q and k by ch^-1/4 each, :588-590) and log2(e) folded into the q rows of
+            # weight AND bias in fp32, as the transformer's self-attention does: the software-pipelined kernel takes the launch
+            ps = ch == 64
+            f = ch ** -0.5 * LOG2E if ps else 1.0
+
             def fused(w, b):
                 wqk_, bqk_, wv_, bv_ = split(w, b)
+                wqk_, bqk_ = wqk_.clone(), bqk_.clone()
+                wqk_[:C] *= f
+                bqk_[:C] *= f
                 return torch.cat([wqk_, wv_], 0), torch.cat([bqk_, bv_], 0)
-            wqkv, bqkv = eng.weight("qkv", (self.qkv.weight, self.qkv.bias), fused)
+            wqkv, bqkv = eng.weight("qkvps" if ps else "qkv", (self.qkv.weight, self.qkv.bias), fused)
             qkv = eng.linear(x=xn, w=wqkv, bias=bqkv)                 # [rows, 3C]: q | k | v, head-major inside each
             o = eng.act(x.n, x.h, x.w, C)
             hip.attention(qkv.v, qkv.v[:, C:], qkv.v[:, 2 * C:], o.v, batch=x.n, heads=H, Nq=N, Nkv=N, head_dim=ch,
                           q_strides=(N * 3 * C, 3 * C, ch), k_strides=(N * 3 * C, 3 * C, ch), vt_strides=(N * 3 * C, 3 * C, ch),
-                          o_strides=(N * C, C, ch), scale=ch ** -0.5, v_rowmajor=True)
+                          o_strides=(N * C, C, ch), scale=(1.0 / LOG2E) if ps else ch ** -0.5, v_rowmajor=True)
             eng.launches += 1
             wp = eng.weight("c1", (self.proj_out.weight,), pack_conv1x1)
             return eng.linear(o, wp, eng.f32("b", self.proj_out.bias), out=out, resid=x)
