@@ -127,6 +127,13 @@ typedef struct MgldIGemm {
                              (GroupNorm32 on a convolution's output: openaimodel.py:401-405,429-436).                                */
   int32_t r_f32;          /* 1: R is fp32 [M, ldr] (needs out_f32, batch <= 1): the fp32 residual stream of the high-precision first-stage
                              encoder (mgld_hp_*, model.py:124-183 ResnetBlock `x + h`); kernels with an fp16-only epilogue are not picked  */
+  const void* Rlo;        /* NULL, or the LOW PLANE of the residual: fp16 [M, ldr] (same leading dimension / batch stride as R), the residual
+                             the kernel adds is R + 2^-11 * Rlo.  The residual STREAM of the networks (`x + f(x)` handed from block to block:
+                             openaimodel.py:359,482, attention.py:431-435,546, model.py:183) is kept as a pair of fp16 planes — hi = fp16(x),
+                             lo = fp16((x - hi) * 2^11) — so its rounding error is 2^-22 instead of 2^-11 while every kernel that takes the tensor
+                             as a contraction operand keeps reading the hi plane as it is (tests/analysis/resid_sim.py)    */
+  void* Clo;              /* NULL, or where the kernel also stores the low plane of its fp16 output: fp16 [M, ldc], Clo = fp16((x - fp16(x)) * 2^11)
+                             of the fp32 value x it rounds into C.  Not with out_f32 / GEGLU / batch > 1.                                       */
 } MgldIGemm;
 
 /* tiles per frame of the statistics output (see gn_part), or 0 when the kernel picked for this problem does not produce it */
@@ -199,6 +206,25 @@ int mgld_gn_fused(const void* x, int ldx, float eps, const float* gamma, const f
 int mgld_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
                    int rows, int C, float eps, void* stream);
 
+/* ---- the residual stream as two fp16 planes (see MgldIGemm.Rlo / Clo) ------------------------------------------------------------
+ * The normalisations that READ the stream (`normalization(channels)` / `Normalize` in front of a block: openaimodel.py:271,401, attention.py:
+ * 427-429,536, model.py:134) and the one kernel besides the contractions that WRITES it (ResBlockDual's `skip_connection(x) + spade(h)`,
+ * openaimodel.py:478-482) in the two-plane form: value = hi + 2^-11 * lo, low planes share the leading dimension of their hi plane.
+ * mgld_gn_apply_lo / mgld_layernorm_lo: x is (x, xlo); statistics `st` are those of the hi plane (the zero-mean 2^-12 residual moves the
+ * moments of a group by ~1e-7).  mgld_spade_apply_lo: skip is (skip, skiplo), the result goes to (y, ylo); h is an ordinary fp16 tensor.
+ * mgld_gn_fused_lo: plain form (gb == NULL): lo_in = low plane of x, lo_out = NULL; SPADE form: lo_in = low plane of skip, lo_out = of y. */
+int mgld_gn_apply_lo(const void* x, const void* xlo, int ldx, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                     void* y, int ldy, int frames, int rows_per_frame, int C, int groups, int silu, void* stream);
+int mgld_spade_apply_lo(const void* h, int ldh, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                        const void* gb, int ldgb, const void* skip, const void* skiplo, int ldskip, void* y, void* ylo, int ldy,
+                        int frames, int rows_per_frame, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
+                        double* stats_out, void* stream);
+int mgld_gn_fused_lo(const void* x, int ldx, float eps, const float* gamma, const float* beta, const void* gb, int ldgb,
+                     const void* skip, int ldskip, void* y, int ldy, int frames, int rows_per_frame, int C, int groups, int silu,
+                     const int32_t* gb_step_idx, int64_t gb_step_stride, const void* lo_in, void* lo_out, void* stream);
+int mgld_layernorm_lo(const void* x, const void* xlo, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                      int rows, int C, float eps, void* stream);
+
 /* ---- K5/K6/K7/K9: attention ----------------------------------------------------------------------------------
  * Flash attention, fp16 q/k/v, fp32 online softmax, exact softmax(q k^T * scale) v.
  * Replaces xformers.ops.memory_efficient_attention (attention.py:298,371; openaimodel.py:582).
@@ -257,6 +283,9 @@ int mgld_tile_conv3p(const void* wp, int N, int Cin, int tap_inner, void* out, v
 int mgld_copy2d(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols, void* stream);
 /* y = a*x + b*y (fp16, strided) */
 int mgld_axpby(const void* x, int ldx, void* y, int ldy, int64_t rows, int cols, float a, float b, void* stream);
+/* the same on residual-stream tensors kept as two fp16 planes (MgldIGemm.Rlo): (y, ylo) <- a (x, xlo) + b (y, ylo), value = hi + 2^-11 lo; xlo may be
+ * NULL.  The fusion layers' `dec_feat + w * enc_feat` (model.py:1367). */
+int mgld_axpby_lo(const void* x, const void* xlo, int ldx, void* y, void* ylo, int ldy, int64_t rows, int cols, float a, float b, void* stream);
 
 /* ---- B2/B3/F1/K10/K15: one reverse-diffusion step + motion guidance (ddpm.py:340-353, 3538-3574, 4325-4380) ---
  * coef table row (8 floats per schedule index i): {sqrt_recip_ac, sqrt_recipm1_ac, post_mean_coef1,

@@ -59,4 +59,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// the residual stream as a pair of fp16 planes (MgldIGemm.Rlo / Clo, mgld_*_lo): x = hi + 2^-11 lo, hi = fp16(x), lo = fp16((x - hi) 2^11)
+#define MGLD_LO_SCALE 4.8828125e-4f
+#define MGLD_LO_INV 2048.f
+__device__ __forceinline__ f16 lo_plane(const float x, const f16 hi) { return (f16)((x - (float)hi) * MGLD_LO_INV); }
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

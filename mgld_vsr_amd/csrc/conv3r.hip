@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
     return;
   }
   PPEpi e;
-  e.bias = p.bias; e.rowvec = p.rowvec; e.R = (const f16*)p.R; e.C = (f16*)p.C;
+  e.bias = p.bias; e.rowvec = p.rowvec; e.R = (const f16*)p.R; e.C = (f16*)p.C; e.Rlo = (const f16*)p.Rlo; e.Clo = (f16*)p.Clo;
   e.rows_per_frame = p.rows_per_frame; e.ld_rowvec = p.ld_rowvec; e.ldr = p.ldr; e.ldc = p.ldc; e.act = p.act; e.alpha = p.alpha; e.beta = p.beta;
   e.noswap = (order & 0x100) != 0;
   const int Hout = p.Hout, Wout = p.Wout;

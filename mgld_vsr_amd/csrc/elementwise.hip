@@ -125,6 +125,30 @@ __global__ void axpby_kernel(const f16* __restrict__ x, int ldx, f16* __restrict
   }
 }
 
+// the same on residual-stream tensors kept as two fp16 planes (common.h: value = hi + 2^-11 lo): y <- a x + b y with x = (x, xlo) — xlo may be
+// null — and y = (y, ylo); the fusion layers' `dec_feat + w * enc_feat` (model.py:1367)
+__global__ void axpby_lo_kernel(const f16* __restrict__ x, const f16* __restrict__ xlo, int ldx, f16* __restrict__ y, f16* __restrict__ ylo, int ldy,
+                                int64_t rows, int nv, float a, float b) {
+  const int64_t total = rows * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / nv;
+    const int v = (int)(idx - r * nv);
+    const f16x8 xv = *(const f16x8*)(x + r * ldx + v * 8);
+    f16x8 xl = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (xlo) xl = *(const f16x8*)(xlo + r * ldx + v * 8);
+    f16x8 yv = *(const f16x8*)(y + r * ldy + v * 8);
+    f16x8 yl = *(const f16x8*)(ylo + r * ldy + v * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = a * ((float)xv[j] + MGLD_LO_SCALE * (float)xl[j]) + b * ((float)yv[j] + MGLD_LO_SCALE * (float)yl[j]);
+      yv[j] = (f16)t;
+      yl[j] = lo_plane(t, yv[j]);
+    }
+    *(f16x8*)(y + r * ldy + v * 8) = yv;
+    *(f16x8*)(ylo + r * ldy + v * 8) = yl;
+  }
+}
+
 // ---- temporal attention (attention.py:124-143): tokens (pixel) x T frames, tiny ------------------------------
 // one wave per (pixel, head); lanes span the head dim.  q,k,v: [T*HW, ld] fp16 (frame-major), out same layout.
 template <int DH>
@@ -686,6 +710,15 @@ extern "C" int mgld_axpby(const void* x, int ldx, void* y, int ldy, int64_t rows
   hipLaunchKernelGGL(axpby_kernel, dim3(egrid(rows * (cols >> 3))), dim3(256), 0, S_(stream), (const f16*)x, ldx, (f16*)y, ldy,
                      rows, cols >> 3, a, b);
   return mgld_check_launch("axpby");
+}
+
+extern "C" int mgld_axpby_lo(const void* x, const void* xlo, int ldx, void* y, void* ylo, int ldy, int64_t rows, int cols, float a, float b,
+                             void* stream) {
+  MGLD_REQUIRE(x && y && ylo && rows > 0 && cols > 0, "axpby_lo: bad args");
+  MGLD_REQUIRE((cols & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0, "axpby_lo: cols/ld % 8");
+  hipLaunchKernelGGL(axpby_lo_kernel, dim3(egrid(rows * (cols >> 3))), dim3(256), 0, S_(stream), (const f16*)x, (const f16*)xlo, ldx, (f16*)y,
+                     (f16*)ylo, ldy, rows, cols >> 3, a, b);
+  return mgld_check_launch("axpby_lo");
 }
 
 extern "C" int mgld_temporal_attention(const void* q, const void* k, const void* v, int ld, void* o, int ldo, int T, int HW,

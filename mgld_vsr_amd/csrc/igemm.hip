@@ -502,9 +502,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MgldIGemm p, c
       if (rv) x += rv[n];
       x = apply_act(x, p.act) * p.alpha;
       if (p.r_f32 && p.R) x += p.beta * ((const float*)p.R)[(int64_t)m * p.ldr + n];
-      else if (R) x += p.beta * (float)R[(int64_t)m * p.ldr + n];
+      else if (R) {
+        x += p.beta * (float)R[(int64_t)m * p.ldr + n];
+        if (p.Rlo) x += p.beta * MGLD_LO_SCALE * (float)((const f16*)p.Rlo)[(int64_t)m * p.ldr + n];
+      }
       if (p.out_f32) ((float*)p.C)[(int64_t)m * p.ldc + n] = x;
-      else ((f16*)p.C)[(int64_t)m * p.ldc + n] = (f16)x;
+      else {
+        const f16 hi = (f16)x;
+        ((f16*)p.C)[(int64_t)m * p.ldc + n] = hi;
+        if (p.Clo) ((f16*)p.Clo)[(int64_t)m * p.ldc + n] = lo_plane(x, hi);
+      }
     }
   }
 }
@@ -819,6 +826,8 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   if (p->r_f32) MGLD_REQUIRE(p->R && p->out_f32 && p->batch <= 1 && p->act != MGLD_ACT_GEGLU && ((((uintptr_t)p->R) & 3) == 0),
                              "igemm: an fp32 residual (r_f32) goes with an fp32 output, batch 1");
   if (p->act == MGLD_ACT_GEGLU) MGLD_REQUIRE((p->N & 63) == 0, "igemm: GEGLU needs N % 64 == 0");
+  if (p->Rlo) MGLD_REQUIRE(p->R && !p->r_f32 && p->batch <= 1 && ((((uintptr_t)p->Rlo) & 15) == 0), "igemm: Rlo goes with an fp16 residual R (same ldr), batch 1, 16-byte aligned");
+  if (p->Clo) MGLD_REQUIRE(!p->out_f32 && p->batch <= 1 && p->act != MGLD_ACT_GEGLU && ((((uintptr_t)p->Clo) & 15) == 0), "igemm: Clo goes with an fp16 output (same ldc), batch 1, no GEGLU, 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   int cfg, splits, kchunk;
   if (p->gn_part) MGLD_REQUIRE(mgld_igemm_gn_chunks(p) > 0 && ((((uintptr_t)p->gn_part) & 3) == 0), "igemm: gn_part set, but the kernel picked for this problem does not write statistics (mgld_igemm_gn_chunks)");

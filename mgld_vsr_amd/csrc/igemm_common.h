@@ -232,6 +232,12 @@ __device__ __forceinline__ void epi_rows(const MgldIGemm& p, const RowMap rmap, 
         const f16* rp = R + (int64_t)m * p.ldr + n;
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += p.beta * (float)rp[j];
+        if (p.Rlo) {                    // low plane of the residual stream (MgldIGemm.Rlo)
+          const f16* rl = (const f16*)p.Rlo + (R - (const f16*)p.R) + (int64_t)m * p.ldr + n;
+          const float bl = p.beta * MGLD_LO_SCALE;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j] += bl * (float)rl[j];
+        }
       } else if (p.r_f32 && p.R) {      // fp32 residual stream (MgldIGemm.r_f32: the high-precision VAE encoder)
         const float* rp = (const float*)p.R + (int64_t)m * p.ldr + n;
 #pragma unroll
@@ -253,6 +259,11 @@ __device__ __forceinline__ void epi_rows(const MgldIGemm& p, const RowMap rmap, 
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j];
+        }
+        if (p.Clo) {                    // low plane of the output (MgldIGemm.Clo)
+          f16* cl = (f16*)p.Clo + cbase + (int64_t)m * ldo + n;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < Nout) cl[j] = lo_plane(v[j], (f16)v[j]);
         }
       }
     }
@@ -294,7 +305,7 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
   int kind = EPI_GENERIC;
   if (splitk) kind = EPI_SLAB;
   else if (geglu) kind = (alpha == 1.f && !of32) ? EPI_GEGLU : EPI_GENERIC;
-  else if (!of32 && !p.bias_m && alpha == 1.f && (act == MGLD_ACT_NONE || act == MGLD_ACT_SILU)) kind = act == MGLD_ACT_SILU ? EPI_PLAIN_SILU : EPI_PLAIN_NONE;
+  else if (!of32 && !p.bias_m && !p.Rlo && !p.Clo && alpha == 1.f && (act == MGLD_ACT_NONE || act == MGLD_ACT_SILU)) kind = act == MGLD_ACT_SILU ? EPI_PLAIN_SILU : EPI_PLAIN_NONE;
   // (column chunks unrolled by hand through compile-time indices: a runtime `c` would index acc[] dynamically = scratch memory)
   auto do_chunk = [&](auto CI) {
   constexpr int c = decltype(CI)::value;

@@ -2,6 +2,7 @@
 // HBM-bound kernels (SURVEY.md §2.2 K2,K3): 16-byte vector loads along channels, fp32 partial sums per channel,
 // fp64 combine, statistics kept in fp32 exactly as the reference does (diffusionmodules/util.py:214-216).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -144,14 +145,18 @@ __device__ __forceinline__ void gn_group_stats_pc(const float* __restrict__ part
 // STATS: the block also reduces ITS OUTPUT rows (the values it stores, before their rounding to fp16) to per-group (sum, sumsq) and writes them in
 // gn_partial_kernel's format with chunks = gridDim.x: the GroupNorm that reads y next (SPADE output -> the transformer's norm)
 // needs no statistics launch of its own.
-template <bool SPADE, bool STATS>
+// LO: the residual stream's low plane (common.h: value = hi + 2^-11 lo).  Plain apply: `lo_in` is the low plane of x (same ldx) and the
+// normalisation sees hi + 2^-11 lo.  SPADE: `lo_in` is the low plane of the skip tensor (same ldskip), `lo_out` receives the low plane of y
+// (same ldy): the block's output `skip + spade(h)` is the next value of the stream.
+template <bool SPADE, bool STATS, bool LO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void gn_apply_kernel(const f16* __restrict__ x, int ldx, const void* __restrict__ sums, int kind,
                                                        int chunks, float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const f16* __restrict__ gb, int ldgb,
                                                        const f16* __restrict__ skip, int ldskip, f16* __restrict__ y, int ldy,
                                                        int rows_per_frame, int C, int groups, int silu, int Cb,
                                                        const int* __restrict__ step_idx, int64_t gb_step_stride,
-                                                       double* __restrict__ gout) {
+                                                       double* __restrict__ gout, const f16* __restrict__ lo_in = nullptr,
+                                                       f16* __restrict__ lo_out = nullptr) {
   // grid (row chunks, frames).  A thread owns ONE 8-channel vector column for all its rows, so the per-channel scale /
   // shift (rstd*gamma, beta - mean*rstd*gamma) are computed once into registers and the row loop is load-fma-store.
   __shared__ float st[GN_MAX_GROUPS][2];
@@ -187,9 +192,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       sa[j] = st[g][1] * gamma[c];
       sb[j] = beta[c] - st[g][0] * sa[j];
     }
-    constexpr int U = 4;  // rows in flight per thread
+    constexpr int U = (SPADE && LO) ? 2 : 4;  // rows in flight per thread (five 16-byte loads per row with the low planes: two rows fill the register budget)
     for (int r = r0 + rr; r < r1; r += rpi * U) {
-      f16x8 d[U], gm[U], bt[U], sk[U];
+      f16x8 d[U], gm[U], bt[U], sk[U], dl[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t row = fbase + r + u * rpi;
@@ -199,6 +204,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             gm[u] = *(const f16x8*)(gb + row * ldgb + c0);
             bt[u] = *(const f16x8*)(gb + row * ldgb + C + c0);
             sk[u] = *(const f16x8*)(skip + row * ldskip + c0);
+            if (LO) dl[u] = *(const f16x8*)(lo_in + row * ldskip + c0);
+          } else if (LO) {
+            dl[u] = *(const f16x8*)(lo_in + row * ldx + c0);
           }
         }
       }
@@ -206,21 +214,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       for (int u = 0; u < U; ++u) {
         if (r + u * rpi < r1) {
           const int64_t row = fbase + r + u * rpi;
-          f16x8 o;
+          f16x8 o, ol;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float f = (float)d[u][j] * sa[j] + sb[j];
+            float xin = (float)d[u][j];
+            if (LO && !SPADE) xin += MGLD_LO_SCALE * (float)dl[u][j];
+            float f = xin * sa[j] + sb[j];
             if (SPADE) {
-              f = f * (1.f + (float)gm[u][j]) + (float)bt[u][j] + (float)sk[u][j];
+              float skv = (float)sk[u][j];
+              if (LO) skv += MGLD_LO_SCALE * (float)dl[u][j];
+              f = f * (1.f + (float)gm[u][j]) + (float)bt[u][j] + skv;
             } else if (silu == 1) {
               f = silu_f(f);
             } else if (silu == 2) {
               f = fmaxf(f, 0.f);
             }
             o[j] = (f16)f;
+            if (LO && SPADE) ol[j] = lo_plane(f, o[j]);
             if (STATS) { os[j] += f; oq[j] += f * f; }       // (before the fp16 rounding: see pp_epilogue_stats)
           }
           *(f16x8*)(y + row * ldy + c0) = o;
+          if (LO && SPADE) *(f16x8*)(lo_out + row * ldy + c0) = ol;
         }
       }
     }
@@ -258,12 +272,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // per group in fp64 exactly like gn_partial_kernel / gn_group_stats, and normalised from the registers.  The 16x16 / 8x8 levels of
 // the UNet (and the struct-cond encoder's) are launch-bound: this halves their GroupNorm launches and reads the tensor once.
 constexpr int GNF_R = 16;
-template <bool SPADE>
+template <bool SPADE, bool LO = false>
 __global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x, int ldx, float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const f16* __restrict__ gb, int ldgb,
                                                        const f16* __restrict__ skip, int ldskip, f16* __restrict__ y, int ldy, int rows,
                                                        int C, int groups, int silu, int Cb, const int* __restrict__ step_idx,
-                                                       int64_t gb_step_stride) {
+                                                       int64_t gb_step_stride, const f16* __restrict__ lo_in = nullptr,
+                                                       f16* __restrict__ lo_out = nullptr) {
   __shared__ float sred[256 * 8 * 2];          // [rpi][Cb][2] : rpi * Cb = 256/NV * NV*8 <= 2048 channels-slots
   __shared__ float st[GN_MAX_GROUPS][2];       // (mean, rstd) of this window's groups
   if (SPADE && step_idx) gb += (int64_t)step_idx[0] * gb_step_stride;
@@ -338,42 +353,62 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x
     const int r = rr + k * rpi;
     if (r < rows) {
       const int64_t row = fbase + r;
-      f16x8 gm, bt, sk;
+      f16x8 gm, bt, sk, dl;
       if (SPADE) {
         gm = *(const f16x8*)(gb + row * ldgb + c0);
         bt = *(const f16x8*)(gb + row * ldgb + C + c0);
         sk = *(const f16x8*)(skip + row * ldskip + c0);
+        if (LO) dl = *(const f16x8*)(lo_in + row * ldskip + c0);
+      } else if (LO) {
+        dl = *(const f16x8*)(lo_in + row * ldx + c0);     // (the statistics above are those of the hi plane: the zero-mean 2^-12 residual moves them by ~1e-7)
       }
-      f16x8 o;
+      f16x8 o, ol;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float f = (float)d[k][j] * sa[j] + sb[j];
-        if (SPADE) f = f * (1.f + (float)gm[j]) + (float)bt[j] + (float)sk[j];
-        else if (silu == 1) f = silu_f(f);
+        float xin = (float)d[k][j];
+        if (LO && !SPADE) xin += MGLD_LO_SCALE * (float)dl[j];
+        float f = xin * sa[j] + sb[j];
+        if (SPADE) {
+          float skv = (float)sk[j];
+          if (LO) skv += MGLD_LO_SCALE * (float)dl[j];
+          f = f * (1.f + (float)gm[j]) + (float)bt[j] + skv;
+        } else if (silu == 1) f = silu_f(f);
         else if (silu == 2) f = fmaxf(f, 0.f);
         o[j] = (f16)f;
+        if (LO && SPADE) ol[j] = lo_plane(f, o[j]);
       }
       *(f16x8*)(y + row * ldy + c0) = o;
+      if (LO && SPADE) *(f16x8*)(lo_out + row * ldy + c0) = ol;
     }
   }
 }
 
 // ---- LayerNorm: one wave per token row ---------------------------------------------------------------------
-template <int MAXV>
+// LO: x is the residual stream, `xlo` its low plane (same ldx): the row is hi + 2^-11 lo, kept in fp32 registers
+template <int MAXV, bool LO = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, f16* __restrict__ y, int ldy,
-                                                        int rows, int C, float eps) {
+                                                        int rows, int C, float eps, const f16* __restrict__ xlo = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int NV = C >> 3;
-  f16x8 d[MAXV];
+  typedef typename std::conditional<LO, float, f16>::type elem_t;
+  elem_t d[MAXV][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = lane + i * 64;
     if (v < NV) {
-      d[i] = *(const f16x8*)(x + (int64_t)row * ldx + v * 8);
+      const f16x8 h = *(const f16x8*)(x + (int64_t)row * ldx + v * 8);
+      if constexpr (LO) {
+        const f16x8 l = *(const f16x8*)(xlo + (int64_t)row * ldx + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[i][j] = (float)h[j] + MGLD_LO_SCALE * (float)l[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[i][j] = h[j];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)d[i][j];
     }
@@ -504,9 +539,10 @@ extern "C" int mgld_gn_apply_chunks(int frames, int rows_per_frame, int C, int g
   return (int)apply_grid(frames, rows_per_frame, C, groups, &Cb).x;
 }
 
-extern "C" int mgld_gn_apply2(const void* x, int ldx, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
-                              void* y, int ldy, int frames, int rows, int C, int groups, int silu, double* stats_out, void* stream) {
+static int gn_apply_impl(const void* x, const void* xlo, int ldx, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                         void* y, int ldy, int frames, int rows, int C, int groups, int silu, double* stats_out, void* stream) {
   MGLD_REQUIRE(x && gamma && beta && y, "gn_apply: null pointer");
+  MGLD_REQUIRE(!xlo || (!stats_out && (((uintptr_t)xlo) & 15) == 0), "gn_apply: the low-plane form writes no statistics; 16-byte aligned");
   MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS,
                "gn_apply: alignment");
   if (int rc = check_stats_in(st, rows, C)) return rc;
@@ -514,7 +550,11 @@ extern "C" int mgld_gn_apply2(const void* x, int ldx, const MgldGnStats* st, flo
   const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
   const size_t shm = apply_lds(st, C, Cb, stats_out != nullptr);
   MGLD_REQUIRE(shm <= 48 * 1024, "gn_apply: LDS budget of the statistics tables");
-  if (stats_out) {
+  if (xlo) {
+    hipLaunchKernelGGL((gn_apply_kernel<false, false, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)x, ldx, st->sums, st->kind,
+                       st->chunks, eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb, nullptr, (int64_t)0,
+                       nullptr, (const f16*)xlo, nullptr);
+  } else if (stats_out) {
     hipLaunchKernelGGL((gn_apply_kernel<false, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)x, ldx, st->sums, st->kind,
                        st->chunks, eps, gamma, beta, nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb, nullptr, (int64_t)0,
                        stats_out);
@@ -526,16 +566,28 @@ extern "C" int mgld_gn_apply2(const void* x, int ldx, const MgldGnStats* st, flo
   return mgld_check_launch("gn_apply");
 }
 
+extern "C" int mgld_gn_apply2(const void* x, int ldx, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                              void* y, int ldy, int frames, int rows, int C, int groups, int silu, double* stats_out, void* stream) {
+  return gn_apply_impl(x, nullptr, ldx, st, eps, gamma, beta, y, ldy, frames, rows, C, groups, silu, stats_out, stream);
+}
+
+extern "C" int mgld_gn_apply_lo(const void* x, const void* xlo, int ldx, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                                void* y, int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
+  MGLD_REQUIRE(xlo, "gn_apply_lo: null low plane");
+  return gn_apply_impl(x, xlo, ldx, st, eps, gamma, beta, y, ldy, frames, rows, C, groups, silu, nullptr, stream);
+}
+
 extern "C" int mgld_gn_apply(const void* x, int ldx, const double* gsums, float eps, const float* gamma, const float* beta,
                              void* y, int ldy, int frames, int rows, int C, int groups, int silu, void* stream) {
   const MgldGnStats st = {gsums, MGLD_GN_GROUP_SUMS, mgld_gn_chunks(rows)};
   return mgld_gn_apply2(x, ldx, &st, eps, gamma, beta, y, ldy, frames, rows, C, groups, silu, nullptr, stream);
 }
 
-extern "C" int mgld_spade_apply2(const void* h, int ldh, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
-                                 const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C,
-                                 int groups, const int32_t* gb_step_idx, int64_t gb_step_stride, double* stats_out, void* stream) {
+static int spade_apply_impl(const void* h, int ldh, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                            const void* gb, int ldgb, const void* skip, const void* skiplo, int ldskip, void* y, void* ylo, int ldy, int frames,
+                            int rows, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride, double* stats_out, void* stream) {
   MGLD_REQUIRE(h && gamma && beta && gb && skip && y, "spade_apply: null pointer");
+  MGLD_REQUIRE((!skiplo) == (!ylo) && ((((uintptr_t)skiplo) | ((uintptr_t)ylo)) & 15) == 0, "spade_apply: low planes of skip and y come together, 16-byte aligned");
   MGLD_REQUIRE((C & 7) == 0 && (ldh & 7) == 0 && (ldy & 7) == 0 && (ldgb & 7) == 0 && (ldskip & 7) == 0 && C % groups == 0 &&
                    groups <= GN_MAX_GROUPS,
                "spade_apply: alignment");
@@ -544,7 +596,15 @@ extern "C" int mgld_spade_apply2(const void* h, int ldh, const MgldGnStats* st, 
   const dim3 grid = apply_grid(frames, rows, C, groups, &Cb);
   const size_t shm = apply_lds(st, C, Cb, stats_out != nullptr);
   MGLD_REQUIRE(shm <= 48 * 1024, "spade_apply: LDS budget of the statistics tables");
-  if (stats_out) {
+  if (ylo && stats_out) {
+    hipLaunchKernelGGL((gn_apply_kernel<true, true, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)h, ldh, st->sums, st->kind,
+                       st->chunks, eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb,
+                       gb_step_idx, gb_step_stride, stats_out, (const f16*)skiplo, (f16*)ylo);
+  } else if (ylo) {
+    hipLaunchKernelGGL((gn_apply_kernel<true, false, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)h, ldh, st->sums, st->kind,
+                       st->chunks, eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb,
+                       gb_step_idx, gb_step_stride, nullptr, (const f16*)skiplo, (f16*)ylo);
+  } else if (stats_out) {
     hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, dim3(256), shm, (hipStream_t)stream, (const f16*)h, ldh, st->sums, st->kind,
                        st->chunks, eps, gamma, beta, (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb,
                        gb_step_idx, gb_step_stride, stats_out);
@@ -554,6 +614,22 @@ extern "C" int mgld_spade_apply2(const void* h, int ldh, const MgldGnStats* st, 
                        gb_step_idx, gb_step_stride, nullptr);
   }
   return mgld_check_launch("spade_apply");
+}
+
+extern "C" int mgld_spade_apply2(const void* h, int ldh, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                                 const void* gb, int ldgb, const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C,
+                                 int groups, const int32_t* gb_step_idx, int64_t gb_step_stride, double* stats_out, void* stream) {
+  return spade_apply_impl(h, ldh, st, eps, gamma, beta, gb, ldgb, skip, nullptr, ldskip, y, nullptr, ldy, frames, rows, C, groups, gb_step_idx,
+                          gb_step_stride, stats_out, stream);
+}
+
+extern "C" int mgld_spade_apply_lo(const void* h, int ldh, const MgldGnStats* st, float eps, const float* gamma, const float* beta,
+                                   const void* gb, int ldgb, const void* skip, const void* skiplo, int ldskip, void* y, void* ylo, int ldy,
+                                   int frames, int rows, int C, int groups, const int32_t* gb_step_idx, int64_t gb_step_stride,
+                                   double* stats_out, void* stream) {
+  MGLD_REQUIRE(skiplo && ylo, "spade_apply_lo: null low plane");
+  return spade_apply_impl(h, ldh, st, eps, gamma, beta, gb, ldgb, skip, skiplo, ldskip, y, ylo, ldy, frames, rows, C, groups, gb_step_idx,
+                          gb_step_stride, stats_out, stream);
 }
 
 extern "C" int mgld_spade_apply(const void* h, int ldh, const double* gsums, float eps, const float* gamma,
@@ -579,23 +655,67 @@ static int fused_window(int rows, int C, int groups) {
 
 extern "C" int mgld_gn_fused_applies(int rows_per_frame, int C, int groups) { return fused_window(rows_per_frame, C, groups) > 0; }
 
-extern "C" int mgld_gn_fused(const void* x, int ldx, float eps, const float* gamma, const float* beta, const void* gb, int ldgb,
-                             const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C, int groups, int silu,
-                             const int32_t* gb_step_idx, int64_t gb_step_stride, void* stream) {
+static int gn_fused_impl(const void* x, int ldx, float eps, const float* gamma, const float* beta, const void* gb, int ldgb,
+                         const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C, int groups, int silu,
+                         const int32_t* gb_step_idx, int64_t gb_step_stride, const void* lo_in, void* lo_out, void* stream) {
   MGLD_REQUIRE(x && gamma && beta && y, "gn_fused: null pointer");
+  MGLD_REQUIRE(((((uintptr_t)lo_in) | ((uintptr_t)lo_out)) & 15) == 0 && (gb ? (!lo_in) == (!lo_out) : !lo_out),
+               "gn_fused: low planes (SPADE: skip's and y's together; plain: x's only), 16-byte aligned");
   MGLD_REQUIRE((ldx & 7) == 0 && (ldy & 7) == 0 && groups <= GN_MAX_GROUPS && frames > 0, "gn_fused: alignment");
   const int Cb = fused_window(rows, C, groups);
   MGLD_REQUIRE(Cb > 0, "gn_fused: shape not covered (mgld_gn_fused_applies)");
   const dim3 grid(C / Cb, frames);
   if (gb) {
     MGLD_REQUIRE(skip && (ldgb & 7) == 0 && (ldskip & 7) == 0, "gn_fused: SPADE operands");
-    hipLaunchKernelGGL((gn_fused_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, eps, gamma, beta,
-                       (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb, gb_step_idx, gb_step_stride);
+    if (lo_in)
+      hipLaunchKernelGGL((gn_fused_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, eps, gamma, beta,
+                         (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb, gb_step_idx, gb_step_stride,
+                         (const f16*)lo_in, (f16*)lo_out);
+    else
+      hipLaunchKernelGGL((gn_fused_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, eps, gamma, beta,
+                         (const f16*)gb, ldgb, (const f16*)skip, ldskip, (f16*)y, ldy, rows, C, groups, 0, Cb, gb_step_idx, gb_step_stride);
+  } else if (lo_in) {
+    hipLaunchKernelGGL((gn_fused_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, eps, gamma, beta,
+                       nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb, nullptr, (int64_t)0, (const f16*)lo_in, nullptr);
   } else {
     hipLaunchKernelGGL((gn_fused_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, eps, gamma, beta,
                        nullptr, 0, nullptr, 0, (f16*)y, ldy, rows, C, groups, silu, Cb, nullptr, (int64_t)0);
   }
   return mgld_check_launch("gn_fused");
+}
+
+extern "C" int mgld_gn_fused(const void* x, int ldx, float eps, const float* gamma, const float* beta, const void* gb, int ldgb,
+                             const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C, int groups, int silu,
+                             const int32_t* gb_step_idx, int64_t gb_step_stride, void* stream) {
+  return gn_fused_impl(x, ldx, eps, gamma, beta, gb, ldgb, skip, ldskip, y, ldy, frames, rows, C, groups, silu, gb_step_idx, gb_step_stride,
+                       nullptr, nullptr, stream);
+}
+
+extern "C" int mgld_gn_fused_lo(const void* x, int ldx, float eps, const float* gamma, const float* beta, const void* gb, int ldgb,
+                                const void* skip, int ldskip, void* y, int ldy, int frames, int rows, int C, int groups, int silu,
+                                const int32_t* gb_step_idx, int64_t gb_step_stride, const void* lo_in, void* lo_out, void* stream) {
+  MGLD_REQUIRE(lo_in, "gn_fused_lo: null low plane");
+  return gn_fused_impl(x, ldx, eps, gamma, beta, gb, ldgb, skip, ldskip, y, ldy, frames, rows, C, groups, silu, gb_step_idx, gb_step_stride,
+                       lo_in, lo_out, stream);
+}
+
+template <int MAXV>
+static void launch_layernorm_lo(dim3 grid, hipStream_t s, const void* x, const void* xlo, int ldx, const float* gamma, const float* beta, void* y,
+                                int ldy, int rows, int C, float eps) {
+  hipLaunchKernelGGL((layernorm_kernel<MAXV, true>), grid, dim3(256), 0, s, (const f16*)x, ldx, gamma, beta, (f16*)y, ldy, rows, C, eps,
+                     (const f16*)xlo);
+}
+
+extern "C" int mgld_layernorm_lo(const void* x, const void* xlo, int ldx, const float* gamma, const float* beta, void* y, int ldy, int rows,
+                                 int C, float eps, void* stream) {
+  MGLD_REQUIRE(x && xlo && gamma && beta && y, "layernorm_lo: null pointer");
+  MGLD_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && C <= 2048 && rows > 0 && (((uintptr_t)xlo) & 15) == 0, "layernorm_lo: shape");
+  const int NV = C >> 3;
+  dim3 grid(cdiv(rows, 4));
+  if (NV <= 64) launch_layernorm_lo<1>(grid, (hipStream_t)stream, x, xlo, ldx, gamma, beta, y, ldy, rows, C, eps);
+  else if (NV <= 128) launch_layernorm_lo<2>(grid, (hipStream_t)stream, x, xlo, ldx, gamma, beta, y, ldy, rows, C, eps);
+  else launch_layernorm_lo<4>(grid, (hipStream_t)stream, x, xlo, ldx, gamma, beta, y, ldy, rows, C, eps);
+  return mgld_check_launch("layernorm_lo");
 }
 
 extern "C" int mgld_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int rows,

@@ -54,6 +54,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // EPI: 0 = bias / rowvec / none or SiLU / alpha / residual; 1 = GEGLU (the wave's 64 weight rows are [32 value | 32 gate] of 32 outputs).
 struct PPEpi {
   const float* bias; const float* rowvec; const f16* R; f16* C;
+  const f16* Rlo; f16* Clo;    // low planes of the residual / the output (MgldIGemm.Rlo / Clo), or null
   int rows_per_frame, ld_rowvec, ldr, ldc, act; float alpha, beta;
   bool noswap;     // A/B and bring-up: every fragment by 8-byte stores (no v_permlane16_swap pairing)
 };
@@ -114,8 +115,16 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
         const f16x4 rr = *(const f16x4*)(e.R + (int64_t)m * e.ldr + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] += e.beta * (float)rr[r];
+        if (e.Rlo) {
+          const f16x4 rl = *(const f16x4*)(e.Rlo + (int64_t)m * e.ldr + n);
+          const float bl = e.beta * MGLD_LO_SCALE;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] += bl * (float)rl[r];
+        }
       }
-      *(f16x4*)(e.C + (int64_t)m * e.ldc + n) = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+      const f16x4 o = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+      *(f16x4*)(e.C + (int64_t)m * e.ldc + n) = o;
+      if (e.Clo) *(f16x4*)(e.Clo + (int64_t)m * e.ldc + n) = f16x4{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3])};
     };
     if (e.noswap) {
 #pragma unroll
@@ -137,8 +146,18 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
         const f16x8 rr = *(const f16x8*)(e.R + (int64_t)m * e.ldr + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { a[r] += e.beta * (float)rr[r]; b[r] += e.beta * (float)rr[4 + r]; }
+        if (e.Rlo) {
+          const f16x8 rl = *(const f16x8*)(e.Rlo + (int64_t)m * e.ldr + n);
+          const float bl = e.beta * MGLD_LO_SCALE;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] += bl * (float)rl[r]; b[r] += bl * (float)rl[4 + r]; }
+        }
       }
-      *(f16x8*)(e.C + (int64_t)m * e.ldc + n) = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
+      const f16x8 o = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
+      *(f16x8*)(e.C + (int64_t)m * e.ldc + n) = o;
+      if (e.Clo)
+        *(f16x8*)(e.Clo + (int64_t)m * e.ldc + n) = f16x8{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3]),
+                                                          lo_plane(b[0], o[4]), lo_plane(b[1], o[5]), lo_plane(b[2], o[6]), lo_plane(b[3], o[7])};
     }
     if constexpr (NO & 1) store4(NO - 1);            // unpaired last fragment
   }
@@ -202,9 +221,18 @@ __device__ __forceinline__ void pp_epilogue_stats(const PPEpi& e, f32x4 (&acc)[N
         const f16x8 rr = *(const f16x8*)(e.R + (int64_t)m * e.ldr + n0 + nl);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { a[r] += e.beta * (float)rr[r]; b[r] += e.beta * (float)rr[4 + r]; }
+        if (e.Rlo) {
+          const f16x8 rl = *(const f16x8*)(e.Rlo + (int64_t)m * e.ldr + n0 + nl);
+          const float bl = e.beta * MGLD_LO_SCALE;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] += bl * (float)rl[r]; b[r] += bl * (float)rl[4 + r]; }
+        }
       }
       const f16x8 o = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
       *(f16x8*)(e.C + (int64_t)m * e.ldc + n0 + nl) = o;
+      if (e.Clo)
+        *(f16x8*)(e.Clo + (int64_t)m * e.ldc + n0 + nl) = f16x8{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3]),
+                                                                lo_plane(b[0], o[4]), lo_plane(b[1], o[5]), lo_plane(b[2], o[6]), lo_plane(b[3], o[7])};
       // (sums of the fp32 values before their rounding to fp16: the zero-mean rounding noise moves mean and variance of >= 10^4 elements
       //  by ~1e-7 relative — the conversions back would cost a third of this block's arithmetic)
       const e2 v[4] = {pk(a[0], a[1]), pk(a[2], a[3]), pk(b[0], b[1]), pk(b[2], b[3])};
@@ -234,9 +262,16 @@ __device__ __forceinline__ void pp_epilogue_stats(const PPEpi& e, f32x4 (&acc)[N
         const f16x4 rr = *(const f16x4*)(e.R + (int64_t)m * e.ldr + n0 + nl);
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] += e.beta * (float)rr[r];
+        if (e.Rlo) {
+          const f16x4 rl = *(const f16x4*)(e.Rlo + (int64_t)m * e.ldr + n0 + nl);
+          const float bl = e.beta * MGLD_LO_SCALE;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] += bl * (float)rl[r];
+        }
       }
       const f16x4 o = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
       *(f16x4*)(e.C + (int64_t)m * e.ldc + n0 + nl) = o;
+      if (e.Clo) *(f16x4*)(e.Clo + (int64_t)m * e.ldc + n0 + nl) = f16x4{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3])};
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ss[r] += a[r]; qq[r] += a[r] * a[r]; }
     }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512) void pptconv_kernel(const MgldIGemm p, const i
   if (grp == 0) pp_barrier();
 
   PPEpi e;
-  e.bias = p.bias; e.rowvec = nullptr; e.R = (const f16*)p.R; e.C = (f16*)p.C;
+  e.bias = p.bias; e.rowvec = nullptr; e.R = (const f16*)p.R; e.C = (f16*)p.C; e.Rlo = (const f16*)p.Rlo; e.Clo = (f16*)p.Clo;
   e.rows_per_frame = 1; e.ld_rowvec = 0; e.ldr = p.ldr; e.ldc = p.ldc; e.act = MGLD_ACT_NONE; e.alpha = p.alpha; e.beta = p.beta;
   e.noswap = false;
   pp_epilogue<MI, NI, false>(e, acc, lane, bn0 + wn * WN, [&](const int mi) {

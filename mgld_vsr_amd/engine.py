@@ -139,16 +139,39 @@ def w2_scopes():
     return frozenset(t.strip() for t in v.split(",") if t.strip())
 
 
+# where the RESIDUAL STREAM is kept as two fp16 planes (env MGLD_STREAM_LO = comma-separated scope names, "all", or "0"):
+#   unet      the UNet: every `x + f(x)` a block hands to the next one (ResBlockDual, the transformer's three residual adds, proj_in / proj_out,
+#             the temporal mixes, down / upsample convolutions, the skip concatenations)
+#   struct    the struct-cond encoder (hoisted out of the loop: five batched passes per segment)
+#   vae_dec   the video decoder (ResnetBlocks, mid attention, temporal mixes, fusion layers, upsample convolutions)
+#   vae_enc   the video VAE's fp16 encoder (features for the decoder's fusion layers)
+# value = hi + 2^-11 lo: hi is the fp16 tensor every contraction keeps reading as its operand, lo = fp16((x - hi) 2^11) is read by the
+# normalisations and the residual adds only (Act.lo, MgldIGemm.Rlo / Clo, mgld_*_lo).  What it removes is the rounding of the stream itself,
+# the largest single term of a network evaluation's error (tests/analysis/resid_sim.py: UNet 1.91e-3 -> 1.57e-3, video decoder 2.26 -> 1.70).
+STREAM_LO_DEFAULT = "unet,struct,vae_dec,vae_enc"
+
+
+def stream_lo_scopes():
+    v = os.environ.get("MGLD_STREAM_LO", STREAM_LO_DEFAULT).strip()
+    if v in ("", "0", "none", "off"):
+        return frozenset()
+    return frozenset(t.strip() for t in v.split(",") if t.strip())
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # activations + arena
 # ------------------------------------------------------------------------------------------------------------------
 class Act:
     """Token-major (NHWC) activation: `v` is a 2-D fp16 view [n*h*w, C] with row stride ld >= C."""
-    __slots__ = ("v", "n", "h", "w", "stats")
+    __slots__ = ("v", "n", "h", "w", "stats", "lo")
 
-    def __init__(self, v, n, h, w):
+    def __init__(self, v, n, h, w, lo=None):
         assert v.dim() == 2 and v.shape[0] == n * h * w, (v.shape, n, h, w)
         self.v, self.n, self.h, self.w = v, n, h, w
+        # low plane of a residual-stream tensor (same shape and row stride as v), or None: value = v + 2^-11 lo (stream_lo_scopes).  Kernels
+        # that take the tensor as a contraction operand read v alone; normalisations and residual adds read both; whoever writes v writes lo.
+        assert lo is None or (lo.shape == v.shape and lo.stride() == v.stride() and lo.dtype == v.dtype)
+        self.lo = lo
         # GroupNorm statistics of THIS tensor written by the kernel that produced it (Engine.conv3x3(stats=True), spade_apply(want_stats=True)):
         # (sums tensor, hip.GN_* kind, chunks per frame, groups or None); Engine.gn_stats() then launches nothing.  Any op that writes into
         # an existing Act (`out=`) clears it first.
@@ -166,8 +189,9 @@ class Act:
     def hw(self):
         return self.h * self.w
 
-    def cols(self, c0, c1):
-        return Act(self.v[:, c0:c1], self.n, self.h, self.w)
+    def cols(self, c0, c1, lo=True):
+        """a channel window; lo=False: without the low plane (columns that do not belong to the residual stream)"""
+        return Act(self.v[:, c0:c1], self.n, self.h, self.w, None if (self.lo is None or not lo) else self.lo[:, c0:c1])
 
 
 class Arena:
@@ -289,6 +313,7 @@ class Engine:
         self.tile_shard = None   # parallel.TileShard when the latent tiles of aggregation sampling are split over ranks
         self.pieces = None       # GraphPieces while a sharded step is recorded / replayed as hipGraph pieces
         self.w2_scopes = w2_scopes()   # precision scopes that run the second MFMA pass on the weight residual (split_residual)
+        self.lo_scopes = stream_lo_scopes()   # scopes that keep the residual stream as two fp16 planes (Act.lo)
         self._scope = []               # stack of active scope names (Engine.scope)
         # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
         self._splitk_ws = hip.ensure_workspace(workspace_bytes) if self.device.type == "cuda" else None
@@ -307,8 +332,12 @@ class Engine:
     def empty(self, rows, C, dtype=torch.float16):
         return self.arena.alloc((rows, C), dtype)
 
-    def act(self, n, h, w, C, dtype=torch.float16):
-        return Act(self.arena.alloc((n * h * w, C), dtype), n, h, w)
+    def act(self, n, h, w, C, dtype=torch.float16, lo=False):
+        """lo: a residual-stream tensor — it gets a low plane when the active scope keeps the stream as two planes (lo_on)"""
+        a = Act(self.arena.alloc((n * h * w, C), dtype), n, h, w)
+        if lo and self.lo_on:
+            a.lo = self.arena.alloc((n * h * w, C), dtype)
+        return a
 
     # ---- packed weights (cached per (tag, parameter identity, version)) ----
     def weight(self, tag, params, fn, dtype=torch.float16):
@@ -348,6 +377,11 @@ class Engine:
         s = self.w2_scopes
         return bool(s) and ("all" in s or any(n in s for n in self._scope))
 
+    @property
+    def lo_on(self):
+        s = self.lo_scopes
+        return bool(s) and ("all" in s or any(n in s for n in self._scope))
+
     def weight2(self, tag, params, fn):
         """like weight(), for a contraction that may run the residual pass: -> (hi, lo-or-None) fp16 device tensors; fn must return
         ONE fp32 matrix.  lo is built (once) only while a scope that MGLD_W2 names is active."""
@@ -374,16 +408,17 @@ class Engine:
 
     # ---- ops ----
     def conv3x3(self, x, wp, bias, cout, out=None, stride=1, pad=(1, 1), up2=False, hw_out=None, rowvec=None,
-                rows_per_frame=0, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, w2=None, stats=False):
+                rows_per_frame=0, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, w2=None, stats=False, lo=False):
         """stats: the output feeds a GroupNorm over all of its channels — where the kernel the launcher picks can, it also writes the
-        per-tile channel sums of what it stores (MgldIGemm.gn_part) and the returned Act carries them (Act.stats)."""
+        per-tile channel sums of what it stores (MgldIGemm.gn_part) and the returned Act carries them (Act.stats).
+        lo: the output is a residual-stream tensor (Engine.act(lo=True)); an `out` / `resid` that carries a low plane has it written / added."""
         hin, win = x.h, x.w
         if hw_out is None:
             hv, wv = (2 * hin, 2 * win) if up2 else (hin, win)
             hw_out = (hv, wv) if stride == 1 else (hv // 2, wv // 2)
         ho, wo = hw_out
         if out is None:
-            out = Act(self.arena.alloc((x.n * ho * wo, cout), out_dtype), x.n, ho, wo)
+            out = self.act(x.n, ho, wo, cout, out_dtype, lo=lo and out_dtype == torch.float16)
         cin = x.C
         assert wp.shape[1] == 9 * cin, (wp.shape, cin)
         tap_inner = 1 if conv_tap_inner(cin, up2) else 0          # must match pack_conv3x3(..., tap_inner) of wp
@@ -406,7 +441,8 @@ class Engine:
             kw["gn_part"] = part
         hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, rowvec=rowvec, w2=w2,
                   rows_per_frame=rows_per_frame or ho * wo, resid=None if resid is None else resid.v, act=act, alpha=alpha,
-                  beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0), tap_inner=tap_inner, **kw)
+                  beta=beta, conv=(cin, hin, win, ho, wo, stride, pad[0], pad[1], 1 if up2 else 0), tap_inner=tap_inner,
+                  resid_lo=None if resid is None else resid.lo, out_lo=out.lo, **kw)
         if got:
             out.stats = got[0]
         self.launches += 1
@@ -447,30 +483,35 @@ class Engine:
         return out
 
     def linear(self, x, w, bias, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, n_out=None,
-               w2=None):
-        """x: Act or 2-D view; w [N, K] fp16 packed."""
+               w2=None, lo=False):
+        """x: Act or 2-D view; w [N, K] fp16 packed.  lo (x an Act, no `out`): the output is a residual-stream tensor; an Act `out` / `resid`
+        that carries a low plane has it written / added."""
         xv = x.v if isinstance(x, Act) else x
         N = n_out if n_out is not None else (w.shape[0] // 2 if act == hip.ACT_GEGLU else w.shape[0])
         if out is None:
-            ov = self.arena.alloc((xv.shape[0], N), out_dtype)
-            out = Act(ov, x.n, x.h, x.w) if isinstance(x, Act) else ov
+            if isinstance(x, Act):
+                out = self.act(x.n, x.h, x.w, N, out_dtype, lo=lo and out_dtype == torch.float16)
+            else:
+                assert not lo, "a residual-stream output needs an Act input (frame geometry)"
+                out = self.arena.alloc((xv.shape[0], N), out_dtype)
         ov = out.v if isinstance(out, Act) else out
         if isinstance(out, Act):
             out.stats = None
         rv = resid.v if isinstance(resid, Act) else resid
-        hip.igemm(xv, w, ov, bias=bias, resid=rv, act=act, alpha=alpha, beta=beta, M=xv.shape[0], N=w.shape[0], K=w.shape[1], w2=w2)
+        hip.igemm(xv, w, ov, bias=bias, resid=rv, act=act, alpha=alpha, beta=beta, M=xv.shape[0], N=w.shape[0], K=w.shape[1], w2=w2,
+                  resid_lo=resid.lo if isinstance(resid, Act) else None, out_lo=out.lo if isinstance(out, Act) else None)
         self.launches += 1
         return out
 
     def tconv3(self, x, wp, bias, T, alpha_blend, out=None, w2=None):
         """SpatialTemporalConv: out = a*(conv3d_t(x)+b) + (1-a)*x."""
         if out is None:
-            out = self.act(x.n, x.h, x.w, x.C)
+            out = self.act(x.n, x.h, x.w, x.C, lo=x.lo is not None)
         out.stats = None
         sh = self.shard
         if sh is None:
             hip.igemm(x.v, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
-                      tconv=(x.C, T, x.hw), w2=w2)
+                      tconv=(x.C, T, x.hw), w2=w2, resid_lo=x.lo, out_lo=out.lo)
             self.launches += 1
             return out
         # frame-sharded clip (parallel.FrameShard): this rank holds F consecutive frames.  The conv runs on a halo-extended
@@ -484,7 +525,7 @@ class Engine:
         hip.copy2d(x.v, mid)
         self.collective(lambda: sh.halo(x.v, hw, ext[:hw], ext[(F + 1) * hw:]))
         hip.igemm(mid, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
-                  tconv=(x.C, F + 2, hw), t_off=1, w2=w2)
+                  tconv=(x.C, F + 2, hw), t_off=1, w2=w2, resid_lo=x.lo, out_lo=out.lo)
         self.launches += 2
         return out
 
@@ -510,9 +551,9 @@ class Engine:
         out.stats = None
         gsums, eps, kind, chunks = stats
         if gsums is None:
-            hip.gn_fused(x.v, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu)
+            hip.gn_fused(x.v, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, lo_in=x.lo)
         else:
-            hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, kind=kind, chunks=chunks)
+            hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, kind=kind, chunks=chunks, x_lo=x.lo)
         self.launches += 1
         return out
 
@@ -523,20 +564,27 @@ class Engine:
         """want_stats: the output feeds a GroupNorm (the transformer's norm after a ResBlockDual): the apply kernel also reduces what it
         stores, and the returned Act carries the sums (Act.stats)"""
         if out is None:
-            out = self.act(h.n, h.h, h.w, h.C)
+            out = self.act(h.n, h.h, h.w, h.C, lo=True)       # skip + spade(h): the block's output, the next value of the residual stream
         out.stats = None
         gsums, eps, kind, chunks = stats
         gbv = gb.v if isinstance(gb, Act) else gb
+        skip_lo, y_lo = skip.lo, out.lo
+        if y_lo is not None and skip_lo is None:      # (a skip tensor without a low plane: an all-zero one)
+            skip_lo = self.const(("lozeros", tuple(skip.v.shape), skip.v.stride(0)),
+                                 lambda: torch.zeros(skip.v.shape[0] * skip.v.stride(0), dtype=torch.float16, device=self.device)
+                                 ).as_strided(skip.v.shape, skip.v.stride())
+        if y_lo is None:
+            skip_lo = None
         if gsums is None:
             hip.gn_fused(h.v, eps, gamma, beta, out.v, h.n, h.hw, self.GROUPS, 0, gb=gbv, skip=skip.v, step_idx=step_idx,
-                         step_stride=step_stride)
+                         step_stride=step_stride, lo_in=skip_lo, lo_out=y_lo)
         else:
             so = None
             if want_stats and self.GN_PRODUCER:
                 oc = hip.gn_apply_chunks(h.n, h.hw, h.C, self.GROUPS)
                 so = self.arena.alloc((h.n, oc, self.GROUPS, 2), torch.float64)
             hip.spade_apply(h.v, gsums, eps, gamma, beta, gbv, skip.v, out.v, h.n, h.hw, self.GROUPS, step_idx, step_stride, kind=kind,
-                            chunks=chunks, stats_out=so)
+                            chunks=chunks, stats_out=so, skip_lo=skip_lo, y_lo=y_lo)
             if so is not None:
                 out.stats = (so, hip.GN_GROUP_SUMS, oc, self.GROUPS)
         self.launches += 1
@@ -545,7 +593,7 @@ class Engine:
     def layernorm(self, x, gamma, beta, eps=1e-5):
         xv = x.v if isinstance(x, Act) else x
         out = self.arena.alloc((xv.shape[0], xv.shape[1]), torch.float16)
-        hip.layernorm(xv, gamma, beta, out, eps)
+        hip.layernorm(xv, gamma, beta, out, eps, x_lo=x.lo if isinstance(x, Act) else None)
         self.launches += 1
         return Act(out, x.n, x.h, x.w) if isinstance(x, Act) else out
 

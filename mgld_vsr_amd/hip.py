@@ -34,6 +34,7 @@ class MgldIGemm(C.Structure):
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
         ("t_off", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("tune", C.c_int32),
         ("w2_scale", C.c_float), ("W2", C.c_void_p), ("gn_part", C.c_void_p), ("r_f32", C.c_int32),
+        ("Rlo", C.c_void_p), ("Clo", C.c_void_p),
     ]
 
 
@@ -56,9 +57,10 @@ EXPORTS = [
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
     "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_igemm_gn_chunks", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply",
     "mgld_gn_apply_chunks", "mgld_gn_apply2", "mgld_spade_apply2", "mgld_gn_fused_applies", "mgld_gn_fused", "mgld_layernorm",
+    "mgld_gn_apply_lo", "mgld_spade_apply_lo", "mgld_gn_fused_lo", "mgld_layernorm_lo",
     "mgld_attention", "mgld_attention_kernel_name", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
     "mgld_linear_small", "mgld_timestep_embedding",
-    "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby", "mgld_tile_conv3p",
+    "mgld_nchw_to_nhwc", "mgld_nhwc_to_nchw", "mgld_copy2d", "mgld_axpby", "mgld_axpby_lo", "mgld_tile_conv3p",
     "mgld_ddpm_step", "mgld_flow_warp", "mgld_guidance", "mgld_guidance_loss", "mgld_step_advance",
     "mgld_step_timestep", "mgld_fb_consistency", "mgld_resize_flow",
     "mgld_adain", "mgld_wavelet_reconstruction", "mgld_init_latent", "mgld_to01",
@@ -122,11 +124,14 @@ W2_SCALE = 2.0 ** -11     # scale of the weight-residual matrices (MgldIGemm.W2)
 
 def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None,
           act=ACT_NONE, alpha=1.0, beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0,
-          M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0, w2=None, w2_scale=W2_SCALE, gn_part=None):
+          M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0, w2=None, w2_scale=W2_SCALE, gn_part=None,
+          resid_lo=None, out_lo=None):
     """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h).
     w2: the scaled fp16 rounding residual of the weights (same layout as w; engine.split_residual): the product then uses weights
-    exact to ~2^-21 at twice the MFMA work."""
-    _req_cuda(a, w, out)
+    exact to ~2^-21 at twice the MFMA work.
+    resid_lo / out_lo: low planes of the residual / of the output (the residual stream as two fp16 planes, value = hi + 2^-11 lo:
+    MgldIGemm.Rlo / Clo); each shares the leading dimension of its hi plane."""
+    _req_cuda(a, w, out, resid_lo, out_lo)
     if not getattr(_TLS, "touched", False):
         ensure_workspace()          # a thread other than the one that built the Engine: give it its own split-K scratch
     p = MgldIGemm()
@@ -147,6 +152,12 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
     p.out_f32 = 1 if out.dtype == torch.float32 else 0
     p.r_f32 = 1 if (resid is not None and resid.dtype == torch.float32) else 0
     p.alpha, p.beta = alpha, beta
+    if resid_lo is not None:
+        assert resid is not None and resid_lo.dtype == torch.float16 and resid.dtype == torch.float16 and _ld(resid_lo) == _ld(resid), "resid_lo mirrors resid"
+        p.Rlo = resid_lo.data_ptr()
+    if out_lo is not None:
+        assert out_lo.dtype == torch.float16 and out.dtype == torch.float16 and _ld(out_lo) == _ld(out), "out_lo mirrors out"
+        p.Clo = out_lo.data_ptr()
     p.batch = batch
     p.tap_inner = tap_inner
     p.t_off = t_off
@@ -288,11 +299,22 @@ def gn_apply_chunks(frames, rows, channels, groups):
     return lib().mgld_gn_apply_chunks(int(frames), int(rows), int(channels), int(groups))
 
 
-def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu, kind=GN_GROUP_SUMS, chunks=0, stats_out=None):
+def _lo_of(lo, hi):
+    assert lo.is_cuda and lo.dtype == torch.float16 and hi.dtype == torch.float16 and lo.shape == hi.shape and _ld(lo) == _ld(hi), "a low plane mirrors its hi plane"
+    return _p(lo)
+
+
+def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu, kind=GN_GROUP_SUMS, chunks=0, stats_out=None, x_lo=None):
     """kind / chunks: format of `gsums` (default: mgld_gn_stats' output); stats_out: float64 [frames, gn_apply_chunks, groups, 2] that
-    receives the per-group sums of y"""
+    receives the per-group sums of y; x_lo: low plane of x (the residual stream as two fp16 planes)"""
     _req_cuda(x, gsums, gamma, beta, y)
     st = _gn_src(gsums, kind, chunks, rows)
+    if x_lo is not None:
+        assert stats_out is None
+        with timed("gn_apply", {"bytes": 6.0 * frames * rows * x.shape[1]}):
+            _chk(lib().mgld_gn_apply_lo(_p(x), _lo_of(x_lo, x), _ld(x), C.byref(st), C.c_float(eps), _p(gamma), _p(beta), _p(y), _ld(y), frames,
+                                        rows, x.shape[1], groups, int(silu), stream_ptr()), "gn_apply_lo")
+        return y
     with timed("gn_apply", {"bytes": 4.0 * frames * rows * x.shape[1]}):
         _chk(lib().mgld_gn_apply2(_p(x), _ld(x), C.byref(st), C.c_float(eps), _p(gamma), _p(beta), _p(y), _ld(y), frames, rows,
                                   x.shape[1], groups, int(silu), _p(stats_out), stream_ptr()), "gn_apply")
@@ -300,11 +322,17 @@ def gn_apply(x, gsums, eps, gamma, beta, y, frames, rows, groups, silu, kind=GN_
 
 
 def spade_apply(h, gsums, eps, gamma, beta, gb, skip, y, frames, rows, groups, step_idx=None, step_stride=0, kind=GN_GROUP_SUMS, chunks=0,
-                stats_out=None):
+                stats_out=None, skip_lo=None, y_lo=None):
     """gb: [frames*rows, 2C] modulation, or (step_idx given) the first slice of a per-step table with `step_stride` elements
-    between consecutive steps.  kind / chunks / stats_out as in gn_apply."""
+    between consecutive steps.  kind / chunks / stats_out as in gn_apply.  skip_lo / y_lo: low planes of skip and y (together)."""
     _req_cuda(h, gsums, gamma, beta, gb, skip, y)
     st = _gn_src(gsums, kind, chunks, rows)
+    if y_lo is not None:
+        with timed("spade_apply", {"bytes": 14.0 * frames * rows * h.shape[1]}):
+            _chk(lib().mgld_spade_apply_lo(_p(h), _ld(h), C.byref(st), C.c_float(eps), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip),
+                                           _lo_of(skip_lo, skip), _ld(skip), _p(y), _lo_of(y_lo, y), _ld(y), frames, rows, h.shape[1], groups,
+                                           _p(step_idx), C.c_int64(step_stride), _p(stats_out), stream_ptr()), "spade_apply_lo")
+        return y
     with timed("spade_apply", {"bytes": 10.0 * frames * rows * h.shape[1]}):
         _chk(lib().mgld_spade_apply2(_p(h), _ld(h), C.byref(st), C.c_float(eps), _p(gamma), _p(beta), _p(gb), _ld(gb), _p(skip),
                                      _ld(skip), _p(y), _ld(y), frames, rows, h.shape[1], groups, _p(step_idx), C.c_int64(step_stride),
@@ -317,12 +345,20 @@ def gn_fused_applies(rows, channels, groups):
     return bool(lib().mgld_gn_fused_applies(int(rows), int(channels), int(groups)))
 
 
-def gn_fused(x, eps, gamma, beta, y, frames, rows, groups, silu=0, gb=None, skip=None, step_idx=None, step_stride=0):
-    """y = act(GN(x)) or, with gb / skip, the SPADE formula of spade_apply; one launch (statistics + apply)"""
+def gn_fused(x, eps, gamma, beta, y, frames, rows, groups, silu=0, gb=None, skip=None, step_idx=None, step_stride=0, lo_in=None, lo_out=None):
+    """y = act(GN(x)) or, with gb / skip, the SPADE formula of spade_apply; one launch (statistics + apply).  lo_in / lo_out: plain form
+    — the low plane of x; SPADE form — the low planes of skip and of y"""
     _req_cuda(x, gamma, beta, y)
     spade = gb is not None
     if spade:
         _req_cuda(gb, skip)
+    if lo_in is not None:
+        with timed("spade_apply" if spade else "gn_apply", {"bytes": (14.0 if spade else 6.0) * frames * rows * x.shape[1]}):
+            _chk(lib().mgld_gn_fused_lo(_p(x), _ld(x), C.c_float(eps), _p(gamma), _p(beta), _p(gb) if spade else None, _ld(gb) if spade else 0,
+                                        _p(skip) if spade else None, _ld(skip) if spade else 0, _p(y), _ld(y), frames, rows, x.shape[1],
+                                        groups, int(silu), _p(step_idx), C.c_int64(step_stride), _lo_of(lo_in, skip if spade else x),
+                                        _lo_of(lo_out, y) if spade else None, stream_ptr()), "gn_fused_lo")
+        return y
     with timed("spade_apply" if spade else "gn_apply", {"bytes": (10.0 if spade else 4.0) * frames * rows * x.shape[1]}):
         _chk(lib().mgld_gn_fused(_p(x), _ld(x), C.c_float(eps), _p(gamma), _p(beta), _p(gb) if spade else None, _ld(gb) if spade else 0,
                                  _p(skip) if spade else None, _ld(skip) if spade else 0, _p(y), _ld(y), frames, rows, x.shape[1],
@@ -330,8 +366,13 @@ def gn_fused(x, eps, gamma, beta, y, frames, rows, groups, silu=0, gb=None, skip
     return y
 
 
-def layernorm(x, gamma, beta, y, eps=1e-5):
+def layernorm(x, gamma, beta, y, eps=1e-5, x_lo=None):
     _req_cuda(x, gamma, beta, y)
+    if x_lo is not None:
+        with timed("layernorm", {"bytes": 6.0 * x.shape[0] * x.shape[1]}):
+            _chk(lib().mgld_layernorm_lo(_p(x), _lo_of(x_lo, x), _ld(x), _p(gamma), _p(beta), _p(y), _ld(y), x.shape[0], x.shape[1],
+                                         C.c_float(eps), stream_ptr()), "layernorm_lo")
+        return y
     with timed("layernorm", {"bytes": 4.0 * x.shape[0] * x.shape[1]}):
         _chk(lib().mgld_layernorm(_p(x), _ld(x), _p(gamma), _p(beta), _p(y), _ld(y), x.shape[0], x.shape[1], C.c_float(eps),
                                   stream_ptr()), "layernorm")
@@ -432,6 +473,13 @@ def copy2d(src, dst):
     _req_cuda(src, dst)
     _chk(lib().mgld_copy2d(_p(src), _ld(src), _p(dst), _ld(dst), C.c_int64(src.shape[0]), src.shape[1], stream_ptr()), "copy2d")
     return dst
+
+
+def axpby_lo(x, x_lo, y, y_lo, a, b):
+    """(y, y_lo) <- a (x, x_lo) + b (y, y_lo) on two-plane residual-stream tensors (x_lo may be None)"""
+    _req_cuda(x, y, y_lo)
+    _chk(lib().mgld_axpby_lo(_p(x), _lo_of(x_lo, x) if x_lo is not None else None, _ld(x), _p(y), _lo_of(y_lo, y), _ld(y), C.c_int64(x.shape[0]),
+                             x.shape[1], C.c_float(a), C.c_float(b), stream_ptr()), "axpby_lo")
 
 
 def axpby(x, y, a, b):

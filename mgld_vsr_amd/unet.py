@@ -62,7 +62,7 @@ class Upsample(nn.Module):
         # nearest-2x upsample folded into the conv gather: per-lane taps -> (tap, Cin) weight order
         w = eng.weight("c3up", (self.conv.weight,), lambda t: pack_conv3x3(t, tap_inner=False))
         b = eng.f32("b", self.conv.bias)
-        return eng.conv3x3(x, w, b, self.out_channels, out=out, up2=True)
+        return eng.conv3x3(x, w, b, self.out_channels, out=out, up2=True, lo=True)
 
 
 class Downsample(nn.Module):
@@ -77,7 +77,7 @@ class Downsample(nn.Module):
     def run(self, eng, x, out=None):
         w = eng.weight("c3", (self.op.weight,), pack_conv3x3)
         b = eng.f32("b", self.op.bias)
-        return eng.conv3x3(x, w, b, self.out_channels, out=out, stride=2)
+        return eng.conv3x3(x, w, b, self.out_channels, out=out, stride=2, lo=True)
 
 
 class ResBlock(nn.Module):
@@ -103,7 +103,7 @@ class ResBlock(nn.Module):
         if isinstance(self.skip_connection, nn.Identity):
             return x
         w = eng.weight("c1", (self.skip_connection.weight,), pack_conv1x1)
-        return eng.linear(x, w, eng.f32("b", self.skip_connection.bias))
+        return eng.linear(x, w, eng.f32("b", self.skip_connection.bias), lo=True)
 
     def _trunk(self, eng, x, emb_all, emb_rpf):
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
@@ -119,7 +119,7 @@ class ResBlock(nn.Module):
         conv2 = self.out_layers[3]
         skip = self._skip(eng, x)
         return eng.conv3x3(t, eng.weight("c3", (conv2.weight,), pack_conv3x3), eng.f32("b", conv2.bias), self.out_channels,
-                           out=out, resid=skip)
+                           out=out, resid=skip, lo=True)
 
 
 class ResBlockDual(ResBlock):
@@ -205,7 +205,7 @@ class AttentionBlock(nn.Module):
                           o_strides=(N * C, C, ch), scale=(1.0 / LOG2E) if ps else ch ** -0.5, v_rowmajor=True)
             eng.launches += 1
             wp = eng.weight("c1", (self.proj_out.weight,), pack_conv1x1)
-            return eng.linear(o, wp, eng.f32("b", self.proj_out.bias), out=out, resid=x)
+            return eng.linear(o, wp, eng.f32("b", self.proj_out.bias), out=out, resid=x, lo=True)
         wqk, bqk = eng.weight("qk", (self.qkv.weight, self.qkv.bias), lambda w, b: split(w, b)[:2])
         wv, bv = eng.weight("v", (self.qkv.weight, self.qkv.bias), lambda w, b: split(w, b)[2:])
         qk = eng.linear(x=xn, w=wqk, bias=bqk)                      # [rows, 2C]: q | k, head-major
@@ -218,7 +218,7 @@ class AttentionBlock(nn.Module):
                       o_strides=(N * C, C, ch), scale=ch ** -0.5)
         eng.launches += 2
         wp = eng.weight("c1", (self.proj_out.weight,), pack_conv1x1)
-        return eng.linear(o, wp, eng.f32("b", self.proj_out.bias), out=out, resid=x)
+        return eng.linear(o, wp, eng.f32("b", self.proj_out.bias), out=out, resid=x, lo=True)
 
 
 class GEGLU(nn.Module):
@@ -256,7 +256,8 @@ LOG2E = 1.4426950408889634
 
 
 def _self_attention(eng, attn, xn, frames, N, resid, out=None):
-    """softmax(q k^T / sqrt(d)) v over the N tokens of each frame; xn: 2-D [frames*N, C] normalized tokens."""
+    """softmax(q k^T / sqrt(d)) v over the N tokens of each frame; xn: 2-D [frames*N, C] normalized tokens; resid: the residual-stream Act
+    the result is added to (-> the stream's next Act)."""
     C, H, d = attn.heads * attn.dim_head, attn.heads, attn.dim_head
     if QKV_FUSED:
         # to_q | to_k | to_v (attention.py:323-330) as one GEMM with N = 3C: the normalised tokens are read once, and the attention
@@ -273,7 +274,7 @@ def _self_attention(eng, attn, xn, frames, N, resid, out=None):
                       o_strides=(N * C, C, d), scale=1.0 / LOG2E, v_rowmajor=True)
         eng.launches += 1
         wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-        return eng.linear(o, wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid)
+        return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=True)
     wqk = eng.weight("qk", (attn.to_q.weight, attn.to_k.weight), lambda q, k: torch.cat([q, k], 0))
     wv = eng.weight("w", (attn.to_v.weight,), lambda v: v)
     qk = eng.linear(xn, wqk, None)
@@ -286,7 +287,7 @@ def _self_attention(eng, attn, xn, frames, N, resid, out=None):
                   o_strides=(N * C, C, d), scale=d ** -0.5)
     eng.launches += 2
     wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-    return eng.linear(o, wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid)
+    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=True)
 
 
 class ContextCache:
@@ -328,7 +329,7 @@ def _cross_attention(eng, attn, xn, frames, N, ctx_cache, resid):
                   scale=d ** -0.5)
     eng.launches += 1
     wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-    return eng.linear(o, wo, eng.f32("b", attn.to_out[0].bias), resid=resid)
+    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), resid=resid, lo=True)
 
 
 class BasicTransformerBlockV2(nn.Module):
@@ -344,14 +345,15 @@ class BasicTransformerBlockV2(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
 
     def run(self, eng, t, frames, N, ctx_cache):
-        ln = lambda x, m: eng.layernorm(x, eng.f32("g", m.weight), eng.f32("b", m.bias), m.eps)
+        """t: the token stream as an Act (its low plane, when it has one, feeds the LayerNorms and the residual adds)"""
+        ln = lambda x, m: eng.layernorm(x, eng.f32("g", m.weight), eng.f32("b", m.bias), m.eps).v
         t = _self_attention(eng, self.attn1, ln(t, self.norm1), frames, N, resid=t)
         t = _cross_attention(eng, self.attn2, ln(t, self.norm2), frames, N, ctx_cache, resid=t)
         proj = self.ff.net[0].proj
         wg, bg = eng.weight("geglu", (proj.weight, proj.bias), pack_geglu)
         g = eng.linear(ln(t, self.norm3), wg, bg, act=hip.ACT_GEGLU)
         w2 = eng.weight("w", (self.ff.net[2].weight,), lambda w: w)
-        return eng.linear(g, w2, eng.f32("b", self.ff.net[2].bias), resid=t)
+        return eng.linear(Act(g, t.n, t.h, t.w), w2, eng.f32("b", self.ff.net[2].bias), resid=t, lo=True)
 
 
 class SpatialTransformerV2(nn.Module):
@@ -374,12 +376,9 @@ class SpatialTransformerV2(nn.Module):
 
     def run(self, eng, x, ctx_cache, out=None):
         xn = eng.groupnorm(x, eng.f32("g", self.norm.weight), eng.f32("b", self.norm.bias), self.norm.eps, False)
-        t = eng.linear(xn.v, eng.weight("w", (self.proj_in.weight,), lambda w: w), eng.f32("b", self.proj_in.bias))
+        t = eng.linear(xn, eng.weight("w", (self.proj_in.weight,), lambda w: w), eng.f32("b", self.proj_in.bias), lo=True)
         t = self.transformer_blocks[0].run(eng, t, x.n, x.hw, ctx_cache)
-        ov = None if out is None else out.v
-        y = eng.linear(t, eng.weight("w", (self.proj_out.weight,), lambda w: w), eng.f32("b", self.proj_out.bias), out=ov,
-                       resid=x.v)
-        return out if out is not None else Act(y, x.n, x.h, x.w)
+        return eng.linear(t, eng.weight("w", (self.proj_out.weight,), lambda w: w), eng.f32("b", self.proj_out.bias), out=out, resid=x, lo=True)
 
 
 class SpatialTemporalConv(nn.Module):
@@ -435,9 +434,7 @@ class TemporalAttention(nn.Module):
                 eng.launches += 1
         alpha = float(self.temporal_alpha.detach())
         wo = eng.weight("w", (a.to_out[0].weight,), lambda w: w)
-        ov = None if out is None else out.v
-        y = eng.linear(o, wo, eng.f32("b", a.to_out[0].bias), out=ov, resid=x.v, alpha=alpha, beta=1.0 - alpha)
-        return out if out is not None else Act(y, x.n, x.h, x.w)
+        return eng.linear(Act(o, x.n, x.h, x.w), wo, eng.f32("b", a.to_out[0].bias), out=out, resid=x, alpha=alpha, beta=1.0 - alpha, lo=True)
 
 
 class TimestepEmbedSequential(nn.Sequential):
@@ -604,6 +601,10 @@ class InflatedUNetModelDualcondV2(nn.Module, _TimeEmbedMixin):
     def run(self, eng, x, tvals, emb_rows, ctx_cache, struct_cond, out_eps=None):
         """x: Act [n,h,w,8] (latent channels zero-padded to 8); struct_cond: dict str(width)->Act; returns the fp32
         token-major eps buffer [n*h*w, 4] (ld = out_channels)."""
+        with eng.scope("unet"):       # (engine.STREAM_LO_DEFAULT: the residual stream as two fp16 planes)
+            return self._run(eng, x, tvals, emb_rows, ctx_cache, struct_cond, out_eps)
+
+    def _run(self, eng, x, tvals, emb_rows, ctx_cache, struct_cond, out_eps):
         emb = self._time_embedding(eng, tvals)
         rpf = emb_rows if emb_rows is not None else None
 
@@ -635,7 +636,7 @@ class InflatedUNetModelDualcondV2(nn.Module, _TimeEmbedMixin):
         for j in range(len(self.output_blocks)):
             i = n_in - 1 - j
             hh, ww = in_hw[i]
-            cats.append(eng.act(x.n, hh, ww, ch_in[j] + in_ch[i]))
+            cats.append(eng.act(x.n, hh, ww, ch_in[j] + in_ch[i], lo=True))
 
         def skip_slot(i):  # where input block i writes its output
             j = n_in - 1 - i
@@ -747,6 +748,10 @@ class InflatedEncoderUNetModelWT(nn.Module, _TimeEmbedMixin):
 
     def run(self, eng, x, tvals, emb_rows):
         """x: Act [n,h,w,8] -> dict str(width) -> Act [n,r,r,out_channels]."""
+        with eng.scope("struct"):
+            return self._run(eng, x, tvals, emb_rows)
+
+    def _run(self, eng, x, tvals, emb_rows):
         emb = self._time_embedding(eng, tvals)
 
         def erpf(a):   # rows sharing one embedding row: all (None), one frame (1), or emb_rows consecutive frames
@@ -758,7 +763,7 @@ class InflatedEncoderUNetModelWT(nn.Module, _TimeEmbedMixin):
             for layer in blk:
                 if isinstance(layer, nn.Conv2d):
                     h = eng.conv3x3(h, eng.weight("c3", (layer.weight,), lambda w: pack_conv3x3(w, h.C)), eng.f32("b", layer.bias),
-                                    layer.out_channels)
+                                    layer.out_channels, lo=True)
                 elif isinstance(layer, ResBlock):
                     h = layer.run(eng, h, emb, erpf(h))
                 elif isinstance(layer, (AttentionBlock, Downsample)):

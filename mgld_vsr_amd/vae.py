@@ -36,9 +36,9 @@ def _conv3(eng, conv, x, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta
                        w2=w2, **kw)
 
 
-def _conv1(eng, conv, x, out=None, resid=None, alpha=1.0, beta=1.0):
+def _conv1(eng, conv, x, out=None, resid=None, alpha=1.0, beta=1.0, lo=False):
     w, w2 = eng.weight2("c1", (conv.weight,), lambda t: pack_conv1x1(t, x.C))
-    return eng.linear(x, w, eng.f32("b", conv.bias), out=out, resid=resid, alpha=alpha, beta=beta, w2=w2)
+    return eng.linear(x, w, eng.f32("b", conv.bias), out=out, resid=resid, alpha=alpha, beta=beta, w2=w2, lo=lo)
 
 
 def _gn(eng, norm, x, silu):
@@ -87,7 +87,7 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1)
 
     def run(self, eng, x):
-        return _conv3(eng, self.conv, x, up2=True)
+        return _conv3(eng, self.conv, x, up2=True, lo=True)
 
 
 class Downsample(nn.Module):
@@ -98,7 +98,7 @@ class Downsample(nn.Module):
 
     def run(self, eng, x):
         # F.pad (0,1,0,1) then stride-2 valid conv (model.py:114-118): pad_t = pad_l = 0, bottom/right implied
-        return _conv3(eng, self.conv, x, stride=2, pad=(0, 0), hw_out=(x.h // 2, x.w // 2))
+        return _conv3(eng, self.conv, x, stride=2, pad=(0, 0), hw_out=(x.h // 2, x.w // 2), lo=True)
 
     def run_hp(self, eng, x):
         return _hp_conv3(eng, self.conv, _hp_split(eng, x), stride=2, pad=(0, 0), hw_out=(x.h // 2, x.w // 2))
@@ -120,8 +120,8 @@ class ResnetBlock(nn.Module):
 
     def run(self, eng, x, out=None):
         h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True), stats=True)          # norm2 reads the epilogue's statistics
-        skip = x if self.in_channels == self.out_channels else _conv1(eng, self.nin_shortcut, x)
-        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip, stats=True)   # the next block's norm likewise
+        skip = x if self.in_channels == self.out_channels else _conv1(eng, self.nin_shortcut, x, lo=True)
+        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip, stats=True, lo=True)   # the next block's norm likewise
 
     def run_hp(self, eng, x):
         """model.py:162-183 with fp32 activations (x, the result and the skip are fp32 Acts)"""
@@ -160,7 +160,7 @@ class AttnBlock(nn.Module):
         o = eng.act(x.n, x.h, x.w, C)
         hip.igemm(P, vt, o.v, M=N, N=C, K=N, batch=F, strideA=N * N, strideW=C * N, strideC=N * C)
         eng.launches += 4
-        return _conv1(eng, self.proj_out, o, resid=x)
+        return _conv1(eng, self.proj_out, o, resid=x, lo=True)
 
     def run_hp(self, eng, x):
         """the same block entirely in fp32 on the f32-input MFMA (model.py:209-244): q, k, v^T, S = q k^T / sqrt(C), row softmax,
@@ -221,7 +221,7 @@ class Encoder(nn.Module):
     def run(self, eng, x, fea_out=None):
         """x: Act (channels padded to 8). Returns (h Act [n, h/8, w/8, 2z], [fea level1, fea level2]).
         fea_out: optional list of 2 Acts to write the encoder features into (decoder concat buffers)."""
-        h = _conv3(eng, self.conv_in, x)
+        h = _conv3(eng, self.conv_in, x, lo=True)
         fea = []
         for lvl in range(self.num_resolutions):
             nb = len(self.down[lvl].block)
@@ -293,7 +293,7 @@ class Decoder(nn.Module):
         self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
 
     def run(self, eng, z):
-        h = _conv3(eng, self.conv_in, z)
+        h = _conv3(eng, self.conv_in, z, lo=True)
         h = self.mid.block_1.run(eng, h)
         h = self.mid.attn_1.run(eng, h)
         h = self.mid.block_2.run(eng, h)
@@ -323,8 +323,8 @@ class ResBlock(nn.Module):
 
     def run(self, eng, x, out=None, resid_extra=None):
         h = _conv3(eng, self.conv1, _gn(eng, self.norm1, x, True), stats=True)          # norm2 reads the epilogue's statistics
-        skip = x if self.in_channels == self.out_channels else _conv1(eng, self.conv_out, x)
-        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip, stats=True)   # the next block's norm likewise
+        skip = x if self.in_channels == self.out_channels else _conv1(eng, self.conv_out, x, lo=True)
+        return _conv3(eng, self.conv2, _gn(eng, self.norm2, h, True), out=out, resid=skip, stats=True, lo=True)   # the next block's norm likewise
 
 
 class ResidualDenseBlock(nn.Module):
@@ -343,8 +343,8 @@ class ResidualDenseBlock(nn.Module):
         """buf: Act [rows, nf+4gc] whose first nf columns hold x; writes x5*0.2+x into out_buf[:, :nf]."""
         nf, gc = self.nf, self.gc
         for i, conv in enumerate([self.conv1, self.conv2, self.conv3, self.conv4]):
-            _conv3(eng, conv, buf.cols(0, nf + i * gc), out=buf.cols(nf + i * gc, nf + (i + 1) * gc), act=hip.ACT_LRELU02)
-        return _conv3(eng, self.conv5, buf, out=out_buf.cols(0, nf), resid=buf.cols(0, nf), alpha=0.2, beta=1.0)
+            _conv3(eng, conv, buf.cols(0, nf + i * gc), out=buf.cols(nf + i * gc, nf + (i + 1) * gc, lo=False), act=hip.ACT_LRELU02)
+        return _conv3(eng, self.conv5, buf, out=out_buf.cols(0, nf), resid=buf.cols(0, nf), alpha=0.2, beta=1.0)   # x5 * 0.2 + x: the stream
 
 
 class Fuse_sft_block_ResidualDenseBlock(nn.Module):
@@ -359,14 +359,22 @@ class Fuse_sft_block_ResidualDenseBlock(nn.Module):
         """cat: Act [rows, 2*in_ch] = [enc_feat | dec_feat]; returns dec_feat + w * f(cat)."""
         dec = cat.cols(self.in_ch, 2 * self.in_ch)
         width = self.in_ch + 4 * self.gc
-        bufs = [eng.act(cat.n, cat.h, cat.w, width) for _ in range(len(self.encode_enc_2) + 1)]
+        bufs = [eng.act(cat.n, cat.h, cat.w, width, lo=True) for _ in range(len(self.encode_enc_2) + 1)]   # (low plane: the first in_ch columns use it)
         self.encode_enc_1.run(eng, cat, out=bufs[0].cols(0, self.in_ch))
         for i, blk in enumerate(self.encode_enc_2):
             blk.run(eng, bufs[i], bufs[i + 1])
         e = self.encode_enc_3.run(eng, bufs[-1].cols(0, self.in_ch))
-        out = eng.act(cat.n, cat.h, cat.w, self.in_ch)
+        out = eng.act(cat.n, cat.h, cat.w, self.in_ch, lo=True)
         hip.copy2d(dec.v, out.v)
-        hip.axpby(e.v, out.v, float(w), 1.0)
+        if out.lo is not None:                    # dec_feat + w * f(cat) on the two-plane stream
+            if dec.lo is not None:
+                hip.copy2d(dec.lo, out.lo)
+            else:
+                out.lo.zero_()
+            hip.axpby_lo(e.v, e.lo, out.v, out.lo, float(w), 1.0)
+            eng.launches += 1
+        else:
+            hip.axpby(e.v, out.v, float(w), 1.0)
         eng.launches += 2
         return out
 
@@ -413,7 +421,7 @@ class VideoDecoder_Mix(nn.Module):
         Returns fp32 token-major output Act [n*H*W, out_ch]."""
         # (precision scopes, engine.w2_scopes: vae_dec_mid / vae_dec_up<level> / vae_dec_fuse / vae_dec_out inside the caller's vae_dec)
         with eng.scope("vae_dec_mid"):
-            h = _conv3(eng, self.conv_in, z)
+            h = _conv3(eng, self.conv_in, z, lo=True)
             h = self.mid.block_1.run(eng, h)
             h = self.temporal_mixing.run(eng, h)
             h = self.mid.attn_1.run(eng, h)
@@ -428,8 +436,13 @@ class VideoDecoder_Mix(nn.Module):
                     o = None
                     if fuse and b == nb - 1:
                         ef = enc_fea[lvl - 1]
-                        cat = eng.act(h.n, h.h, h.w, ef.C + h.C)
+                        cat = eng.act(h.n, h.h, h.w, ef.C + h.C, lo=True)
                         hip.copy2d(ef.v, cat.v[:, :ef.C])
+                        if cat.lo is not None:
+                            if ef.lo is not None:
+                                hip.copy2d(ef.lo, cat.lo[:, :ef.C])
+                            else:
+                                cat.lo[:, :ef.C].zero_()
                         eng.launches += 1
                         o = cat.cols(ef.C, ef.C + h.C)
                     h = self.up[lvl].temporal_mixing[b].run(eng, h, out=o)
@@ -634,7 +647,11 @@ class VideoAutoencoderKLResi(_AutoencoderBase):
         for f in fea:
             t = torch.empty(f.rows, f.C, dtype=torch.float16, device=eng.device)
             hip.copy2d(f.v, t)
-            keep.append(Act(t, f.n, f.h, f.w))
+            tl = None
+            if f.lo is not None:                  # the features are residual-stream tensors of the encoder: their low plane goes along
+                tl = torch.empty(f.rows, f.C, dtype=torch.float16, device=eng.device)
+                hip.copy2d(f.lo, tl)
+            keep.append(Act(t, f.n, f.h, f.w, tl))
         return DiagonalGaussianDistribution(m), keep
 
     @torch.no_grad()

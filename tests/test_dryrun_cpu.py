@@ -18,6 +18,7 @@ class Recorder:
     def __init__(self):
         self.calls = []
         self.tiled = []
+        self.lo_writes = 0
 
     def ptrs(self):
         return [(name, tuple(p)) for name, p in self.calls]
@@ -35,8 +36,16 @@ def dry(monkeypatch):
 
     def igemm(a, w, out, *, mode=0, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None, act=0, alpha=1.0,
               beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0, M=None, N=None, K=None,
-              tap_inner=0, w2=None, **_):
+              tap_inner=0, w2=None, resid_lo=None, out_lo=None, **_):
         assert w2 is None or (w2.shape == w.shape and w2.dtype == w.dtype)
+        # low planes of the residual stream (MgldIGemm.Rlo / Clo): each mirrors its hi plane, fp16 only, never with GEGLU / batches
+        if resid_lo is not None:
+            assert resid is not None and resid_lo.shape == resid.shape and resid_lo.stride() == resid.stride() and resid_lo.dtype == torch.float16
+            assert resid_lo.data_ptr() % 16 == 0 and batch == 1
+        if out_lo is not None:
+            assert out_lo.shape == out.shape and out_lo.stride() == out.stride() and out.dtype == torch.float16 and out_lo.dtype == torch.float16
+            assert out_lo.data_ptr() % 16 == 0 and out_lo.data_ptr() != out.data_ptr() and batch == 1 and act != hip.ACT_GEGLU
+            rec.lo_writes += 1
         M = M if M is not None else out.shape[0]
         N = N if N is not None else w.shape[0]
         K = K if K is not None else w.shape[1]
@@ -86,7 +95,7 @@ def dry(monkeypatch):
     monkeypatch.setattr(hip, "gn_chunks", lambda rows: 1 if rows <= 64 else (rows + 63) // 64)
     monkeypatch.setattr(hip, "gn_fused_applies", lambda rows, c, g: rows <= 256 and (c // g) * (8 // __import__("math").gcd(c // g, 8)) <= 128)
     for name in ["gn_stats", "gn_apply", "spade_apply", "gn_fused", "layernorm", "temporal_attention", "softmax_rows", "linear_small",
-                 "timestep_embedding", "nchw_to_nhwc", "nhwc_to_nchw", "copy2d", "axpby"]:
+                 "timestep_embedding", "nchw_to_nhwc", "nhwc_to_nchw", "copy2d", "axpby", "axpby_lo"]:
         monkeypatch.setattr(hip, name, generic(name))
     monkeypatch.setattr(hip, "conv3p_applies", lambda *a: False)   # (a planner query into the library: keep the [N, K] weights)
     monkeypatch.setattr(hip, "tile_conv3p", E.tile_conv3p)         # (the device re-layout kernel -> the host statement of the same layout)
@@ -119,6 +128,37 @@ def test_unet_structcond_launch_plan(dry):
     same = sum(1 for a, b in zip(first, second) if a == b)
     assert same >= len(first) - 8, (same, len(first))   # only the host->device input staging tensors may move
     assert sum(1 for c in first if c[0] == "attention") == 2 * 16  # 16 transformer blocks: self + cross
+
+
+def test_residual_stream_low_planes_follow_the_scopes(dry, monkeypatch):
+    """engine.STREAM_LO_DEFAULT: inside the scopes it names every contraction that writes the residual stream also writes its low plane (the
+    stub checks each pair of planes mirrors its hi plane); MGLD_STREAM_LO=0 is the plain fp16 stream with the same launch sequence"""
+    eng, rec = dry
+    from mgld_vsr_amd import engine as E
+    from ldm.modules.diffusionmodules.openaimodel import InflatedEncoderUNetModelWT, InflatedUNetModelDualcondV2
+    unet, sc = InflatedUNetModelDualcondV2(**UNET_SMALL), InflatedEncoderUNetModelWT(**STRUCT_SMALL)
+    unet.set_engine(eng)
+    sc.set_engine(eng)
+    x, t, ctx = torch.randn(T, 4, 16, 16), torch.tensor([541] * T), torch.randn(1, 77, 64)
+    assert {"unet", "struct", "vae_dec"} <= eng.lo_scopes
+    scd = sc(x, t)
+    n_sc = rec.lo_writes
+    unet(x, t, context=ctx, struct_cond=scd)
+    n0 = len(rec.calls)
+    unet(x, t, context=ctx, struct_cond=scd)
+    names_on, n_unet = [c[0] for c in rec.calls[n0:]], rec.lo_writes - n_sc
+    # per UNet pass: the stem, down / upsample convolutions, every transformer's five projections onto the stream, the 1x1 skips, the two
+    # temporal mixes and the temporal attention's output projection (ResBlockDual's own output is written by the SPADE apply kernel)
+    assert n_sc > 0 and n_unet // 2 >= 16 * 5
+    monkeypatch.setenv("MGLD_STREAM_LO", "0")
+    eng2 = E.Engine(device="cpu", chunk_bytes=64 << 20)
+    assert not eng2.lo_scopes
+    unet.set_engine(eng2)
+    before = rec.lo_writes
+    unet(x, t, context=ctx, struct_cond=scd)
+    n1 = len(rec.calls)
+    unet(x, t, context=ctx, struct_cond=scd)
+    assert rec.lo_writes == before and [c[0] for c in rec.calls[n1:]] == names_on
 
 
 def test_unet_launch_plan_with_tiled_conv_weights(dry, monkeypatch):
