@@ -314,6 +314,11 @@ class Engine:
         self.pieces = None       # GraphPieces while a sharded step is recorded / replayed as hipGraph pieces
         self.w2_scopes = w2_scopes()   # precision scopes that run the second MFMA pass on the weight residual (split_residual)
         self.lo_scopes = stream_lo_scopes()   # scopes that keep the residual stream as two fp16 planes (Act.lo)
+        # measured choices (profiles/r06_stream_lo.md): the normalisations read both planes (hi alone: +6 % latent error for 1.3 % of time);
+        # the token stream INSIDE a transformer block (proj_in .. ff) stays one plane — its five projections per block are HBM-bound at the
+        # 64^2 level and the low plane there cost 3.2 % of a segment for 3 % of the latent's error
+        self.lo_norms = os.environ.get("MGLD_STREAM_LO_NORMS", "1") != "0"
+        self.lo_inner = os.environ.get("MGLD_STREAM_LO_INNER", "0") != "0"   # (A/B: inside the UNet, low planes only for frames of at most this many pixels)
         self._scope = []               # stack of active scope names (Engine.scope)
         # split-K scratch of the igemm launcher (fp32 partials of the low-resolution, deep-K convolutions)
         self._splitk_ws = hip.ensure_workspace(workspace_bytes) if self.device.type == "cuda" else None
@@ -551,9 +556,9 @@ class Engine:
         out.stats = None
         gsums, eps, kind, chunks = stats
         if gsums is None:
-            hip.gn_fused(x.v, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, lo_in=x.lo)
+            hip.gn_fused(x.v, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, lo_in=x.lo if self.lo_norms else None)
         else:
-            hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, kind=kind, chunks=chunks, x_lo=x.lo)
+            hip.gn_apply(x.v, gsums, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, kind=kind, chunks=chunks, x_lo=x.lo if self.lo_norms else None)
         self.launches += 1
         return out
 
@@ -593,7 +598,7 @@ class Engine:
     def layernorm(self, x, gamma, beta, eps=1e-5):
         xv = x.v if isinstance(x, Act) else x
         out = self.arena.alloc((xv.shape[0], xv.shape[1]), torch.float16)
-        hip.layernorm(xv, gamma, beta, out, eps, x_lo=x.lo if isinstance(x, Act) else None)
+        hip.layernorm(xv, gamma, beta, out, eps, x_lo=x.lo if (isinstance(x, Act) and self.lo_norms) else None)
         self.launches += 1
         return Act(out, x.n, x.h, x.w) if isinstance(x, Act) else out
 

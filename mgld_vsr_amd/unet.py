@@ -274,7 +274,7 @@ def _self_attention(eng, attn, xn, frames, N, resid, out=None):
                       o_strides=(N * C, C, d), scale=1.0 / LOG2E, v_rowmajor=True)
         eng.launches += 1
         wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-        return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=True)
+        return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=resid.lo is not None)
     wqk = eng.weight("qk", (attn.to_q.weight, attn.to_k.weight), lambda q, k: torch.cat([q, k], 0))
     wv = eng.weight("w", (attn.to_v.weight,), lambda v: v)
     qk = eng.linear(xn, wqk, None)
@@ -287,7 +287,7 @@ def _self_attention(eng, attn, xn, frames, N, resid, out=None):
                   o_strides=(N * C, C, d), scale=d ** -0.5)
     eng.launches += 2
     wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=True)
+    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=resid.lo is not None)
 
 
 class ContextCache:
@@ -329,7 +329,7 @@ def _cross_attention(eng, attn, xn, frames, N, ctx_cache, resid):
                   scale=d ** -0.5)
     eng.launches += 1
     wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), resid=resid, lo=True)
+    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), resid=resid, lo=resid.lo is not None)
 
 
 class BasicTransformerBlockV2(nn.Module):
@@ -353,7 +353,7 @@ class BasicTransformerBlockV2(nn.Module):
         wg, bg = eng.weight("geglu", (proj.weight, proj.bias), pack_geglu)
         g = eng.linear(ln(t, self.norm3), wg, bg, act=hip.ACT_GEGLU)
         w2 = eng.weight("w", (self.ff.net[2].weight,), lambda w: w)
-        return eng.linear(Act(g, t.n, t.h, t.w), w2, eng.f32("b", self.ff.net[2].bias), resid=t, lo=True)
+        return eng.linear(Act(g, t.n, t.h, t.w), w2, eng.f32("b", self.ff.net[2].bias), resid=t, lo=t.lo is not None)
 
 
 class SpatialTransformerV2(nn.Module):
@@ -376,7 +376,7 @@ class SpatialTransformerV2(nn.Module):
 
     def run(self, eng, x, ctx_cache, out=None):
         xn = eng.groupnorm(x, eng.f32("g", self.norm.weight), eng.f32("b", self.norm.bias), self.norm.eps, False)
-        t = eng.linear(xn, eng.weight("w", (self.proj_in.weight,), lambda w: w), eng.f32("b", self.proj_in.bias), lo=True)
+        t = eng.linear(xn, eng.weight("w", (self.proj_in.weight,), lambda w: w), eng.f32("b", self.proj_in.bias), lo=eng.lo_inner)
         t = self.transformer_blocks[0].run(eng, t, x.n, x.hw, ctx_cache)
         return eng.linear(t, eng.weight("w", (self.proj_out.weight,), lambda w: w), eng.f32("b", self.proj_out.bias), out=out, resid=x, lo=True)
 
