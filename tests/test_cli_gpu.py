@@ -103,7 +103,7 @@ def test_cli_reproduces_a_run_of_the_reference_script(tmp_path):
     assert max(m[f"harness_x0_patch{c}"] for c in range(4)) < 6e-3, m
     # uint8 frames: the float images agree to ~1e-3, so a pixel differs (by one level) only where its value sits next to a
     # rounding boundary
-    assert m["harness_hr_mean_abs_lsb"] < 0.04 and m["harness_hr_max_abs_lsb"] <= 1 and m["harness_hr_rel_l2"] < 1.7e-3, m
+    assert m["harness_hr_mean_abs_lsb"] < 0.04 and m["harness_hr_max_abs_lsb"] <= 1 and m["harness_hr_rel_l2"] < 1.6e-3, m
     assert np.abs(hr.reshape(T, -1, 3).astype(np.float64).mean(1) - g["hr_mean"]).max() < 0.5
 
 
@@ -179,8 +179,8 @@ def test_cli_reproduces_the_reference_script_at_the_production_schedule(tmp_path
     # round 5: high-precision first-stage encoder — the struct-cond latent of every patch agrees to 1.2e-5 (fp16 encoder: 9.7e-4), and with
     # it x_0 of these smooth frames came down from 1.0-1.8e-3 to 0.61-0.81e-3: under the north_star tolerance on every patch
     assert max(m[f"lat_patch{c}"] for c in range(4)) < 5e-5, m
-    assert max(m[f"x0_patch{c}"] for c in range(4)) < 1e-3, m
-    assert m["hr_rel_l2"] < 1e-3 and m["hr_max_abs_lsb"] <= 1, m
+    assert max(m[f"x0_patch{c}"] for c in range(4)) < 8.5e-4, m        # measured 0.55-0.77e-3
+    assert m["hr_rel_l2"] < 8.5e-4 and m["hr_max_abs_lsb"] <= 1, m          # measured 7.2e-4 (0.8 % of the bytes one level off)
 
 
 @pytest.mark.gpu
@@ -252,9 +252,9 @@ def test_fixed_size_cli_reproduces_the_reference_scripts(tmp_path, tag):
         with open(os.path.join(out, f"harness_{tag}_metrics.json"), "w") as fh:
             json.dump(m, fh, indent=1, sort_keys=True)
     # (1.3 x measured, profiles/r06_harness_old_metrics.json: flows 1.1e-6, no mask flips, x_0 1.18-1.25e-3, frames 1.2e-3)
-    assert all(m[f"{tag}_flow_s{k}"] < 1e-4 and m[f"{tag}_mask_flips_s{k}"] == 0 and m[f"{tag}_x0_s{k}"] < 1.6e-3 for k in range(2)), m
-    assert m[f"{tag}_hr_mean_abs_lsb"] < 0.035 and m[f"{tag}_hr_rel_l2"] < 1.6e-3, m
-    assert tag != "wlat" or m["wlat_npy"] < 1.6e-3, m
+    assert all(m[f"{tag}_flow_s{k}"] < 1e-4 and m[f"{tag}_mask_flips_s{k}"] == 0 and m[f"{tag}_x0_s{k}"] < 1.4e-3 for k in range(2)), m
+    assert m[f"{tag}_hr_mean_abs_lsb"] < 0.025 and m[f"{tag}_hr_rel_l2"] < 1.4e-3, m
+    assert tag != "wlat" or m["wlat_npy"] < 1.4e-3, m
 
 
 @pytest.mark.gpu
@@ -323,10 +323,10 @@ def test_fixed_size_cli_reproduces_the_reference_script_at_the_production_schedu
     assert m["flow"] < 3e-4 and m["mask_flips"] == 0.0, m
     # the sampler with the reference's flows / masks: latents to 1e-3 (measured 5.8e-4); frames one level, 1.1e-3 (the 128^2 frames are
     # dominated by the decoder's fp16 arithmetic: tests/test_nets_gpu.py decoder-only metrics)
-    assert m["x0_ref_flows"] < 1e-3 and m["hr_rel_l2_ref_flows"] < 1.3e-3 and m["hr_max_abs_lsb_ref_flows"] <= 1, m
+    assert m["x0_ref_flows"] < 6e-4 and m["hr_rel_l2_ref_flows"] < 1.15e-3 and m["hr_max_abs_lsb_ref_flows"] <= 1, m     # measured 4.6e-4 / 8.9e-4
     # end to end with this build's own RAFT flows (fp32 since round 5: they agree with the reference's to fp32 round-off, no mask pixel
     # flips): the same bounds as with the reference's flows handed in (the fp16 estimator of round 4 sat at x0 4.8e-3 / 2 levels)
-    assert m["x0"] < 1e-3 and m["hr_rel_l2"] < 1.3e-3 and m["hr_max_abs_lsb"] <= 1, m
+    assert m["x0"] < 6e-4 and m["hr_rel_l2"] < 1.15e-3 and m["hr_max_abs_lsb"] <= 1, m
 
 
 @pytest.mark.gpu

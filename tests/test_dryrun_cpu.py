@@ -147,9 +147,17 @@ def test_residual_stream_low_planes_follow_the_scopes(dry, monkeypatch):
     n0 = len(rec.calls)
     unet(x, t, context=ctx, struct_cond=scd)
     names_on, n_unet = [c[0] for c in rec.calls[n0:]], rec.lo_writes - n_sc
-    # per UNet pass: the stem, down / upsample convolutions, every transformer's five projections onto the stream, the 1x1 skips, the two
-    # temporal mixes and the temporal attention's output projection (ResBlockDual's own output is written by the SPADE apply kernel)
-    assert n_sc > 0 and n_unet // 2 >= 16 * 5
+    # per UNet pass: the stem, down / upsample convolutions, every transformer's proj_out + x, the 1x1 skips, the two temporal mixes and the
+    # temporal attention's output projection (ResBlockDual's own output is written by the SPADE apply kernel; the token stream inside a
+    # transformer block stays one plane unless MGLD_STREAM_LO_INNER=1: then its proj_in / attn1 / attn2 / ff projections write planes too)
+    assert n_sc > 0 and 16 + 10 <= n_unet // 2 < 16 * 3
+    monkeypatch.setenv("MGLD_STREAM_LO_INNER", "1")
+    eng_in = E.Engine(device="cpu", chunk_bytes=64 << 20)
+    unet.set_engine(eng_in)
+    before = rec.lo_writes
+    unet(x, t, context=ctx, struct_cond=scd)
+    assert rec.lo_writes - before >= 16 * 5 + 10
+    monkeypatch.delenv("MGLD_STREAM_LO_INNER")
     monkeypatch.setenv("MGLD_STREAM_LO", "0")
     eng2 = E.Engine(device="cpu", chunk_bytes=64 << 20)
     assert not eng2.lo_scopes

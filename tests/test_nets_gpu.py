@@ -59,7 +59,7 @@ def test_structcond_small_vs_golden(hip, small_nets):
     out = sc(g["lat"].cuda(), g["t"].cuda())
     assert set(out.keys()) == {"16", "8", "4", "2"}
     for k, v in out.items():
-        assert record(f"structcond_small_{k}", rel_l2(v, g[f"sc_{k}"])) < {"16": 1.25e-3, "8": 1.6e-3, "4": 1.95e-3, "2": 2.2e-3}[k]   # 1.3 x measured
+        assert record(f"structcond_small_{k}", rel_l2(v, g[f"sc_{k}"])) < {"16": 1.0e-3, "8": 1.3e-3, "4": 1.6e-3, "2": 1.65e-3}[k]   # 1.3 x measured (two-plane residual stream: 0.77 / 0.98 / 1.21 / 1.27e-3)
 
 
 def test_unet_small_vs_golden(hip, small_nets):
@@ -67,14 +67,14 @@ def test_unet_small_vs_golden(hip, small_nets):
     g = G("g_unet")
     sc = {k[3:]: v.cuda() for k, v in g.items() if k.startswith("sc_")}
     eps = unet(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].cuda(), struct_cond=sc)
-    assert record("unet_small", rel_l2(eps, g["eps"])) < 2.4e-3   # fp16-storage floor 1.8e-3 (tests/analysis/fp16_sim.py; DESIGN.md parity table)
+    assert record("unet_small", rel_l2(eps, g["eps"])) < 2.05e-3   # measured 1.57e-3 (round 5, one-plane stream: 1.85e-3; tests/analysis/resid_sim.py)
     # per-frame (non-uniform) timesteps go through the M = n embedding path
     t2 = torch.tensor([541, 20, 999])
     usd = {k: v for k, v in unet.state_dict().items()}
     sc_cpu = {k[3:]: v for k, v in g.items() if k.startswith("sc_")}
     ref = onets.unet_forward(usd, UNET_SMALL, g["x"], t2, g["ctx"], sc_cpu)
     eps2 = unet(g["x"].cuda(), t2.cuda(), context=g["ctx"].cuda(), struct_cond=sc)
-    assert record("unet_small_mixed_t", rel_l2(eps2, ref)) < 2.4e-3
+    assert record("unet_small_mixed_t", rel_l2(eps2, ref)) < 2.05e-3
 
 
 def test_unet_small_with_outlier_channels_vs_oracle(hip):
@@ -106,7 +106,7 @@ def test_unet_small_with_outlier_channels_vs_oracle(hip):
     eps = unet(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].cuda(), struct_cond={k: v.cuda() for k, v in sc_cpu.items()})
     assert torch.isfinite(eps).all() and torch.isfinite(ref).all()
     assert rel_l2(ref, g["eps"]) > 0.5                                          # the outliers do reach the output
-    assert record("unet_small_outlier_channels", rel_l2(eps, ref)) < 3e-3
+    assert record("unet_small_outlier_channels", rel_l2(eps, ref)) < 2.6e-3
 
 
 def test_vae_small_vs_golden(hip):
@@ -115,19 +115,19 @@ def test_vae_small_vs_golden(hip):
     vq = synth.fill_module_(VideoAutoencoderKLResi(ddconfig=dict(VAE_DD_SMALL), lossconfig={"target": "torch.nn.Identity"},
                                                    embed_dim=4), "vae")
     post, fea = vq.encode(g["x"].cuda())
-    assert record("vae_small_mean", rel_l2(post.mean, g["mean"])) < 2e-3
-    assert record("vae_small_logvar", rel_l2(post.logvar, g["logvar"])) < 2e-3
+    assert record("vae_small_mean", rel_l2(post.mean, g["mean"])) < 1.6e-3
+    assert record("vae_small_logvar", rel_l2(post.logvar, g["logvar"])) < 1.6e-3
     from mgld_vsr_amd.engine import Engine
     f0 = vq.engine().to_nchw(fea[0])
     f1 = vq.engine().to_nchw(fea[1])
-    assert record("vae_small_fea0", rel_l2(f0, g["fea0"])) < 1.6e-3 and record("vae_small_fea1", rel_l2(f1, g["fea1"])) < 1.8e-3
+    assert record("vae_small_fea0", rel_l2(f0, g["fea0"])) < 1.2e-3 and record("vae_small_fea1", rel_l2(f1, g["fea1"])) < 1.45e-3
     dec = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])
-    assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 2.8e-3          # fp16-storage floor 2.15e-3 (tests/analysis/fp16_sim.py)
+    assert record("vae_small_dec", rel_l2(dec, g["dec"])) < 1.95e-3          # measured 1.48e-3 (one-plane stream: 2.06e-3; tests/analysis/resid_sim.py)
     vq.decoder.fusion_w = 0.5                                   # the reference script's default --dec_w
     dec05 = vq.decode(g["z"].cuda(), [g["fea0"].cuda(), g["fea1"].cuda()])     # decoder alone: the reference's own features
-    assert record("vae_small_dec_w05", rel_l2(dec05, g["dec_w05"])) < 4e-3   # floor 3.2e-3: the fusion layers blend two fp16 feature sets
+    assert record("vae_small_dec_w05", rel_l2(dec05, g["dec_w05"])) < 2.8e-3   # measured 2.14e-3: the fusion layers blend two fp16 feature sets
     dec05p = vq.decode(g["z"].cuda(), fea)                                     # chained with the product's encoder features
-    assert record("vae_small_dec_w05_chained", rel_l2(dec05p, g["dec_w05"])) < 4.6e-3
+    assert record("vae_small_dec_w05_chained", rel_l2(dec05p, g["dec_w05"])) < 3.5e-3
     from scripts.wavelet_color_fix import adaptive_instance_normalization, wavelet_reconstruction
     assert rel_l2(adaptive_instance_normalization(g["dec"], g["style"]), g["adain"]) < 1e-5
     assert rel_l2(wavelet_reconstruction(g["dec"], g["style"]), g["wavelet"]) < 1e-5
@@ -166,7 +166,7 @@ def test_vae_decoder_with_outlier_channels_vs_oracle(hip):
     assert torch.isfinite(dec).all() and rel_l2(ref, g["dec"]) > 0.5
     # 4.5e-3 against 2.1e-3 without outliers: the fp16-stored residual stream now carries ~6.5e3 beside O(1) channels, and the GroupNorms
     # that follow divide both by the group's (outlier-dominated) deviation — the small channels keep the absolute rounding error of the large
-    assert record("vae_small_dec_outlier_channels", rel_l2(dec, ref)) < 5.5e-3
+    assert record("vae_small_dec_outlier_channels", rel_l2(dec, ref)) < 4.4e-3
 
 
 def _small_model():
@@ -206,9 +206,9 @@ def test_sample_small_vs_golden(hip, tag):
               time_replace=S, x_T=g[f"{tag}_xT"], noise=noise)
     fn = model.sample if tag == "plain" else (lambda **k: model.sample_canvas(tile_size=16, tile_overlap=8, batch_size_sample=1, **k))
     x0_ng = fn(**kw)
-    assert record(f"sample_{tag}_noguid", rel_l2(x0_ng, g[f"{tag}_x0_noguid"])) < 1.45e-3      # measured 1.08-1.10e-3 (reduced width, 4 steps)
+    assert record(f"sample_{tag}_noguid", rel_l2(x0_ng, g[f"{tag}_x0_noguid"])) < 1.25e-3      # measured 0.87-0.96e-3 (reduced width, 4 steps)
     x0 = fn(flows=flows, masks=masks, **kw)
-    assert record(f"sample_{tag}_guided", rel_l2(x0, g[f"{tag}_x0"])) < 1.45e-3                # measured 1.08-1.13e-3
+    assert record(f"sample_{tag}_guided", rel_l2(x0, g[f"{tag}_x0"])) < 1.25e-3                # measured 0.87-0.96e-3
     # hipGraph replay == eager launches, bit for bit
     x0_eager = fn(flows=flows, masks=masks, use_graph=False, **kw)
     assert torch.equal(x0_eager, x0)
@@ -232,20 +232,20 @@ def test_sample_loop_options_vs_golden(hip):
     def loop(**opt):       # p_sample_loop takes no `noise=`: route through sample() for the injected draws, p_sample_loop for the hooks
         return model._sample_loop(g["ctx"], g["lat"], shape, -10.0, None, None, g["xT"], S, S, False, None, g["noise"], None, True, hooks=opt)
     x = loop(start_T=600)
-    assert record("opts_start_T", rel_l2(x, g["x_start_T"])) < 1.15e-3
+    assert record("opts_start_T", rel_l2(x, g["x_start_T"])) < 9.5e-4
     # q_sample(x0, ts) inside the loop draws randn_like(x0) from the global generator, seeded 4242 in the golden run, one draw per step
     torch.manual_seed(4242)
     mn = torch.zeros(S, *shape)
     for i in reversed(range(S)):
         mn[i] = torch.randn(shape)
     x = loop(mask=g["mask"], x0=g["x0m"], mask_noise=mn)
-    assert record("opts_mask", rel_l2(x, g["x_mask"])) < 1.45e-3
+    assert record("opts_mask", rel_l2(x, g["x_mask"])) < 1.2e-3
     x = loop(adain_fea=g["adain_fea"])
-    assert record("opts_adain", rel_l2(x, g["x_adain"])) < 1.3e-3
+    assert record("opts_adain", rel_l2(x, g["x_adain"])) < 1.05e-3
     calls, imgs = [], []
     x = loop(callback=lambda i: calls.append((0, i)), img_callback=lambda img, i: (calls.append((1, i)), imgs.append(img.clone())))
     assert calls == [tuple(r) for r in g["cb_order"].tolist()]
-    assert record("opts_callbacks", rel_l2(torch.stack(imgs), g["cb_imgs"])) < 1.45e-3 and rel_l2(x, g["x_cb"]) < 1.45e-3
+    assert record("opts_callbacks", rel_l2(torch.stack(imgs), g["cb_imgs"])) < 1.2e-3 and rel_l2(x, g["x_cb"]) < 1.2e-3
     # the public entries accept the options (no NotImplementedError) and agree with the loop
     x2 = model.sample(cond=g["ctx"], struct_cond=g["lat"], guidance_scale=-10.0, batch_size=1, timesteps=S, time_replace=S, x_T=g["xT"],
                       noise=g["noise"], start_T=600)
@@ -267,7 +267,7 @@ def test_canvas_loop_start_T_vs_golden(hip):
     st = int(g["start_T"][0])
     x = model._sample_loop(g["ctx"], g["lat"], shape, -10.0, None, None, g["xT"], S, S, False, None, g["noise"], (16, 8), True,
                            hooks={"start_T": st})
-    assert record("opts_canvas_start_T", rel_l2(x, g["x_start_T"])) < 1.4e-3
+    assert record("opts_canvas_start_T", rel_l2(x, g["x_start_T"])) < 1.15e-3
     # the plain loop's rule on the same inputs gives ANOTHER result (ori_timesteps[i] <= 3 keeps index 0 only): the two rules are distinct
     y = model._sample_loop(g["ctx"], g["lat"], shape, -10.0, None, None, g["xT"], S, S, False, None, g["noise"], None, True, hooks={"start_T": st})
     assert rel_l2(y, g["x_start_T"]) > 1e-2
@@ -296,11 +296,11 @@ def test_single_step_api_and_decode_first_stage_vs_golden(hip):
                                                                 t_replace=t_rep[:1], tile_size=16, tile_overlap=8, batch_size=1, tile_weights=tw)
             z = model.p_sample_canvas(x, g["ctx"], lat, ts, guidance_scale=-10.0, flows=flows, masks=masks, t_replace=t_rep[:1], tile_size=16,
                                       tile_overlap=8, batch_size=1, tile_weights=tw, noise=nz)
-        assert record(f"pstep_{tag}_x0", rel_l2(x0, g[f"{tag}_x0"])) < 1.55e-3          # measured 1.10 / 1.17e-3 (one network evaluation)
-        assert record(f"pstep_{tag}_mean", rel_l2(mean, g[f"{tag}_mean"])) < 1.4e-3
+        assert record(f"pstep_{tag}_x0", rel_l2(x0, g[f"{tag}_x0"])) < 1.25e-3          # measured 0.87 / 0.96e-3 (one network evaluation)
+        assert record(f"pstep_{tag}_mean", rel_l2(mean, g[f"{tag}_mean"])) < 1.15e-3
         assert abs(float(logvar.reshape(-1)[0]) - float(g[f"{tag}_logvar"].reshape(-1)[0])) < 1e-6
         assert abs(float(var.reshape(-1)[0]) - float(g[f"{tag}_var"].reshape(-1)[0])) < 1e-9
-        assert record(f"pstep_{tag}_z", rel_l2(z, g[f"{tag}_z"])) < 1.35e-3
+        assert record(f"pstep_{tag}_z", rel_l2(z, g[f"{tag}_z"])) < 1.1e-3
     dec = model.decode_first_stage(g["dec_z"].cuda())
     assert dec.shape == g["dec_out"].shape
     assert record("first_stage_image_decode", rel_l2(dec, g["dec_out"])) < 2e-3
@@ -345,9 +345,9 @@ def test_unet_fullwidth_vs_oracle(hip):
         eps_ref = onets.unet_forward(unet.state_dict(), ucfg, x, t, ctx, sc_ref)
     sc_out = sc(lat.cuda(), t.cuda())
     for k in sc_ref:
-        assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < {"32": 1.0e-3, "16": 1.25e-3, "8": 1.5e-3, "4": 1.7e-3}[k]   # 1.3 x measured
+        assert record(f"structcond_full_{k}", rel_l2(sc_out[k], sc_ref[k])) < {"32": 8.3e-4, "16": 1.0e-3, "8": 1.2e-3, "4": 1.3e-3}[k]   # 1.3 x measured
     eps = unet(x.cuda(), t.cuda(), context=ctx.cuda(), struct_cond={k: v.cuda() for k, v in sc_ref.items()})
-    assert record("unet_full", rel_l2(eps, eps_ref)) < 2.4e-3
+    assert record("unet_full", rel_l2(eps, eps_ref)) < 1.9e-3       # measured 1.49e-3 (one-plane stream: 1.79e-3)
 
 
 def test_pipeline_small_end_to_end_vs_oracle(hip):
@@ -391,7 +391,7 @@ def test_pipeline_small_end_to_end_vs_oracle(hip):
     # and moves +-15 % between equally accurate kernel variants (8.9e-4 with the im2col conv, 1.05e-3 with the patch conv;
     # per-op parity identical, see unet_small / vae_small).  The 1e-3 bar itself is asserted on the full-width (SD-2.1
     # shaped) networks in test_pipeline_fullwidth_end_to_end_vs_oracle; this case guards against regressions.
-    assert record("e2e_small_frames", rel_l2(out, ref)) < 1.3e-3
+    assert record("e2e_small_frames", rel_l2(out, ref)) < 9e-4
 
 
 def test_pipeline_single_frame_vs_oracle(hip):
@@ -427,8 +427,8 @@ def test_pipeline_single_frame_vs_oracle(hip):
         _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
-    assert record("e2e_single_frame_latent", rel_l2(lat, x0)) < 1.9e-3
-    assert record("e2e_single_frame_frames", rel_l2(out, ref)) < 1.7e-3
+    assert record("e2e_single_frame_latent", rel_l2(lat, x0)) < 1.2e-3
+    assert record("e2e_single_frame_frames", rel_l2(out, ref)) < 1.05e-3
 
 
 def test_pipeline_config0_fullwidth_vs_reference(hip):
@@ -457,12 +457,12 @@ def test_pipeline_config0_fullwidth_vs_reference(hip):
            "c1_full_latent": rel_l2(lat, g["x0"]), "c1_full_frames": rel_l2(out[:, :, ::4, ::4], g["out_s4"])}
     for k, v in got.items():
         record(k, v)
-    assert got["c1_full_structcond_8"] < 2e-3 and got["c1_full_vae_fea0"] < 2e-3
-    assert got["c1_full_unet_eps"] < 2.6e-3 and got["c1_full_decoder"] < 2.5e-3
-    # the outputs, at the north_star tolerance.  The sampled latent measures 9.6e-4.  The colour-fixed frame of this one-frame config is the
-    # worst case of the path: it inherits the video decoder's single-evaluation error (2.0e-3 with plain fp16 weights -> frame 1.031e-3);
-    # with the weight-residual pass on the decoder (MgldIGemm.W2, engine.W2_DEFAULT) it measures 0.986e-3 (profiles/r03_w2_scopes_c1.json).
-    assert got["c1_full_latent"] < 1e-3 and got["c1_full_frames"] < 1e-3, got
+    assert got["c1_full_structcond_8"] < 1.4e-3 and got["c1_full_vae_fea0"] < 1.1e-3      # measured 1.07e-3 / 8.5e-4
+    assert got["c1_full_unet_eps"] < 2.2e-3 and got["c1_full_decoder"] < 1.75e-3           # measured 1.72e-3 / 1.36e-3 (T = 1: the decoder's worst case)
+    # the outputs: north_star's 1e-3, asserted with 15 % of margin.  Round 5 measured latent 8.9e-4 / frames 9.8e-4 (the one-frame config inherits the
+    # video decoder's single-evaluation error); with the residual stream on two fp16 planes (engine.STREAM_LO_DEFAULT): 7.25e-4 / 7.04e-4
+    # (profiles/r06_stream_lo.md)
+    assert got["c1_full_latent"] < 8.5e-4 and got["c1_full_frames"] < 8.5e-4, got
     assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
 
 
@@ -501,7 +501,7 @@ def test_pipeline_frame_sharded_matches_unsharded(hip):
             assert rp.pos == len(rec.trace)                               # identical communication sequence
             assert o.shape[0] == Tn // world
             worst = max(worst, rp.worst, rel_l2(o, out0[sh.f0:sh.f1]), rel_l2(l, lat0[sh.f0:sh.f1]))
-    assert record("frame_sharded_vs_unsharded", worst) < 1.1e-3            # tile configs differ with M: fp16-level only
+    assert record("frame_sharded_vs_unsharded", worst) < 7.5e-4            # tile configs differ with M: fp16-level only
     # the same virtual ranks with the step replayed as hipGraph PIECES around its collectives (engine.GraphPieces: 2 halo
     # exchanges + the temporal-attention gather + the guidance gather = 5 pieces per step): bit-identical to eager launches
     for world, r in ((2, 1), (4, 2)):
@@ -559,7 +559,7 @@ def test_sample_canvas_tile_sharded_matches_unsharded(hip):
     finally:
         eng.tile_shard = None
     assert record("tile_sharded_vs_unsharded", worst) < 1e-3     # fewer tiles per pass -> other tile configs: fp16-level only
-    assert record("sample_canvas_guided_ref", rel_l2(x0, g["canvas_x0"])) < 1.45e-3
+    assert record("sample_canvas_guided_ref", rel_l2(x0, g["canvas_x0"])) < 1.25e-3
 
 
 def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
@@ -596,11 +596,11 @@ def test_pipeline_fullwidth_end_to_end_vs_oracle(hip):
         _, _, fea = onets.vae_moments(vq.state_dict(), dd, x)
         dec = onets.vae_decode(vq.state_dict(), dd, x0 / 0.18215, fea)
         ref = torch.clamp((ocf.adaptive_instance_normalization(dec, x) + 1.0) / 2.0, 0.0, 1.0)
-    assert record("e2e_full_latent", rel_l2(lat, x0)) < 1.3e-3
+    assert record("e2e_full_latent", rel_l2(lat, x0)) < 1e-3
     # the full-width video decoder alone, fed the ORACLE's latents and encoder features (measured 1.67e-3: the fp16-operand floor of
     # a single network evaluation; the frames below meet the 1e-3 bar because AdaIN renormalises per plane)
-    assert record("e2e_full_decoder_only", rel_l2(vq.decode(x0.cuda() / 0.18215, [f.cuda() for f in fea]), dec)) < 2.2e-3
-    assert record("e2e_full_frames", rel_l2(out, ref)) < 1e-3      # north_star: outputs within 1e-3 rel-L2 (measured 9.5e-4)
+    assert record("e2e_full_decoder_only", rel_l2(vq.decode(x0.cuda() / 0.18215, [f.cuda() for f in fea]), dec)) < 1.3e-3
+    assert record("e2e_full_frames", rel_l2(out, ref)) < 8.5e-4      # north_star: outputs within 1e-3 rel-L2, kept with 15 % of margin (measured 6.3e-4)
 
 
 def test_sample_lr_images_guidance_vs_reference(hip):
@@ -619,9 +619,9 @@ def test_sample_lr_images_guidance_vs_reference(hip):
     kw = dict(cond=ctx, struct_cond=c["lat"], guidance_scale=-10.0, batch_size=1, timesteps=S, time_replace=S, x_T=c["xT"], noise=noise,
               lr_images=c["lr"])
     x0 = model.sample(**kw)
-    assert record("sample_lr_images", rel_l2(x0, g["x0_lr"])) < 1.45e-3
+    assert record("sample_lr_images", rel_l2(x0, g["x0_lr"])) < 1.15e-3
     x0b = model.sample(flows=(c["ff"][None], c["fb"][None]), masks=(g["focc"][None, :, None], g["bocc"][None, :, None]), **kw)
-    assert record("sample_lr_images_and_flows", rel_l2(x0b, g["x0_lr_flows"])) < 1.45e-3
+    assert record("sample_lr_images_and_flows", rel_l2(x0b, g["x0_lr_flows"])) < 1.15e-3
     assert rel_l2(g["x0_lr"], g["x0_lr_flows"]) > 3e-4              # (the second term acts on this fixture)
     # the flows the term uses: this build's RAFT on the resized LR frames vs the reference's
     res = hip.resize_bicubic(c["lr"].cuda(), (c["h"], c["w"]))
@@ -656,7 +656,7 @@ def test_sample_small_50_steps_vs_oracle(hip):
                           time_replace=S, x_T=xT, noise=noise)
         ref = osamp.sample(usd, UNET_SMALL, ssd, STRUCT_SMALL, ctx, lat, xT, [noise[S - 1 - k] for k in range(S)], S,
                            guidance_scale=-10.0, flows=fl, masks=mk)
-        assert record(f"sample50_small_{tag}", rel_l2(x0, ref)) < 7.5e-4         # measured 5.6 / 5.7e-4 (50 steps average the per-evaluation error down)
+        assert record(f"sample50_small_{tag}", rel_l2(x0, ref)) < 6.8e-4         # measured 5.2e-4 (50 steps average the per-evaluation error down)
 
 
 def test_raft_flow_vs_oracle(hip):

@@ -26,6 +26,7 @@ from test_nets_gpu import G, record, rel_l2  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3          # BASELINE.json north_star: outputs within 1e-3 rel-L2 of the reference
+MARGIN = 0.85       # ... asserted with 15 % of headroom (round 6: the worst full-width output is the smooth workload's 50-step latent, 8.3e-4)
 
 
 def _have(name):
@@ -68,11 +69,11 @@ def test_workload_vs_reference(hip, case, S):
     # the first-stage latent: high-precision encoder since round 5 (fp32 round-off; the fp16 encoder sat at 0.8-1.1e-3 and, because this
     # latent conditions every step, put x_0 of the smooth workload at 2.4e-3)
     assert got[f"work_{case}_S{S}_init"] < 2e-5, got
-    # c2s at S = 4: the OUTPUTS (frames) are asserted at the tolerance; the sampled latent of the 4-step schedule on smooth content sits at
-    # 1.5e-3 — four steps do not average the per-evaluation fp16 error of the UNet (1.8e-3) down the way the 50-step production schedule
-    # does (8.9e-4 there, asserted below at TOL), and on low-pass content the latent's norm is carried by a few coarse modes.  Stated
-    # bound for that one case: 1.8e-3 (measured 1.52e-3).
-    lat_tol = 1.8e-3 if (case, S) == ("c2s", 4) else TOL
-    assert got[f"work_{case}_S{S}_latent"] < lat_tol and got[f"work_{case}_S{S}_frames"] < TOL, got
-    assert got[f"work_{case}_S{S}_frames_w05"] < TOL, got
+    # c2s at S = 4: the OUTPUTS (frames, 2.2e-4) are asserted at the tolerance; the sampled latent of the 4-step schedule on smooth content sits at
+    # 1.38e-3 — four steps do not average the per-evaluation fp16 error of the UNet (1.5e-3) down the way the 50-step production schedule
+    # does (8.3e-4 there, asserted below with the margin), and on low-pass content the latent's norm is carried by a few coarse modes.  Stated
+    # bound for that one case: 1.65e-3 (S = 4 is not a BASELINE schedule for this config).
+    lat_tol = 1.65e-3 if (case, S) == ("c2s", 4) else MARGIN * TOL
+    assert got[f"work_{case}_S{S}_latent"] < lat_tol and got[f"work_{case}_S{S}_frames"] < MARGIN * TOL, got
+    assert got[f"work_{case}_S{S}_frames_w05"] < MARGIN * TOL, got
     assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
