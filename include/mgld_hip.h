@@ -134,10 +134,28 @@ typedef struct MgldIGemm {
                              as a contraction operand keeps reading the hi plane as it is (tests/analysis/resid_sim.py)    */
   void* Clo;              /* NULL, or where the kernel also stores the low plane of its fp16 output: fp16 [M, ldc], Clo = fp16((x - fp16(x)) * 2^11)
                              of the fp32 value x it rounds into C.  Not with out_f32 / GEGLU / batch > 1.                                       */
+  /* ---- LayerNorm folded into the projection that consumes it (LINEAR problems the ping-pong kernel takes: mgld_igemm_row_chunks > 0) ----
+   * attention.py:427-435: `attn1(norm1(x))`, `attn2(norm2(x))`, `ff(norm3(x))` — LayerNorm over the K = C channels of a token row followed by
+   * a linear map is   y[m, n] = rstd[m] * (sum_k x[m, k] g[k] W[n, k]  -  mean[m] * s[n]) + b'[n],   s[n] = sum_k g[k] W[n, k],
+   * b'[n] = sum_k beta[k] W[n, k] + bias[n]:  the contraction runs on the RAW token rows against W' = W diag(g) (packed on the host), and
+   * the epilogue applies the per-row scale and the rank-one mean correction.  No normalised copy of the tokens is written or read, no
+   * LayerNorm launch, and the operand skips one rounding to fp16.  The per-row sums come from the kernel that PRODUCED the token rows:     */
+  float* row_part;        /* producer side.  NULL, or float [row_chunks][M][2]: the kernel also writes, per output row and column tile, the (sum, sumsq)
+                             of the values it stores in that tile (taken before their rounding to fp16); row_chunks = mgld_igemm_row_chunks(p)    */
+  const float* ln_part;   /* consumer side.  NULL, or the row sums of A's rows as written through row_part: float [ln_chunks][M][2]; mean / rstd of
+                             row m over the K channels = the chunk sums added up, / K, eps = ln_eps.  The epilogue becomes
+                             act(rstd * (acc - mean * ln_s[n]) + bias[n] + rowvec) ...; W must be W' and bias b' as above (GEGLU: in the packed
+                             row order of W).                                                                                                      */
+  const float* ln_s;      /* [N] the column sums s[n] of W' (fp32, of the fp16-rounded W' so that the correction cancels what the MFMA summed)    */
+  int32_t ln_chunks;
+  float ln_eps;
 } MgldIGemm;
 
 /* tiles per frame of the statistics output (see gn_part), or 0 when the kernel picked for this problem does not produce it */
 int mgld_igemm_gn_chunks(const MgldIGemm* p);
+/* column tiles of the row-statistics output (see row_part), or 0 when the kernel picked for this problem does not produce it / does not take
+ * ln_part (today: the ping-pong LINEAR kernels produce and consume; everything else 0, and a launch with either field set is refused) */
+int mgld_igemm_row_chunks(const MgldIGemm* p);
 
 int mgld_igemm(const MgldIGemm* p, void* stream);
 /* block tile the launcher selects for this problem, encoded BM*1000+BN, plus splits*1000000 when the problem is

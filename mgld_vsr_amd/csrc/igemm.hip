@@ -752,6 +752,13 @@ extern "C" int mgld_igemm_gn_chunks(const MgldIGemm* p) {
   return 0;
 }
 
+// row statistics (MgldIGemm.row_part) / folded LayerNorm (ln_part): column tiles when the ping-pong LINEAR kernel takes the problem, else 0
+extern "C" int mgld_igemm_row_chunks(const MgldIGemm* p) {
+  if (!p) return 0;
+  int cfg;
+  return ppgemm_plan(p, &cfg) ? ppgemm_row_chunks(p, cfg) : 0;
+}
+
 // name of the kernel template instantiation the launcher runs for this problem, spelled as rocprofv3 prints it
 extern "C" int mgld_igemm_kernel_name(const MgldIGemm* p, char* buf, int buflen) {
   MGLD_REQUIRE(p && buf && buflen > 0, "igemm_kernel_name: null");
@@ -832,6 +839,7 @@ extern "C" int mgld_igemm(const MgldIGemm* p, void* stream) {
   int cfg, splits, kchunk;
   if (p->gn_part) MGLD_REQUIRE(mgld_igemm_gn_chunks(p) > 0 && ((((uintptr_t)p->gn_part) & 3) == 0), "igemm: gn_part set, but the kernel picked for this problem does not write statistics (mgld_igemm_gn_chunks)");
   if (ppgemm_plan(p, &cfg)) return dispatch_ppgemm(p, s, cfg);
+  MGLD_REQUIRE(!p->row_part && !p->ln_part, "igemm: row_part / ln_part set, but the kernel picked for this problem takes neither (mgld_igemm_row_chunks)");
   if (conv3r_plan(p, &cfg, &splits)) return dispatch_conv3r(p, s, cfg, splits);
   { int lg_; if (pptconv_plan(p, &cfg, &lg_)) return dispatch_pptconv(p, s, cfg, lg_); }
   if (conv3q_plan(p, &cfg, &splits, &kchunk)) return dispatch_conv3q(p, s, cfg, splits, kchunk);

@@ -23,6 +23,7 @@ void conv3q_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
 bool ppgemm_plan(const MgldIGemm* p, int* id);
 int dispatch_ppgemm(const MgldIGemm* p, hipStream_t s, int id);
 void ppgemm_kernel_name(const MgldIGemm* p, int id, char* buf, int buflen);
+int ppgemm_row_chunks(const MgldIGemm* p, int id);   // column tiles of configuration `id` (MgldIGemm.row_part)
 // conv3r.hip (ping-pong patch convolutions)
 bool conv3r_plan(const MgldIGemm* p, int* id, int* splits);
 int dispatch_conv3r(const MgldIGemm* p, hipStream_t s, int id, int splits);

@@ -55,6 +55,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct PPEpi {
   const float* bias; const float* rowvec; const f16* R; f16* C;
   const f16* Rlo; f16* Clo;    // low planes of the residual / the output (MgldIGemm.Rlo / Clo), or null
+  // LayerNorm folded into this projection (MgldIGemm.ln_part): out = act(rstd_m (acc - mean_m s_n) + bias_n); ln_M = rows of one chunk of ln_part
+  const float* ln_part = nullptr; const float* ln_s = nullptr; int ln_chunks = 0, ln_M = 0; float ln_invK = 0.f, ln_eps = 0.f;
+  // row statistics of what this tile stores (MgldIGemm.row_part): this WAVE's slot of the block table in LDS, [BM rows][2] floats, or null
+  float* row_tab = nullptr;
   int rows_per_frame, ld_rowvec, ldr, ldc, act; float alpha, beta;
   bool noswap;     // A/B and bring-up: every fragment by 8-byte stores (no v_permlane16_swap pairing)
 };
@@ -91,15 +95,33 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
       const int fr = (!GEGLU && e.rowvec && m >= 0) ? m / e.rows_per_frame : -1;
       if (fr != fr_loaded && (m >= 0 || fr_loaded == -2)) load_cv(fr);
     }
+    // folded LayerNorm: this row's (mean, rstd) from the producer's chunk sums
+    float ln_mu = 0.f, ln_rs = 1.f;
+    if (e.ln_part && m >= 0) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = 0; c < e.ln_chunks; ++c) {
+        const f32x2 t = *(const f32x2*)(e.ln_part + ((int64_t)c * e.ln_M + m) * 2);
+        s1 += t[0]; s2 += t[1];
+      }
+      ln_mu = s1 * e.ln_invK;
+      ln_rs = __builtin_amdgcn_rsqf(fmaxf(s2 * e.ln_invK - ln_mu * ln_mu, 0.f) + e.ln_eps);
+    }
+    // (the column sums s_n are re-read per fragment from L1 instead of being held like the bias: ten more live f32x4 spilled the 256 x 320 tile)
+    auto ln_of = [&](const f32x4 a, const int f) -> f32x4 {
+      if (!e.ln_part) return a;
+      const f32x4 sn = *(const f32x4*)(e.ln_s + n0 + f * 16 + 4 * q);
+      return (a - ln_mu * sn) * ln_rs;
+    };
     auto out_frag = [&](const int f) -> f32x4 {      // output fragment f of this row block, epilogue arithmetic applied (not the residual)
       if constexpr (GEGLU) {
         const f32x4 bv = cv[f], bg = cv[2 + f];
-        const e2 v0 = pk(acc[f][mi][0] + bv[0], acc[f][mi][1] + bv[1]), v1 = pk(acc[f][mi][2] + bv[2], acc[f][mi][3] + bv[3]);
-        const e2 g0 = gelu2(pk(acc[2 + f][mi][0] + bg[0], acc[2 + f][mi][1] + bg[1])), g1 = gelu2(pk(acc[2 + f][mi][2] + bg[2], acc[2 + f][mi][3] + bg[3]));
+        const f32x4 av = ln_of(acc[f][mi], f), ag = ln_of(acc[2 + f][mi], 2 + f);
+        const e2 v0 = pk(av[0] + bv[0], av[1] + bv[1]), v1 = pk(av[2] + bv[2], av[3] + bv[3]);
+        const e2 g0 = gelu2(pk(ag[0] + bg[0], ag[1] + bg[1])), g1 = gelu2(pk(ag[2] + bg[2], ag[3] + bg[3]));
         const e2 r0 = v0 * g0, r1 = v1 * g1;
         return f32x4{r0[0] * alpha, r0[1] * alpha, r1[0] * alpha, r1[1] * alpha};
       } else {
-        f32x4 v = acc[f][mi] + cv[f];
+        f32x4 v = ln_of(acc[f][mi], f) + cv[f];
         if (e.act == MGLD_ACT_SILU) {
           const e2 s0 = silu2(pk(v[0], v[1])), s1 = silu2(pk(v[2], v[3]));
           v = f32x4{s0[0], s0[1], s1[0], s1[1]};
@@ -107,6 +129,7 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
         return v * alpha;
       }
     };
+    float rsum = 0.f, rsq = 0.f;                     // row_tab: this lane's share of row m's (sum, sumsq) over the wave's columns
     auto store4 = [&](const int f) {                 // fragment f by 8-byte stores of 4 channels
       f32x4 a = out_frag(f);
       if (m < 0) return;
@@ -125,10 +148,21 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
       const f16x4 o = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
       *(f16x4*)(e.C + (int64_t)m * e.ldc + n) = o;
       if (e.Clo) *(f16x4*)(e.Clo + (int64_t)m * e.ldc + n) = f16x4{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3])};
+      if (e.row_tab) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rsum += a[r]; rsq += a[r] * a[r]; }
+      }
+    };
+    auto row_flush = [&]() {                         // the four lane rows q hold the same output row: add them up, lane row 0 writes the wave's slot
+      if (!e.row_tab) return;
+      rsum += __shfl_xor(rsum, 16, 64); rsq += __shfl_xor(rsq, 16, 64);
+      rsum += __shfl_xor(rsum, 32, 64); rsq += __shfl_xor(rsq, 32, 64);
+      if (q == 0) *(f32x2*)(e.row_tab + (mi * 16 + (lane & 15)) * 2) = f32x2{rsum, rsq};
     };
     if (e.noswap) {
 #pragma unroll
       for (int f = 0; f < NO; ++f) store4(f);
+      row_flush();
       continue;
     }
     // pairs of fragments -> 16-byte stores: after the swap, lane (row q) holds fragment 2 pr + (q & 1), channels 8 (q >> 1) .. + 8
@@ -158,8 +192,13 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
       if (e.Clo)
         *(f16x8*)(e.Clo + (int64_t)m * e.ldc + n) = f16x8{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3]),
                                                           lo_plane(b[0], o[4]), lo_plane(b[1], o[5]), lo_plane(b[2], o[6]), lo_plane(b[3], o[7])};
+      if (e.row_tab) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rsum += a[r] + b[r]; rsq += a[r] * a[r] + b[r] * b[r]; }
+      }
     }
     if constexpr (NO & 1) store4(NO - 1);            // unpaired last fragment
+    row_flush();
   }
 }
 

@@ -150,6 +150,11 @@ __global__ __launch_bounds__(512) void ppgemm_kernel(const MgldIGemm p, const in
   e.bias = p.bias; e.rowvec = p.rowvec; e.R = (const f16*)p.R; e.C = (f16*)p.C; e.Rlo = (const f16*)p.Rlo; e.Clo = (f16*)p.Clo;
   e.rows_per_frame = p.rows_per_frame; e.ld_rowvec = p.ld_rowvec; e.ldr = p.ldr; e.ldc = p.ldc; e.act = p.act; e.alpha = p.alpha; e.beta = p.beta;
   e.noswap = (order & 0x100) != 0;
+  if (p.ln_part) { e.ln_part = p.ln_part; e.ln_s = p.ln_s; e.ln_chunks = p.ln_chunks; e.ln_M = p.M; e.ln_invK = 1.f / (float)p.K; e.ln_eps = p.ln_eps; }
+  // row statistics of the output (MgldIGemm.row_part): every wave writes its columns' share of its rows into the block table (the stages are
+  // dead: both wave groups are past their last fragment read), the WGN shares of a row are added after a block barrier
+  float* const rtab = (float*)smem;                // [WGN][BM][2]
+  if (!GEGLU && p.row_part) e.row_tab = rtab + ((wn * BM) + wm * WM) * 2;
   const int mrow = bm0 + wm * WM + l15;
   if constexpr ((PPG & 4) && GEGLU) {             // (the GEGLU tile written as a plain tile of half the width: store pattern kept, arithmetic dropped)
     e.act = MGLD_ACT_NONE;
@@ -162,6 +167,15 @@ __global__ __launch_bounds__(512) void ppgemm_kernel(const MgldIGemm p, const in
     return;
   }
   pp_epilogue<MI, NI, GEGLU>(e, acc, lane, bn0 + wn * WN, [&](const int mi) { return mrow + mi * 16; });
+  if (!GEGLU && p.row_part) {
+    __syncthreads();
+    for (int r = tid; r < BM; r += 512) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGN; ++w) { s1 += rtab[(w * BM + r) * 2]; s2 += rtab[(w * BM + r) * 2 + 1]; }
+      *(f32x2*)(p.row_part + ((int64_t)tile_n * p.M + bm0 + r) * 2) = f32x2{s1, s2};
+    }
+  }
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------------------------------
@@ -226,6 +240,8 @@ bool ppgemm_plan(const MgldIGemm* p, int* id) {
   if (lda_ < p->K || ldw_ < p->K || 320 * lda_ * 2 + (int64_t)p->K * 2 >= 0x7fffffffLL || 320 * ldw_ * 2 + (int64_t)p->K * 2 >= 0x7fffffffLL) return false;
   if ((p->ldc & 7) || (((uintptr_t)p->C) & 15) || (p->R && ((p->ldr & 7) || (((uintptr_t)p->R) & 15)))) return false;
   if ((p->bias && (((uintptr_t)p->bias) & 15)) || (p->rowvec && ((((uintptr_t)p->rowvec) & 15) || (p->ld_rowvec & 3)))) return false;
+  if (p->ln_part && (!p->ln_s || p->ln_chunks <= 0 || (((uintptr_t)p->ln_s) & 15) || (((uintptr_t)p->ln_part) & 7))) return false;
+  if (p->row_part && (p->act == MGLD_ACT_GEGLU || (((uintptr_t)p->row_part) & 7))) return false;
   if (p->tune > 20) {
     if (!pp_cfg_fits(p, p->tune - 21)) return false;
     *id = p->tune - 21;
@@ -273,6 +289,8 @@ bool ppgemm_plan(const MgldIGemm* p, int* id) {
   *id = bid;
   return true;
 }
+
+int ppgemm_row_chunks(const MgldIGemm* p, int id) { return p->N / PP_CFG[id].bn; }
 
 int dispatch_ppgemm(const MgldIGemm* p, hipStream_t s, int id) {
   const bool g = p->act == MGLD_ACT_GEGLU;

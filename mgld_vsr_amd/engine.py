@@ -163,7 +163,7 @@ def stream_lo_scopes():
 # ------------------------------------------------------------------------------------------------------------------
 class Act:
     """Token-major (NHWC) activation: `v` is a 2-D fp16 view [n*h*w, C] with row stride ld >= C."""
-    __slots__ = ("v", "n", "h", "w", "stats", "lo")
+    __slots__ = ("v", "n", "h", "w", "stats", "lo", "rstats")
 
     def __init__(self, v, n, h, w, lo=None):
         assert v.dim() == 2 and v.shape[0] == n * h * w, (v.shape, n, h, w)
@@ -172,6 +172,9 @@ class Act:
         # that take the tensor as a contraction operand read v alone; normalisations and residual adds read both; whoever writes v writes lo.
         assert lo is None or (lo.shape == v.shape and lo.stride() == v.stride() and lo.dtype == v.dtype)
         self.lo = lo
+        # per-ROW (sum, sumsq) over all channels of this tensor, written by the projection that produced it (Engine.linear(rowstats=True)):
+        # (float32 [chunks, rows, 2], chunks) — what a LayerNorm folded into the consuming projection needs (Engine.linear_ln); None otherwise
+        self.rstats = None
         # GroupNorm statistics of THIS tensor written by the kernel that produced it (Engine.conv3x3(stats=True), spade_apply(want_stats=True)):
         # (sums tensor, hip.GN_* kind, chunks per frame, groups or None); Engine.gn_stats() then launches nothing.  Any op that writes into
         # an existing Act (`out=`) clears it first.
@@ -298,6 +301,10 @@ class Engine:
     GROUPS = 32
     GN_FUSED = os.environ.get("MGLD_GN_FUSED", "1") != "0"    # single-launch GroupNorm for frames of <= 256 rows
     GN_PRODUCER = os.environ.get("MGLD_GN_PRODUCER", "1") != "0"   # GroupNorm statistics written by the kernel that produces the tensor
+    LN_FOLD = os.environ.get("MGLD_LN_FOLD", "1") != "0"           # LayerNorm folded into the projection that consumes it (linear_ln)
+    # ... also into the GEGLU projection: measured SLOWER (13.67 against 13.93 frames/s; unfolded 13.84): that epilogue is VALU-bound already and
+    # the kernel is 8 % of a segment — off by default, the LayerNorm in front of the feed-forward stays a launch (profiles/r06_ln_fold.md)
+    LN_FOLD_GEGLU = os.environ.get("MGLD_LN_FOLD_GEGLU", "0") != "0"
 
     def __init__(self, device="cuda", chunk_bytes=1 << 30, workspace_bytes=256 << 20):
         hip.lib()  # fail loudly if the HIP library is missing
@@ -309,6 +316,7 @@ class Engine:
         self._c3p_geo, self._c3p_w = {}, {}     # patch-conv applicability per geometry / tiled weights per packed tensor
         self.launches = 0
         self.gn_stats_saved = 0   # GroupNorm statistics launches that a producer's epilogue replaced
+        self.ln_folded = 0        # LayerNorm launches folded into their consumer (linear_ln)
         self.shard = None   # parallel.FrameShard when the frames of one segment are split over ranks
         self.tile_shard = None   # parallel.TileShard when the latent tiles of aggregation sampling are split over ranks
         self.pieces = None       # GraphPieces while a sharded step is recorded / replayed as hipGraph pieces
@@ -437,7 +445,7 @@ class Engine:
                 w2t = None if w2 is None else self._conv3p_tiled(w2, x.n, cin, cout, hin, win, tap_inner, up2)
                 if w2 is None or w2t is not None:
                     wp, w2, tap_inner, kw = wt, w2t, 2, dict(N=cout, K=9 * cin)
-        out.stats = None
+        out.stats = out.rstats = None
         got = []
         if stats and self.GN_PRODUCER and out.v.dtype == torch.float16 and not (self.GN_FUSED and hip.gn_fused_applies(ho * wo, cout, self.GROUPS)):
             def part(chunks):
@@ -480,7 +488,7 @@ class Engine:
         if out is None:
             out = Act(self.arena.alloc((x.n * ho * wo, cout), out_dtype), x.n, ho, wo)
         cin = x.C
-        out.stats = None
+        out.stats = out.rstats = None
         assert wp.shape[1] == kh * kw * cin, (wp.shape, kh, kw, cin)
         hip.igemm(x.v, wp, out.v, mode=hip.MODE_CONV3X3, bias=bias, act=act, alpha=alpha, N=cout,
                   conv=(cin, x.h, x.w, ho, wo, stride, pad[0], pad[1], 0), ksize=(kh, kw))
@@ -488,9 +496,10 @@ class Engine:
         return out
 
     def linear(self, x, w, bias, out=None, resid=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0, out_dtype=torch.float16, n_out=None,
-               w2=None, lo=False):
+               w2=None, lo=False, rowstats=False, ln=None):
         """x: Act or 2-D view; w [N, K] fp16 packed.  lo (x an Act, no `out`): the output is a residual-stream tensor; an Act `out` / `resid`
-        that carries a low plane has it written / added."""
+        that carries a low plane has it written / added.  rowstats: the output feeds a LayerNorm — where the kernel the launcher picks can, it
+        also writes the per-row sums of what it stores and the returned Act carries them (Act.rstats).  ln: see linear_ln."""
         xv = x.v if isinstance(x, Act) else x
         N = n_out if n_out is not None else (w.shape[0] // 2 if act == hip.ACT_GEGLU else w.shape[0])
         if out is None:
@@ -501,18 +510,63 @@ class Engine:
                 out = self.arena.alloc((xv.shape[0], N), out_dtype)
         ov = out.v if isinstance(out, Act) else out
         if isinstance(out, Act):
-            out.stats = None
+            out.stats = out.rstats = None
         rv = resid.v if isinstance(resid, Act) else resid
+        kw, got = {}, []
+        if rowstats and self.LN_FOLD and isinstance(out, Act) and ov.dtype == torch.float16:
+            def part(chunks):
+                got.append((self.arena.alloc((chunks, xv.shape[0], 2), torch.float32), chunks))
+                return got[0][0]
+            kw["row_part"] = part
         hip.igemm(xv, w, ov, bias=bias, resid=rv, act=act, alpha=alpha, beta=beta, M=xv.shape[0], N=w.shape[0], K=w.shape[1], w2=w2,
-                  resid_lo=resid.lo if isinstance(resid, Act) else None, out_lo=out.lo if isinstance(out, Act) else None)
+                  resid_lo=resid.lo if isinstance(resid, Act) else None, out_lo=out.lo if isinstance(out, Act) else None, ln=ln, **kw)
+        if got:
+            out.rstats = got[0]
         self.launches += 1
         return out
+
+    def linear_ln(self, x, norm, tag, params, fn, act=hip.ACT_NONE):
+        """act(LayerNorm(x) W^T + b) -> 2-D fp16 tensor; x: Act of token rows [rows, C]; fn(*fp32 params) -> (W [N, C], bias [N] or None) (GEGLU:
+        both in the packed row order of pack_geglu).  When x carries the row sums its producer wrote (Act.rstats) and the ping-pong kernel takes
+        the problem, the LayerNorm is FOLDED into the projection (MgldIGemm.ln_part): the contraction runs on the raw rows against W diag(gamma),
+        the epilogue applies rstd_m (acc - mean_m s_n) + b'_n — no normalised copy, no LayerNorm launch, one rounding of the operand less.
+        Otherwise: the LayerNorm kernel + the plain projection."""
+        xv = x.v
+        rows, C = xv.shape
+        if self.LN_FOLD and x.rstats is not None and (act != hip.ACT_GEGLU or self.LN_FOLD_GEGLU):
+            def pack(*ts):
+                W, bz = fn(*ts[:-2])
+                gam, bet = ts[-2], ts[-1]
+                Wp = W * gam[None, :]
+                s = Wp.to(torch.float16).to(torch.float32).sum(1)           # of the ROUNDED rows: cancels exactly what the MFMA sums
+                b2 = W @ bet + (bz if bz is not None else 0.0)
+                return Wp, s, b2
+            wp, sv, b2 = self.weight(tag + "#ln", tuple(params) + (norm.weight, norm.bias), pack)
+            N = wp.shape[0] // 2 if act == hip.ACT_GEGLU else wp.shape[0]
+            key = ("lnq", rows, wp.shape[0], C, act)
+            ok = self._wcache.get(key)
+            out = self.arena.alloc((rows, N), torch.float16)
+            if ok is None:
+                ok = self._wcache[key] = hip.igemm(xv, wp, out, bias=b2, act=act, M=rows, N=wp.shape[0], K=C, query_row_chunks=True) > 0
+            if ok:
+                part, chunks = x.rstats
+                hip.igemm(xv, wp, out, bias=b2, act=act, M=rows, N=wp.shape[0], K=C, ln=(part, chunks, sv, float(norm.eps)))
+                self.launches += 1
+                self.ln_folded += 1
+                return out
+        xn = self.layernorm(x, self.f32("g", norm.weight), self.f32("b", norm.bias), norm.eps).v
+
+        def plain(*ts):
+            W, bz = fn(*ts)
+            return (W, bz) if bz is not None else (W, torch.zeros(0))
+        w, bz = self.weight(tag, tuple(params), plain)
+        return self.linear(xn, w, bz if bz.numel() else None, act=act)
 
     def tconv3(self, x, wp, bias, T, alpha_blend, out=None, w2=None):
         """SpatialTemporalConv: out = a*(conv3d_t(x)+b) + (1-a)*x."""
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C, lo=x.lo is not None)
-        out.stats = None
+        out.stats = out.rstats = None
         sh = self.shard
         if sh is None:
             hip.igemm(x.v, wp, out.v, mode=hip.MODE_TCONV3, bias=bias, resid=x.v, alpha=alpha_blend, beta=1.0 - alpha_blend,
@@ -553,7 +607,7 @@ class Engine:
     def gn_apply(self, x, stats, gamma, beta, silu, out=None, groups=None):
         if out is None:
             out = self.act(x.n, x.h, x.w, x.C)
-        out.stats = None
+        out.stats = out.rstats = None
         gsums, eps, kind, chunks = stats
         if gsums is None:
             hip.gn_fused(x.v, eps, gamma, beta, out.v, x.n, x.hw, groups or self.GROUPS, silu, lo_in=x.lo if self.lo_norms else None)
@@ -570,7 +624,7 @@ class Engine:
         stores, and the returned Act carries the sums (Act.stats)"""
         if out is None:
             out = self.act(h.n, h.h, h.w, h.C, lo=True)       # skip + spade(h): the block's output, the next value of the residual stream
-        out.stats = None
+        out.stats = out.rstats = None
         gsums, eps, kind, chunks = stats
         gbv = gb.v if isinstance(gb, Act) else gb
         skip_lo, y_lo = skip.lo, out.lo

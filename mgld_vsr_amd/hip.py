@@ -35,6 +35,7 @@ class MgldIGemm(C.Structure):
         ("t_off", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("tune", C.c_int32),
         ("w2_scale", C.c_float), ("W2", C.c_void_p), ("gn_part", C.c_void_p), ("r_f32", C.c_int32),
         ("Rlo", C.c_void_p), ("Clo", C.c_void_p),
+        ("row_part", C.c_void_p), ("ln_part", C.c_void_p), ("ln_s", C.c_void_p), ("ln_chunks", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -55,7 +56,7 @@ EXPORTS = [
     "mgld_version", "mgld_last_error", "mgld_device_info",
     "mgld_graph_begin", "mgld_graph_end", "mgld_graph_launch", "mgld_graph_destroy",
     "mgld_event_create", "mgld_event_record", "mgld_event_sync", "mgld_event_elapsed_ms", "mgld_event_destroy",
-    "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_igemm_gn_chunks", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply",
+    "mgld_igemm", "mgld_igemm_config", "mgld_igemm_kernel_name", "mgld_igemm_gn_chunks", "mgld_igemm_row_chunks", "mgld_set_workspace", "mgld_gn_chunks", "mgld_gn_stats", "mgld_gn_apply", "mgld_spade_apply",
     "mgld_gn_apply_chunks", "mgld_gn_apply2", "mgld_spade_apply2", "mgld_gn_fused_applies", "mgld_gn_fused", "mgld_layernorm",
     "mgld_gn_apply_lo", "mgld_spade_apply_lo", "mgld_gn_fused_lo", "mgld_layernorm_lo",
     "mgld_attention", "mgld_attention_kernel_name", "mgld_temporal_attention", "mgld_softmax_rows", "mgld_softmax_rows_masked",
@@ -125,12 +126,16 @@ W2_SCALE = 2.0 ** -11     # scale of the weight-residual matrices (MgldIGemm.W2)
 def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None,
           act=ACT_NONE, alpha=1.0, beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0,
           M=None, N=None, K=None, tap_inner=0, t_off=0, ksize=None, tune=0, w2=None, w2_scale=W2_SCALE, gn_part=None,
-          resid_lo=None, out_lo=None):
+          resid_lo=None, out_lo=None, row_part=None, ln=None, query_row_chunks=False):
     """out[M,N] = alpha*act(gather(a) @ w^T + bias + rowvec) + beta*resid   (see include/mgld_hip.h).
     w2: the scaled fp16 rounding residual of the weights (same layout as w; engine.split_residual): the product then uses weights
     exact to ~2^-21 at twice the MFMA work.
     resid_lo / out_lo: low planes of the residual / of the output (the residual stream as two fp16 planes, value = hi + 2^-11 lo:
-    MgldIGemm.Rlo / Clo); each shares the leading dimension of its hi plane."""
+    MgldIGemm.Rlo / Clo); each shares the leading dimension of its hi plane.
+    LayerNorm folded into the projection (MgldIGemm.ln_part / row_part): `ln` = (part, chunks, s, eps) — the row sums of a's rows written by
+    the launch that produced them, the column sums of w (= W diag(gamma)) and the norm's eps; `row_part(chunks)` -> float32 [chunks, M, 2]
+    is called when the kernel picked for this problem writes the row sums of ITS output (the caller keeps what it returned).
+    query_row_chunks: no launch; returns mgld_igemm_row_chunks of the problem (> 0: the kernel takes ln / row_part)."""
     _req_cuda(a, w, out, resid_lo, out_lo)
     if not getattr(_TLS, "touched", False):
         ensure_workspace()          # a thread other than the one that built the Engine: give it its own split-K scratch
@@ -180,6 +185,19 @@ def igemm(a, w, out, *, mode=MODE_LINEAR, bias=None, bias_m=None, rowvec=None, r
             t = gn_part(chunks)
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
             p.gn_part = t.data_ptr()
+    if query_row_chunks:
+        return lib().mgld_igemm_row_chunks(C.byref(p))
+    if ln is not None:
+        part, chunks, sv, eps = ln
+        assert part.is_cuda and part.dtype == torch.float32 and part.is_contiguous() and part.shape == (chunks, p.M, 2), "ln: row sums [chunks, M, 2]"
+        assert sv.is_cuda and sv.dtype == torch.float32 and sv.numel() == p.N
+        p.ln_part, p.ln_s, p.ln_chunks, p.ln_eps = part.data_ptr(), sv.data_ptr(), int(chunks), float(eps)
+    if row_part is not None:
+        chunks = lib().mgld_igemm_row_chunks(C.byref(p))
+        if chunks > 0:
+            t = row_part(chunks)
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (chunks, p.M, 2)
+            p.row_part = t.data_ptr()
     if IGEMM_LOG is not None:
         IGEMM_LOG.append(MgldIGemm.from_buffer_copy(p))
     if TIMED is not None:

@@ -255,9 +255,9 @@ QKV_FUSED = os.environ.get("MGLD_QKV_FUSED", "1") != "0"    # q|k|v as ONE proje
 LOG2E = 1.4426950408889634
 
 
-def _self_attention(eng, attn, xn, frames, N, resid, out=None):
-    """softmax(q k^T / sqrt(d)) v over the N tokens of each frame; xn: 2-D [frames*N, C] normalized tokens; resid: the residual-stream Act
-    the result is added to (-> the stream's next Act)."""
+def _self_attention(eng, attn, norm, frames, N, resid, out=None):
+    """resid + to_out(softmax(q k^T / sqrt(d)) v) over the N tokens of each frame, q / k / v = projections of norm(resid); resid: the
+    residual-stream Act (-> the stream's next Act).  The LayerNorm is folded into the fused q|k|v projection where Engine.linear_ln can."""
     C, H, d = attn.heads * attn.dim_head, attn.heads, attn.dim_head
     if QKV_FUSED:
         # to_q | to_k | to_v (attention.py:323-330) as one GEMM with N = 3C: the normalised tokens are read once, and the attention
@@ -266,15 +266,17 @@ def _self_attention(eng, attn, xn, frames, N, resid, out=None):
         # the scores leave the matrix pipe in log2 units and the attention kernel's probability is a bare exp2 (`scale` = ln 2 tells the
         # launcher: flash_attn_kernel<64, true, true, 1, true>, csrc/attention.hip); every other kernel variant computes the same softmax
         f = d ** -0.5 * LOG2E
-        wqkv = eng.weight("qkvps", (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight), lambda q, k, v: torch.cat([q * f, k, v], 0))
-        qkv = eng.linear(xn, wqkv, None)
+        qkv = eng.linear_ln(resid, norm, "qkvps", (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight),
+                            lambda q, k, v: (torch.cat([q * f, k, v], 0), None))
         o = eng.empty(frames * N, C)
         hip.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], o, batch=frames, heads=H, Nq=N, Nkv=N, head_dim=d,
                       q_strides=(N * 3 * C, 3 * C, d), k_strides=(N * 3 * C, 3 * C, d), vt_strides=(N * 3 * C, 3 * C, d),
                       o_strides=(N * C, C, d), scale=1.0 / LOG2E, v_rowmajor=True)
         eng.launches += 1
         wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-        return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=resid.lo is not None)
+        return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), out=out, resid=resid, lo=resid.lo is not None,
+                          rowstats=True)       # feeds norm2
+    xn = eng.layernorm(resid, eng.f32("g", norm.weight), eng.f32("b", norm.bias), norm.eps).v
     wqk = eng.weight("qk", (attn.to_q.weight, attn.to_k.weight), lambda q, k: torch.cat([q, k], 0))
     wv = eng.weight("w", (attn.to_v.weight,), lambda v: v)
     qk = eng.linear(xn, wqk, None)
@@ -318,10 +320,9 @@ class ContextCache:
         return self.kv[key]
 
 
-def _cross_attention(eng, attn, xn, frames, N, ctx_cache, resid):
+def _cross_attention(eng, attn, norm, frames, N, ctx_cache, resid):
     C, H, d = attn.heads * attn.dim_head, attn.heads, attn.dim_head
-    wq = eng.weight("w", (attn.to_q.weight,), lambda w: w)
-    q = eng.linear(xn, wq, None)
+    q = eng.linear_ln(resid, norm, "w", (attn.to_q.weight,), lambda w: (w, None))
     k, vt = ctx_cache.get(attn)
     o = eng.empty(frames * N, C)
     hip.attention(q, k, vt, o, batch=frames, heads=H, Nq=N, Nkv=ctx_cache.L, head_dim=d, q_strides=(N * C, C, d),
@@ -329,7 +330,8 @@ def _cross_attention(eng, attn, xn, frames, N, ctx_cache, resid):
                   scale=d ** -0.5)
     eng.launches += 1
     wo = eng.weight("w", (attn.to_out[0].weight,), lambda w: w)
-    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), resid=resid, lo=resid.lo is not None)
+    return eng.linear(Act(o, resid.n, resid.h, resid.w), wo, eng.f32("b", attn.to_out[0].bias), resid=resid, lo=resid.lo is not None,
+                      rowstats=True)           # feeds norm3
 
 
 class BasicTransformerBlockV2(nn.Module):
@@ -346,12 +348,10 @@ class BasicTransformerBlockV2(nn.Module):
 
     def run(self, eng, t, frames, N, ctx_cache):
         """t: the token stream as an Act (its low plane, when it has one, feeds the LayerNorms and the residual adds)"""
-        ln = lambda x, m: eng.layernorm(x, eng.f32("g", m.weight), eng.f32("b", m.bias), m.eps).v
-        t = _self_attention(eng, self.attn1, ln(t, self.norm1), frames, N, resid=t)
-        t = _cross_attention(eng, self.attn2, ln(t, self.norm2), frames, N, ctx_cache, resid=t)
+        t = _self_attention(eng, self.attn1, self.norm1, frames, N, resid=t)
+        t = _cross_attention(eng, self.attn2, self.norm2, frames, N, ctx_cache, resid=t)
         proj = self.ff.net[0].proj
-        wg, bg = eng.weight("geglu", (proj.weight, proj.bias), pack_geglu)
-        g = eng.linear(ln(t, self.norm3), wg, bg, act=hip.ACT_GEGLU)
+        g = eng.linear_ln(t, self.norm3, "geglu", (proj.weight, proj.bias), pack_geglu, act=hip.ACT_GEGLU)
         w2 = eng.weight("w", (self.ff.net[2].weight,), lambda w: w)
         return eng.linear(Act(g, t.n, t.h, t.w), w2, eng.f32("b", self.ff.net[2].bias), resid=t, lo=t.lo is not None)
 
@@ -376,7 +376,8 @@ class SpatialTransformerV2(nn.Module):
 
     def run(self, eng, x, ctx_cache, out=None):
         xn = eng.groupnorm(x, eng.f32("g", self.norm.weight), eng.f32("b", self.norm.bias), self.norm.eps, False)
-        t = eng.linear(xn, eng.weight("w", (self.proj_in.weight,), lambda w: w), eng.f32("b", self.proj_in.bias), lo=eng.lo_inner)
+        t = eng.linear(xn, eng.weight("w", (self.proj_in.weight,), lambda w: w), eng.f32("b", self.proj_in.bias), lo=eng.lo_inner,
+                       rowstats=True)          # feeds the block's norm1
         t = self.transformer_blocks[0].run(eng, t, x.n, x.hw, ctx_cache)
         return eng.linear(t, eng.weight("w", (self.proj_out.weight,), lambda w: w), eng.f32("b", self.proj_out.bias), out=out, resid=x, lo=True)
 

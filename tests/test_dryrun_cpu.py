@@ -19,6 +19,7 @@ class Recorder:
         self.calls = []
         self.tiled = []
         self.lo_writes = 0
+        self.ln_folded = 0
 
     def ptrs(self):
         return [(name, tuple(p)) for name, p in self.calls]
@@ -36,8 +37,24 @@ def dry(monkeypatch):
 
     def igemm(a, w, out, *, mode=0, bias=None, bias_m=None, rowvec=None, rows_per_frame=0, resid=None, act=0, alpha=1.0,
               beta=1.0, conv=None, tconv=None, batch=1, strideA=0, strideW=0, strideC=0, strideR=0, M=None, N=None, K=None,
-              tap_inner=0, w2=None, resid_lo=None, out_lo=None, **_):
+              tap_inner=0, w2=None, resid_lo=None, out_lo=None, row_part=None, ln=None, query_row_chunks=False, **_):
         assert w2 is None or (w2.shape == w.shape and w2.dtype == w.dtype)
+        # LayerNorm folded into the projection (MgldIGemm.row_part / ln_part): a stand-in for the library's planner — the ping-pong LINEAR
+        # kernel takes whole 128 x 128 tiles with K % 64 == 0 and reports its column tiles
+        M_ = M if M is not None else out.shape[0]
+        N_ = N if N is not None else w.shape[0]
+        K_ = K if K is not None else w.shape[1]
+        pp_chunks = max(1, N_ // 256) if (mode == 0 and batch == 1 and M_ % 128 == 0 and N_ % 128 == 0 and K_ % 64 == 0 and w2 is None) else 0
+        if query_row_chunks:
+            return pp_chunks
+        if ln is not None:
+            part, chunks, sv, eps = ln
+            assert pp_chunks > 0 and part.shape == (chunks, M_, 2) and part.dtype == torch.float32 and sv.shape == (N_,) and eps > 0
+            assert bias is not None and a.shape[1] == K_          # b' = W beta + bias always exists; the operand is the raw token rows
+            rec.ln_folded += 1
+        if row_part is not None and pp_chunks > 0 and act != hip.ACT_GEGLU:
+            t_ = row_part(pp_chunks)
+            assert t_.shape == (pp_chunks, M_, 2) and t_.dtype == torch.float32
         # low planes of the residual stream (MgldIGemm.Rlo / Clo): each mirrors its hi plane, fp16 only, never with GEGLU / batches
         if resid_lo is not None:
             assert resid is not None and resid_lo.shape == resid.shape and resid_lo.stride() == resid.stride() and resid_lo.dtype == torch.float16

@@ -1041,6 +1041,70 @@ def _attn_ref(q, k, v, scale):
     return torch.einsum("bhij,bhjd->bhid", s.softmax(-1), v)
 
 
+@pytest.mark.parametrize("M,C,N,ptune,ctune,act", [(4096, 320, 960, 27, 27, 0), (2048, 320, 320, 27, 20, 3), (1024, 640, 1920, 22, 20, 0), (512, 1280, 1280, 23, 20, 0),
+                                                   (4096, 320, 2560, 27, 21, 4), (1024, 640, 5120, 22, 24, 4), (512, 1280, 10240, 26, 20, 4), (256, 128, 256, 26, 26, 4)])
+def test_layernorm_folded_into_the_projection(hip, M, C, N, ptune, ctune, act):
+    """MgldIGemm.row_part / ln_part: a projection writes the row sums of its output t (producer, every ping-pong tile width: one to eight
+    column tiles per row), the next projection runs on the RAW rows of t against W diag(gamma) and applies the LayerNorm in its epilogue
+    (plain, SiLU and GEGLU forms) — against fp64 LayerNorm(t) W^T + b of the stored fp16 t"""
+    from mgld_vsr_amd.engine import pack_geglu
+    a, wp_, bp_ = h16(rnd(M, C, seed=400)), h16(rnd(C, C, seed=401, scale=C ** -0.5)), rnd(C, seed=402)
+    r = h16(rnd(M, C, seed=403) * 2.0 + 0.5)
+    t = torch.full((M, C), float("nan"), dtype=torch.half, device=DEV)
+    got = []
+
+    def part(chunks):
+        got.append(torch.full((chunks, M, 2), float("nan"), dtype=torch.float32, device=DEV))
+        return got[0]
+    hip.igemm(a.to(DEV), wp_.to(DEV), t, bias=bp_.to(DEV), resid=r.to(DEV), tune=ptune, row_part=part)
+    torch.cuda.synchronize()
+    assert got, "the ping-pong kernel writes the row sums of its output"
+    t64 = a.double() @ wp_.double().t() + bp_.double() + r.double()
+    sums = got[0].cpu().double().sum(0)
+    assert rel_l2(sums[:, 0], t64.sum(1)) < 2e-5 and rel_l2(sums[:, 1], (t64 * t64).sum(1)) < 1e-5
+    # consumer
+    gam, bet = 1 + 0.2 * rnd(C, seed=404), 0.2 * rnd(C, seed=405)
+    W, b = rnd(N, C, seed=406, scale=C ** -0.5), rnd(N, seed=407)
+    if act == 4:
+        W, b = pack_geglu(W, b)
+    Wp = (W * gam[None, :]).half()
+    sv = Wp.float().sum(1)
+    b2 = W @ bet + b
+    ts = t.cpu()
+    ln = F.layer_norm(ts.double(), (C,), gam.double(), bet.double(), 1e-5)
+    pre = ln @ W.double().t() + b.double()
+    if act == 4:
+        pv = pre.reshape(M, N // 64, 2, 32)
+        ref = (pv[:, :, 0] * F.gelu(pv[:, :, 1])).reshape(M, N // 2)
+    else:
+        ref = F.silu(pre) if act == 3 else pre
+    out = torch.full((M, N // 2 if act == 4 else N), float("nan"), dtype=torch.half, device=DEV)
+    hip.igemm(t, Wp.to(DEV), out, bias=b2.to(DEV), act=act, tune=ctune, N=N, ln=(got[0], got[0].shape[0], sv.to(DEV), 1e-5))
+    torch.cuda.synchronize()
+    # against the exact weights: the rounding of fp16(W gamma) is part of the figure (2.8e-4 per weight) beside the rounding of the stored output
+    assert rel_l2(out.cpu(), ref) < 6e-4
+    # against the same algebra on the ROUNDED weights in fp64: only the output's own rounding is left — no normalised fp16 copy of t in between
+    mu, var = ts.double().mean(1, keepdim=True), ts.double().var(1, unbiased=False, keepdim=True)
+    pre_r = ((ts.double() - mu) / (var + 1e-5).sqrt()) @ Wp.double().t() + b2.double()
+    if act == 4:
+        pv = pre_r.reshape(M, N // 64, 2, 32)
+        ref_r = (pv[:, :, 0] * F.gelu(pv[:, :, 1])).reshape(M, N // 2)
+    else:
+        ref_r = F.silu(pre_r) if act == 3 else pre_r
+    assert rel_l2(out.cpu(), ref_r) < 3.2e-4
+
+
+def test_layernorm_fold_refused_off_the_pingpong_path(hip):
+    a, w = h16(rnd(100, 72, seed=410)).to(DEV), h16(rnd(72, 72, seed=411)).to(DEV)
+    out = torch.empty(100, 72, dtype=torch.half, device=DEV)
+    assert hip.igemm(a, w, out, query_row_chunks=True) == 0
+    called = []
+    hip.igemm(a, w, out, row_part=lambda c: called.append(c))            # a producer the family does not take: no statistics, no error
+    assert not called
+    with pytest.raises(RuntimeError):
+        hip.igemm(a, w, out, ln=(torch.zeros(1, 100, 2, device=DEV), 1, torch.zeros(72, device=DEV), 1e-5))
+
+
 @pytest.mark.parametrize("B,H,Nq,Nkv,D", [(2, 5, 256, 256, 64), (1, 2, 200, 77, 64), (2, 4, 130, 130, 128), (1, 1, 64, 64, 64),
                                           (1, 3, 1024, 1024, 64), (3, 2, 64, 5, 64),
                                           (8, 5, 300, 300, 64), (4, 6, 256, 77, 64)])   # batch * heads % 8 == 0: XCD-grouped block order
