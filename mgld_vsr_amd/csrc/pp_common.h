@@ -73,6 +73,14 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
   // per-lane column constants (bias, plus the per-frame row vector of the frame the rows lie in), loaded ONCE per frame: inside the row
   // loop every fragment row paid an L2 round trip for them.  Rows of a tile are almost always one frame.
   f32x4 cv[NI];
+  // folded LayerNorm: the column sums s_n.  Narrow wave tiles (the GEGLU tiles: 64 weight rows = 4 fragments) hold them like the bias; wide ones
+  // (the 256 x 320 tile: 10 fragments, 250 registers already) re-read them per fragment from L1
+  constexpr bool HOIST_S = NI <= 4;
+  f32x4 sv[HOIST_S ? NI : 1];
+  if constexpr (HOIST_S) {
+#pragma unroll
+    for (int f = 0; f < NI; ++f) sv[f] = e.ln_part ? *(const f32x4*)(e.ln_s + n0 + f * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   int fr_loaded = -2;
   auto load_cv = [&](const int fr) {
 #pragma unroll
@@ -103,14 +111,16 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
         const f32x2 t = *(const f32x2*)(e.ln_part + ((int64_t)c * e.ln_M + m) * 2);
         s1 += t[0]; s2 += t[1];
       }
-      ln_mu = s1 * e.ln_invK;
-      ln_rs = __builtin_amdgcn_rsqf(fmaxf(s2 * e.ln_invK - ln_mu * ln_mu, 0.f) + e.ln_eps);
+      const float mu = s1 * e.ln_invK;
+      ln_rs = __builtin_amdgcn_rsqf(fmaxf(s2 * e.ln_invK - mu * mu, 0.f) + e.ln_eps);
+      ln_mu = -mu * ln_rs;                         // rstd (acc - mean s) = acc rstd + (-mean rstd) s: two FMAs per element
     }
-    // (the column sums s_n are re-read per fragment from L1 instead of being held like the bias: ten more live f32x4 spilled the 256 x 320 tile)
     auto ln_of = [&](const f32x4 a, const int f) -> f32x4 {
       if (!e.ln_part) return a;
-      const f32x4 sn = *(const f32x4*)(e.ln_s + n0 + f * 16 + 4 * q);
-      return (a - ln_mu * sn) * ln_rs;
+      f32x4 sn;
+      if constexpr (HOIST_S) sn = sv[f];
+      else sn = *(const f32x4*)(e.ln_s + n0 + f * 16 + 4 * q);
+      return a * ln_rs + ln_mu * sn;
     };
     auto out_frag = [&](const int f) -> f32x4 {      // output fragment f of this row block, epilogue arithmetic applied (not the residual)
       if constexpr (GEGLU) {
