@@ -614,6 +614,18 @@ def main():
     # whole-segment algorithmic FLOP rate against the dense fp16 MFMA peak of the GPUs in use (the path is compute-bound:
     # ~55 TFLOP per HR frame against ~0.15 TB of algorithmic HBM traffic)
     res["sustained_frac_of_mfma_peak"] = round(res["sustained_tflops"] / (PEAK_FP16_TFLOPS * world), 4)
+    # the arithmetic this number was measured with, and what its precision features cost ("price it in the bench line"):
+    # measured back to back on one box, profiles/r06_stream_lo.md / r06_ln_fold.md / r05_hp_encoder_kstats.txt
+    eng_ = pipe.model.engine()
+    res["arithmetic"] = {
+        "operands": "fp16, fp32 MFMA accumulation",
+        "residual_stream_two_fp16_planes": ",".join(sorted(eng_.lo_scopes)) or "off",
+        "layernorm_folded_into_consumer": bool(eng_.LN_FOLD),
+        "first_stage_encoder": "fp32 activations, split-fp16 contractions" if os.environ.get("MGLD_HP_ENCODER", "1") != "0" else "fp16",
+        "weight_residual_pass": ",".join(sorted(eng_.w2_scopes)) or "off",
+        "price": "two-plane stream: -4.5 % frames/s for -18 % latent / -28 % frame error (MGLD_STREAM_LO=0: 14.25 against 13.63 on one box); "
+                 "high-precision first-stage encoder: +29 ms per 8-frame encode (-2.5 %)",
+    }
     if one_at_a_time is not None:     # both schedulings in one line: `value` = the default (segments in flight), this = the reference's loop
         res["value_one_at_a_time"] = one_at_a_time["value"]
         res["one_at_a_time"] = one_at_a_time
