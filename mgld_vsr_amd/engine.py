@@ -99,6 +99,16 @@ def pack_geglu(w, b):
     return wp, bp
 
 
+def pack_ln_fold(W, bias, gamma, beta):
+    """LayerNorm(x; gamma, beta) W^T + bias as a contraction on the RAW rows (MgldIGemm.ln_part): -> (W' = W diag(gamma), s, b') with
+    y[m, n] = rstd[m] * (x[m] . W'[n] - mean[m] * s[n]) + b'[n];  s = row sums of the fp16-ROUNDED W' (what the MFMA actually sums, so the
+    mean correction cancels it exactly), b' = W beta + bias.  attention.py:427-435."""
+    Wp = W * gamma[None, :]
+    s = Wp.to(torch.float16).to(torch.float32).sum(1)
+    b2 = W @ beta + (bias if bias is not None else 0.0)
+    return Wp, s, b2
+
+
 def pack_hp(w32):
     """split-fp16 weights of the high-precision encoder (csrc/hpenc.hip): [Cout, Cin, ...] fp32 -> [Cout, 3*Cin, ...] =
     [wh | wh / 16 | 256 wl] along the input-channel axis (wh = fp16(w), wl = w - wh), every entry exactly representable in fp16 (wl to
@@ -536,11 +546,7 @@ class Engine:
         if self.LN_FOLD and x.rstats is not None and (act != hip.ACT_GEGLU or self.LN_FOLD_GEGLU):
             def pack(*ts):
                 W, bz = fn(*ts[:-2])
-                gam, bet = ts[-2], ts[-1]
-                Wp = W * gam[None, :]
-                s = Wp.to(torch.float16).to(torch.float32).sum(1)           # of the ROUNDED rows: cancels exactly what the MFMA sums
-                b2 = W @ bet + (bz if bz is not None else 0.0)
-                return Wp, s, b2
+                return pack_ln_fold(W, bz, ts[-2], ts[-1])
             wp, sv, b2 = self.weight(tag + "#ln", tuple(params) + (norm.weight, norm.bias), pack)
             N = wp.shape[0] // 2 if act == hip.ACT_GEGLU else wp.shape[0]
             key = ("lnq", rows, wp.shape[0], C, act)

@@ -691,3 +691,29 @@ def test_pipeline_clone_shares_weights_not_modules():
     with pytest.raises(RuntimeError):
         a.clone_shared()
     a.model._engine = None
+
+
+def test_layernorm_fold_packing_is_the_same_linear_map():
+    """engine.pack_ln_fold (MgldIGemm.ln_part): LayerNorm(x) W^T + b == rstd (x W'^T - mean s) + b' on the raw rows, in fp64 — plain and in the
+    packed GEGLU row order (the fold commutes with any row permutation of W)"""
+    import torch.nn.functional as F
+    from mgld_vsr_amd.engine import pack_geglu, pack_ln_fold
+    g = torch.Generator().manual_seed(5)
+    M, C, N = 37, 96, 128
+    x = (torch.randn(M, C, generator=g) * 3 + 1.5).double()
+    W, b = torch.randn(N, C, generator=g).double() * C ** -0.5, torch.randn(N, generator=g).double()
+    gam, bet = 1 + 0.3 * torch.randn(C, generator=g).double(), 0.3 * torch.randn(C, generator=g).double()
+    ref = F.layer_norm(x, (C,), gam, bet, 1e-5) @ W.t() + b
+    mean, rstd = x.mean(1, keepdim=True), (x.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    for Wk, bk, refk in ((W, b, ref), pack_geglu(W, b) + (None,)):
+        if refk is None:
+            refk = F.layer_norm(x, (C,), gam, bet, 1e-5) @ Wk.t() + bk
+        Wp, s, b2 = pack_ln_fold(Wk, bk, gam, bet)
+        # s is taken from the fp16-rounded rows on purpose: evaluate the identity with the matrix the MFMA sees
+        W16 = Wp.to(torch.float16).double()
+        got = rstd * (x @ W16.t() - mean * s.double()) + b2
+        want = rstd * ((x - mean) @ W16.t()) + b2
+        assert float((got - want).abs().max()) < 1e-4                  # the mean correction cancels what was summed (fp32 row sums)
+        assert float((rstd * (x @ Wp.t() - mean * Wp.sum(1)) + b2 - refk).abs().max()) < 1e-9
+    W0, s0, b0 = pack_ln_fold(W, None, gam, bet)
+    assert torch.equal(b0, W @ bet)
