@@ -203,12 +203,37 @@ __device__ __forceinline__ void epi_rows(const MgldIGemm& p, const RowMap rmap, 
 #pragma unroll
           for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j >> 1][j & 1] += p.beta * (float)rp[j];
         }
+        if (p.Rlo) {                    // low plane of the residual stream (same index as R; batch 1)
+          const f16* rl = (const f16*)p.Rlo + (int64_t)m * p.ldr + n;
+          const e2 bl2 = pk(p.beta * MGLD_LO_SCALE, p.beta * MGLD_LO_SCALE);
+          if (full && ((((uintptr_t)rl) & 15) == 0)) {
+            const f16x8 rr = *(const f16x8*)rl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bl2 * pk((float)rr[2 * j], (float)rr[2 * j + 1]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n + j < Nout) v[j >> 1][j & 1] += p.beta * MGLD_LO_SCALE * (float)rl[j];
+          }
+        }
       }
+      const f16x8 o8 = f16x8{(f16)v[0][0], (f16)v[0][1], (f16)v[1][0], (f16)v[1][1], (f16)v[2][0], (f16)v[2][1], (f16)v[3][0], (f16)v[3][1]};
       if (full && ((((uintptr_t)cp) & 15) == 0)) {
-        *(f16x8*)cp = f16x8{(f16)v[0][0], (f16)v[0][1], (f16)v[1][0], (f16)v[1][1], (f16)v[2][0], (f16)v[2][1], (f16)v[3][0], (f16)v[3][1]};
+        *(f16x8*)cp = o8;
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = (f16)v[j >> 1][j & 1];
+        for (int j = 0; j < 8; ++j) if (n + j < Nout) cp[j] = o8[j];
+      }
+      if (p.Clo) {                      // low plane of the output
+        f16* cl = (f16*)p.Clo + cbase + (int64_t)m * ldo + n;
+        f16x8 l8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l8[j] = lo_plane(v[j >> 1][j & 1], o8[j]);
+        if (full && ((((uintptr_t)cl) & 15) == 0)) {
+          *(f16x8*)cl = l8;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < Nout) cl[j] = l8[j];
+        }
       }
     } else {
       float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -306,7 +331,7 @@ __device__ __forceinline__ void tile_epilogue(const MgldIGemm& p, float* __restr
   int kind = EPI_GENERIC;
   if (splitk) kind = EPI_SLAB;
   else if (geglu) kind = (alpha == 1.f && !of32) ? EPI_GEGLU : EPI_GENERIC;
-  else if (!of32 && !p.bias_m && !p.Rlo && !p.Clo && alpha == 1.f && (act == MGLD_ACT_NONE || act == MGLD_ACT_SILU)) kind = act == MGLD_ACT_SILU ? EPI_PLAIN_SILU : EPI_PLAIN_NONE;
+  else if (!of32 && !p.bias_m && alpha == 1.f && (act == MGLD_ACT_NONE || act == MGLD_ACT_SILU)) kind = act == MGLD_ACT_SILU ? EPI_PLAIN_SILU : EPI_PLAIN_NONE;
   // (column chunks unrolled by hand through compile-time indices: a runtime `c` would index acc[] dynamically = scratch memory)
   auto do_chunk = [&](auto CI) {
   constexpr int c = decltype(CI)::value;

@@ -63,8 +63,10 @@ struct PPEpi {
   bool noswap;     // A/B and bring-up: every fragment by 8-byte stores (no v_permlane16_swap pairing)
 };
 
-template <int MI, int NI, bool GEGLU, typename RowFn>
-__device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const RowFn row_of) {
+// FEAT: the round-6 extras (stream low planes, folded LayerNorm, row statistics) are compiled in; callers branch ONCE per block on whether any of
+// them is set, so a plain launch runs the round-5 instruction stream (the GEGLU epilogue is VALU-bound: the dormant checks cost it 5 %)
+template <int MI, int NI, bool GEGLU, bool FEAT, typename RowFn>
+__device__ __forceinline__ void pp_epilogue_(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const RowFn row_of) {
   // n0: first output channel (packed weight row for GEGLU) of this wave; row_of(mi) = global output row of this lane in fragment mi, or -1
   const int q = lane >> 4;
   constexpr int NO = GEGLU ? NI / 2 : NI;            // output fragments
@@ -75,7 +77,7 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
   f32x4 cv[NI];
   // folded LayerNorm: the column sums s_n.  Narrow wave tiles (the GEGLU tiles: 64 weight rows = 4 fragments) hold them like the bias; wide ones
   // (the 256 x 320 tile: 10 fragments, 250 registers already) re-read them per fragment from L1
-  constexpr bool HOIST_S = NI <= 4;
+  constexpr bool HOIST_S = FEAT && NI <= 4;
   f32x4 sv[HOIST_S ? NI : 1];
   if constexpr (HOIST_S) {
 #pragma unroll
@@ -105,7 +107,7 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
     }
     // folded LayerNorm: this row's (mean, rstd) from the producer's chunk sums
     float ln_mu = 0.f, ln_rs = 1.f;
-    if (e.ln_part && m >= 0) {
+    if (FEAT && e.ln_part && m >= 0) {
       float s1 = 0.f, s2 = 0.f;
       for (int c = 0; c < e.ln_chunks; ++c) {
         const f32x2 t = *(const f32x2*)(e.ln_part + ((int64_t)c * e.ln_M + m) * 2);
@@ -116,7 +118,7 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
       ln_mu = -mu * ln_rs;                         // rstd (acc - mean s) = acc rstd + (-mean rstd) s: two FMAs per element
     }
     auto ln_of = [&](const f32x4 a, const int f) -> f32x4 {
-      if (!e.ln_part) return a;
+      if (!FEAT || !e.ln_part) return a;
       f32x4 sn;
       if constexpr (HOIST_S) sn = sv[f];
       else sn = *(const f32x4*)(e.ln_s + n0 + f * 16 + 4 * q);
@@ -148,7 +150,7 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
         const f16x4 rr = *(const f16x4*)(e.R + (int64_t)m * e.ldr + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] += e.beta * (float)rr[r];
-        if (e.Rlo) {
+        if (FEAT && e.Rlo) {
           const f16x4 rl = *(const f16x4*)(e.Rlo + (int64_t)m * e.ldr + n);
           const float bl = e.beta * MGLD_LO_SCALE;
 #pragma unroll
@@ -157,14 +159,14 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
       }
       const f16x4 o = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
       *(f16x4*)(e.C + (int64_t)m * e.ldc + n) = o;
-      if (e.Clo) *(f16x4*)(e.Clo + (int64_t)m * e.ldc + n) = f16x4{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3])};
-      if (e.row_tab) {
+      if (FEAT && e.Clo) *(f16x4*)(e.Clo + (int64_t)m * e.ldc + n) = f16x4{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3])};
+      if (FEAT && e.row_tab) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { rsum += a[r]; rsq += a[r] * a[r]; }
       }
     };
     auto row_flush = [&]() {                         // the four lane rows q hold the same output row: add them up, lane row 0 writes the wave's slot
-      if (!e.row_tab) return;
+      if (!FEAT || !e.row_tab) return;
       rsum += __shfl_xor(rsum, 16, 64); rsq += __shfl_xor(rsq, 16, 64);
       rsum += __shfl_xor(rsum, 32, 64); rsq += __shfl_xor(rsq, 32, 64);
       if (q == 0) *(f32x2*)(e.row_tab + (mi * 16 + (lane & 15)) * 2) = f32x2{rsum, rsq};
@@ -190,7 +192,7 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
         const f16x8 rr = *(const f16x8*)(e.R + (int64_t)m * e.ldr + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { a[r] += e.beta * (float)rr[r]; b[r] += e.beta * (float)rr[4 + r]; }
-        if (e.Rlo) {
+        if (FEAT && e.Rlo) {
           const f16x8 rl = *(const f16x8*)(e.Rlo + (int64_t)m * e.ldr + n);
           const float bl = e.beta * MGLD_LO_SCALE;
 #pragma unroll
@@ -199,10 +201,10 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
       }
       const f16x8 o = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
       *(f16x8*)(e.C + (int64_t)m * e.ldc + n) = o;
-      if (e.Clo)
+      if (FEAT && e.Clo)
         *(f16x8*)(e.Clo + (int64_t)m * e.ldc + n) = f16x8{lo_plane(a[0], o[0]), lo_plane(a[1], o[1]), lo_plane(a[2], o[2]), lo_plane(a[3], o[3]),
                                                           lo_plane(b[0], o[4]), lo_plane(b[1], o[5]), lo_plane(b[2], o[6]), lo_plane(b[3], o[7])};
-      if (e.row_tab) {
+      if (FEAT && e.row_tab) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { rsum += a[r] + b[r]; rsq += a[r] * a[r] + b[r] * b[r]; }
       }
@@ -210,6 +212,12 @@ __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI]
     if constexpr (NO & 1) store4(NO - 1);            // unpaired last fragment
     row_flush();
   }
+}
+
+template <int MI, int NI, bool GEGLU, typename RowFn>
+__device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const RowFn row_of) {
+  if (e.Rlo || e.Clo || e.ln_part || e.row_tab) pp_epilogue_<MI, NI, GEGLU, true>(e, acc, lane, n0, row_of);
+  else pp_epilogue_<MI, NI, GEGLU, false>(e, acc, lane, n0, row_of);
 }
 
 // ---- the same epilogue + per-channel (sum, sumsq) of the output values (GroupNorm statistics of the output, MgldIGemm.gn_part) ----

@@ -169,7 +169,9 @@ __global__ __launch_bounds__(512) void ppgemm_kernel(const MgldIGemm p, const in
   pp_epilogue<MI, NI, GEGLU>(e, acc, lane, bn0 + wn * WN, [&](const int mi) { return mrow + mi * 16; });
   if (!GEGLU && p.row_part) {
     __syncthreads();
-    for (int r = tid; r < BM; r += 512) {
+    // (thread index rebuilt from the lane count: keeping `tid` alive across the K loop costs the 256 x 320 tile its last registers)
+    const int tid2 = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    for (int r = tid2; r < BM; r += 512) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WGN; ++w) { s1 += rtab[(w * BM + r) * 2]; s2 += rtab[(w * BM + r) * 2 + 1]; }
