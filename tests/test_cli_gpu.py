@@ -358,8 +358,11 @@ def test_bench_json_line_contract(steps):
     else:
         assert d["value_one_at_a_time"] == d["value"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline"):
+              "dtype", "data", "config", "roofline", "arithmetic"):
         assert k in d, k
+    # the precision features the number was measured with, and their price
+    assert d["arithmetic"]["residual_stream_two_fp16_planes"] == "struct,unet,vae_dec,vae_enc" and d["arithmetic"]["layernorm_folded_into_consumer"] is True
+    assert "price" in d["arithmetic"]
     assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["dtype"] == "f16" and d["data"] == "synthetic" and d["value"] > 0
     assert d["config"]["finite"] is True and d["config"]["reduced_width"] is True and "workload" in d["config"]
