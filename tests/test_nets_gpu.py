@@ -77,6 +77,33 @@ def test_unet_small_vs_golden(hip, small_nets):
     assert record("unet_small_mixed_t", rel_l2(eps2, ref)) < 2.05e-3
 
 
+def test_residual_stream_planes_and_layernorm_fold_are_switches(hip, small_nets, monkeypatch):
+    """MGLD_STREAM_LO=0 / MGLD_LN_FOLD=0 (read when an Engine is built) give the round-5 arithmetic on the same kernels: still inside the round-5
+    bound, and measurably behind the default — the planes are what moved the figure, not something else in the build"""
+    from mgld_vsr_amd.engine import Engine
+    unet, _ = small_nets
+    g = G("g_unet")
+    sc = {k[3:]: v.cuda() for k, v in g.items() if k.startswith("sc_")}
+    keep = unet.engine()
+    try:
+        errs = {}
+        for name, env in (("default", {}), ("one_plane", {"MGLD_STREAM_LO": "0"}), ("one_plane_unfolded", {"MGLD_STREAM_LO": "0", "MGLD_LN_FOLD": "0"})):
+            for k in ("MGLD_STREAM_LO", "MGLD_LN_FOLD"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            eng = Engine()
+            eng.LN_FOLD = env.get("MGLD_LN_FOLD", "1") != "0"         # (class attribute read at import: set per instance here)
+            unet.set_engine(eng)
+            errs[name] = rel_l2(unet(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].cuda(), struct_cond=sc), g["eps"])
+            assert bool(eng.lo_scopes) == (name == "default")
+        record("unet_small_one_plane", errs["one_plane"])
+        assert errs["default"] < 2.05e-3 and errs["one_plane"] < 2.4e-3 and errs["one_plane_unfolded"] < 2.4e-3, errs
+        assert errs["one_plane"] > 1.08 * errs["default"], errs
+    finally:
+        unet.set_engine(keep)
+
+
 def test_unet_small_with_outlier_channels_vs_oracle(hip):
     """Trained SD-2.1 weights carry a few outlier channels (activations in the thousands) and non-zero "zero-initialised" output
     convolutions; the synthetic weights of the other tests have neither.  Here some output channels of the res-block / transformer

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from mgld_vsr_amd import hip  # noqa: E402
 
 # (frames, rows per frame, C)
-SHAPES = [(8, 4096, 320), (8, 4096, 640), (8, 4096, 960), (8, 1024, 640), (8, 1024, 1280), (8, 1024, 1920),
+SHAPES = [(16, 4096, 320), (16, 4096, 640), (16, 4096, 960), (16, 1024, 640), (16, 1024, 1280), (16, 256, 1280), (8, 4096, 320), (8, 4096, 640), (8, 4096, 960), (8, 1024, 640), (8, 1024, 1280), (8, 1024, 1920),
           (8, 256, 1280), (8, 256, 2560), (8, 64, 1280), (8, 64, 2560), (8, 16384, 512), (8, 65536, 256), (8, 262144, 128)]
 
 
@@ -39,6 +39,10 @@ def main():
         t_s = timeit(lambda: hip.gn_stats(x, frames, rows, 32, gs), e0, e1)
         t_a = timeit(lambda: hip.gn_apply(x, gs, 1e-5, g, b, y, frames, rows, 32, True), e0, e1)
         line = f"frames={frames} rows={rows:6d} C={C:5d} ({mb:7.1f} MB)  stats {t_s:8.2f} us {mb / t_s * 1e-3:6.2f} TB/s   apply {t_a:8.2f} us {2 * mb / t_a * 1e-3:6.2f} TB/s"
+        if not hip.gn_fused_applies(rows, C, 32):
+            xl = torch.randn(frames * rows, C, device=dev).half()
+            t_l = timeit(lambda: hip.gn_apply(x, gs, 1e-5, g, b, y, frames, rows, 32, True, x_lo=xl), e0, e1)
+            line += f"   apply_lo {t_l:8.2f} us {3 * mb / t_l * 1e-3:6.2f} TB/s"
         if rows <= 4096:
             gb = torch.randn(frames * rows, 2 * C, device=dev).half()
             sk = torch.randn(frames * rows, C, device=dev).half()
