@@ -455,6 +455,28 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
   const int64_t most = (3 * cus) / 4;
   if (p->N % 128 == 0) { take(8, most); take(3, most); take(2, cus / 2 - cus / 8); }
   if (p->N % 80 == 0) { take(6, most); take(0, most); take(7, most); take(5, most); }
+  // round 6 (two segments batched as clips double every row count; the table above was measured at 8 frames): a choice whose LAST round of
+  // tiles is mostly empty gives way to a large-tile configuration that fills whole rounds.  Measured (profiles/r06_conv_2clip.txt): 16 frames
+  // x 32^2, 640 -> 640: 8 x 32 x 128 tiles = 320 blocks (1.25 rounds) 118.0 us against 16 x 32 x 80 = 256 blocks 85.0 us; 8 frames x 64^2,
+  // 128 -> 640 (SPADE): 16 x 32 x 128 = 320 blocks 56.6 us against 16 x 32 x 80 = 512 blocks 46.8 us (profiles/r04_pp_conv.txt).  The small
+  // tiles (configurations 1, 5, 7) are not candidates: a full round of them measures no better than a ragged round of a large tile.
+  // env MGLD_CONV3R_FILL = 0: the round-4 table alone (A/B runs).
+  if (bid >= 0 && p->tune == 0) {
+    static int onf = -1;
+    if (onf < 0) { const char* e = getenv("MGLD_CONV3R_FILL"); onf = e ? atoi(e) : 1; }
+    auto fill = [&](int i) { const int64_t t = tiles_of(i); return (double)t / (double)(cdiv(t, (int64_t)cus) * cus); };
+    if (onf && fill(bid) < 0.8) {
+      const int cand[4] = {6, 0, 8, 2};
+      int alt = -1;
+      double fa = 0.95;
+      for (int k = 0; k < 4; ++k) {
+        const int i = cand[k];
+        if (i == bid || !fits(i) || p->Wout < R3_CFG[i].tx || p->Hout < R3_CFG[i].ty || tiles_of(i) < most) continue;
+        if (fill(i) >= fa && (alt < 0 || fill(i) > fa)) { fa = fill(i); alt = i; }
+      }
+      if (alt >= 0) bid = alt;
+    }
+  }
   // few tiles, deep K (the 16^2 UNet level: 8 frames x 256 pixels x 1280 channels, K = 11520 .. 23040): the channel slices split over
   // grid.z so that tiles x slabs fill the chip once (profiles/r04_conv3r_split.txt)
   if (bid < 0 && p->tune == 0 && w8 && (p->Cin >> 5) >= 8) {      // the 8^2 level (profiles/r04_conv3r_split.txt)
@@ -462,10 +484,12 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
     // 54.4 -> 41.4 us at K = 23040), but no measurable change of the segment (708.9 vs 709.7 ms, A/B on one box): eight fp32 slabs + the
     // reduction launch eat what the 256-class tiles gain.  tune = 40 / 41 / 59 / 60 select them per launch (tests, tools/igemm_bench.py)
     static int on8 = -1;
-    if (on8 < 0) { const char* e = getenv("MGLD_CONV3R_W8"); on8 = e ? atoi(e) : 0; }
+    // round 6: at two clips (16 frames, M = 1024) they measure +0.5 .. 0.9 % on the whole pass (13.57 / 13.56 against 13.51 / 13.44 frames/s, two
+    // alternated runs each, one box): default on from 16 frames up, off below; the env value forces either way
+    if (on8 < 0) { const char* e = getenv("MGLD_CONV3R_W8"); on8 = e ? (atoi(e) ? 1 : 0) : 2; }
     const bool deep = (p->Cin >> 5) >= 64;          // measured: 4-frame tiles win from Cin = 2048 up (46.5 -> 41.4 us at 2560), 2-frame tiles below
     const int cand[2] = {deep ? 9 : 10, deep ? 10 : 9};
-    for (int k = 0; k < 2 && bid < 0 && on8; ++k) {
+    for (int k = 0; k < 2 && bid < 0 && (on8 == 1 || (on8 == 2 && frames >= 16)); ++k) {
       const int i = cand[k];
       if (!fits(i)) continue;
       const int sp = splits_of(i);

@@ -38,19 +38,19 @@ def main():
         mb = x.numel() * 2 / 1e6
         t_s = timeit(lambda: hip.gn_stats(x, frames, rows, 32, gs), e0, e1)
         t_a = timeit(lambda: hip.gn_apply(x, gs, 1e-5, g, b, y, frames, rows, 32, True), e0, e1)
-        line = f"frames={frames} rows={rows:6d} C={C:5d} ({mb:7.1f} MB)  stats {t_s:8.2f} us {mb / t_s * 1e-3:6.2f} TB/s   apply {t_a:8.2f} us {2 * mb / t_a * 1e-3:6.2f} TB/s"
+        line = f"frames={frames} rows={rows:6d} C={C:5d} ({mb:7.1f} MB)  stats {t_s:8.2f} us {mb / t_s:6.2f} TB/s   apply {t_a:8.2f} us {2 * mb / t_a:6.2f} TB/s"
         if not hip.gn_fused_applies(rows, C, 32):
             xl = torch.randn(frames * rows, C, device=dev).half()
             t_l = timeit(lambda: hip.gn_apply(x, gs, 1e-5, g, b, y, frames, rows, 32, True, x_lo=xl), e0, e1)
-            line += f"   apply_lo {t_l:8.2f} us {3 * mb / t_l * 1e-3:6.2f} TB/s"
+            line += f"   apply_lo {t_l:8.2f} us {3 * mb / t_l:6.2f} TB/s"
         if rows <= 4096:
             gb = torch.randn(frames * rows, 2 * C, device=dev).half()
             sk = torch.randn(frames * rows, C, device=dev).half()
             t_p = timeit(lambda: hip.spade_apply(x, gs, 1e-5, g, b, gb, sk, y, frames, rows, 32), e0, e1)
-            line += f"   spade {t_p:8.2f} us {5 * mb / t_p * 1e-3:6.2f} TB/s"
+            line += f"   spade {t_p:8.2f} us {5 * mb / t_p:6.2f} TB/s"
         if hip.gn_fused_applies(rows, C, 32):
             t_f = timeit(lambda: hip.gn_fused(x, 1e-5, g, b, y, frames, rows, 32, 1), e0, e1)
-            line += f"   fused {t_f:8.2f} us {2 * mb / t_f * 1e-3:6.2f} TB/s"
+            line += f"   fused {t_f:8.2f} us {2 * mb / t_f:6.2f} TB/s"
         print(line)
 
 
