@@ -402,7 +402,12 @@ bool conv3r_plan(const MgldIGemm* p, int* id, int* splits) {
   if (p->tune != 0 && (p->tune < 30 || p->tune > 30 + R3_NCFG) && (p->tune < 50 || p->tune >= 50 + R3_NCFG)) return false;
   if (p->kh > 0 && !(p->kh == 3 && p->kw == 3)) return false;
   if (p->stride != 1 || p->pad_t != 1 || p->pad_l != 1 || p->batch > 1 || p->up2 || p->bias_m || (p->Cin & 31)) return false;
-  if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU)) return false;
+  if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU || p->act == MGLD_ACT_RELU)) return false;
+  if (p->act == MGLD_ACT_RELU && p->tune == 0) {    // round 6: SPADE's shared convolution + ReLU (64^2: 41.0 -> 33.4 us in isolation); env MGLD_CONV3R_RELU = 0: conv3q as before (A/B)
+    static int onr = -1;
+    if (onr < 0) { const char* e = getenv("MGLD_CONV3R_RELU"); onr = e ? atoi(e) : 1; }
+    if (!onr) return false;
+  }
   // fp32 output (+ fp32 residual): the plain form only — bias, no activation / row vector / statistics (the split-fp16 convolutions of
   // the high-precision encoder, hpenc.hip)
   if (p->out_f32 && (p->act != MGLD_ACT_NONE || p->rowvec || p->gn_part || p->alpha != 1.f || (p->R && !p->r_f32) || (p->N & 3))) return false;

@@ -137,6 +137,8 @@ __device__ __forceinline__ void pp_epilogue_(const PPEpi& e, f32x4 (&acc)[NI][MI
         if (e.act == MGLD_ACT_SILU) {
           const e2 s0 = silu2(pk(v[0], v[1])), s1 = silu2(pk(v[2], v[3]));
           v = f32x4{s0[0], s0[1], s1[0], s1[1]};
+        } else if (e.act == MGLD_ACT_RELU) {           // SPADE's shared convolution (openaimodel.py: mlp_shared = conv + ReLU)
+          v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         }
         return v * alpha;
       }
@@ -255,6 +257,8 @@ __device__ __forceinline__ void pp_epilogue_stats(const PPEpi& e, f32x4 (&acc)[N
     if (e.act == MGLD_ACT_SILU) {
       const e2 s0 = silu2(pk(v[0], v[1])), s1 = silu2(pk(v[2], v[3]));
       v = f32x4{s0[0], s0[1], s1[0], s1[1]};
+    } else if (e.act == MGLD_ACT_RELU) {
+      v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     }
     return v * alpha;
   };

@@ -234,7 +234,7 @@ bool ppgemm_plan(const MgldIGemm* p, int* id) {
   if (!knob || p->mode != MGLD_MODE_LINEAR) return false;
   if (p->tune != 0 && (p->tune < 20 || p->tune > 20 + PP_NCFG)) return false;
   if (p->batch > 1 || p->W2 || p->out_f32 || p->bias_m || (p->K & 63) || p->K < 64) return false;
-  if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU || p->act == MGLD_ACT_GEGLU)) return false;
+  if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU || p->act == MGLD_ACT_RELU || p->act == MGLD_ACT_GEGLU)) return false;
   // operands go through unbounded buffer descriptors with 32-bit byte offsets relative to a tile's first row: a 256-row tile of either
   // operand must stay inside that range, and rows must hold K elements
   // (planner queries may leave the leading dimensions unset = 0: dense rows are assumed then)
@@ -271,6 +271,9 @@ bool ppgemm_plan(const MgldIGemm* p, int* id) {
     // projection N = 960, K = 320 is 768 tiles = three full rounds: 87.6 -> 61.8 us (profiles/r05_pp_lin_mscale2.txt); ragged rounds of
     // this short-K tile, and the 256 x 160 tile at K = 320 even in full rounds (46.8 vs 41.2 us at M = 32768), stay on the 128-class kernel
     if (bid < 0 && pp_cfg_fits(p, 6) && tiles_of(6) >= 2 * cus && tiles_of(6) % cus == 0) bid = 6;
+    // (round 6, measured and NOT taken: the 256 x 160 tile for the fused q|k|v projection of the 32^2 level at two clips — M = 16384, N = 1920,
+    //  K = 640, three full rounds, 58.3 -> 55.8 us in isolation and the LayerNorm in front folds into it — is 0.3 % SLOWER end to end,
+    //  13.41 / 13.43 / 13.44 against 13.43 / 13.48 / 13.48 frames/s alternated on one box: stays on the 128-class kernel)
     if (bid < 0 && p->K >= 1024) {
       static const double eff[PP_NCFG] = {1.00, 0.90, 0.72, 0.85, 0.85, 0.68, 0.95};
       double best = 0.0;

@@ -435,7 +435,8 @@ R3_BN = {0: 160, 1: 320, 2: 128, 3: 256, 4: 160, 5: 160, 6: 80, 7: 80, 8: 128}  
     (1, 128, 2, 72, 80, 1),        # W > 64, residual + SiLU epilogue, two column tiles
     (3, 320, 2, 64, 64, 2),        # the UNet's dominant shape, per-frame row vector, strided (concat-slice) input
     (1, 32, 1, 16, 16, 0),         # single slice (the ring is deeper than the problem), one tile
-    (2, 96, 1, 8, 16, 3)])         # three slices, nothing in the epilogue
+    (2, 96, 1, 8, 16, 3),          # three slices, nothing in the epilogue
+    (2, 64, 1, 16, 32, 4)])        # ReLU (SPADE's shared convolution)
 def test_igemm_conv3x3_pingpong(hip, cfg, n, cin, nt, h, w, epi):
     """conv3r: the ping-pong patch conv, every configuration (tune = 31 + id) vs torch's conv2d on the same fp16 operands"""
     from mgld_vsr_amd.engine import tile_conv3p
@@ -458,6 +459,9 @@ def test_igemm_conv3x3_pingpong(hip, cfg, n, cin, nt, h, w, epi):
         big = torch.zeros(n * h * w, cin + 64, dtype=torch.half, device=DEV)
         big[:, 32:32 + cin] = xt
         xt = big[:, 32:32 + cin]
+    elif epi == 4:
+        kw.update(act=hip.ACT_RELU)
+        ref = F.relu(ref)
     p = hip.MgldIGemm()
     p.mode, p.M, p.N, p.K, p.batch, p.tap_inner, p.tune = hip.MODE_CONV3X3, n * h * w, cout, 9 * cin, 1, 2, 31 + cfg
     p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, 1, 1, 1, 0
