@@ -339,6 +339,22 @@ def test_conv3p_planner_routes_the_unet_convolutions():
     # frame-stacked conv3r tiles of the 8 x 8 level: configurations 9 / 10 by tune only (the planner leaves the level to conv3q by default)
     assert qcode(8, 1280, 1280, 8, 8, tune=40) == 600009 and qcode(8, 1280, 1280, 8, 8, tune=41) == 600010
     assert qcode(8, 1280, 1280, 16, 16, tune=40) < 600000      # they take 8 x 8 frames only
+    # round 6 (two segments batched as clips: 16 frames; profiles/r06_conv_2clip.txt): a choice whose last round of tiles is mostly empty gives
+    # way to a large tile that fills whole rounds — 32^2 at 16 frames: 8x32x128 = 320 blocks (1.25 rounds) -> 16x32x80 = 256 blocks; the
+    # SPADE convolution 128 -> 640 at 8 frames x 64^2: 16x32x128 = 320 blocks -> 16x32x80 = 512; choices with >= 0.8 of the last round stay
+    assert qcode(16, 640, 640, 32, 32) == 600006 and qcode(8, 640, 640, 32, 32) == 600002
+    assert qcode(8, 128, 640, 64, 64) == 600006 and qcode(16, 128, 640, 64, 64) == 600008        # 640 of 768 slots: stays
+    assert qcode(16, 320, 320, 64, 64) == 600006 and qcode(16, 1280, 1280, 16, 16) == 600005     # 16^2 at 16 frames: 8x16x160 tiles = 256 blocks, no K split
+    assert qcode(5, 320, 320, 64, 64) == 600007 and qcode(10, 320, 320, 64, 64) == 600006        # no full-round alternative: the table's choice
+
+    def rcode(frames, cin, cout, h, w, act):
+        p = hip.MgldIGemm()
+        p.mode, p.M, p.N, p.K, p.batch, p.tap_inner, p.act = hip.MODE_CONV3X3, frames * h * w, cout, 9 * cin, 1, 2, act
+        p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.pad_t, p.pad_l, p.up2 = cin, h, w, h, w, 1, 1, 1, 0
+        return hip.igemm_config(p) % 1000000
+    # SPADE's shared convolution + ReLU rides the ping-pong kernel since round 6; activations its epilogue does not hold stay on conv3q
+    assert rcode(16, 256, 128, 64, 64, hip.ACT_RELU) == 600002 and rcode(16, 256, 128, 64, 64, hip.ACT_SILU) == 600002
+    assert 400000 <= rcode(16, 256, 128, 64, 64, hip.ACT_LRELU02) < 500000
 
     # statistics output of the producer (MgldIGemm.gn_part): tiles per frame where the picked kernel writes it, 0 where it does not
     def chunks(frames, cin, cout, h, w, tune=0, mode=hip.MODE_CONV3X3):
