@@ -323,13 +323,13 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const MgldIGemm p, const in
     // GroupNorm statistics of the output (MgldIGemm.gn_part): every wave's per-channel sums of its stored rows meet in LDS (the stages
     // are dead: both wave groups are past their last fragment read), one row of part[] per tile.  A tile lies in one frame.
     float* table = (float*)smem;
-    pp_epilogue_stats<MI, NI>(e, acc, lane, bn0 + wn * WN, p.rowvec ? (frame * Hout * Wout) / p.rows_per_frame : -1, row_of,
+    pp_epilogue_stats<MI, NI, true>(e, acc, lane, bn0 + wn * WN, p.rowvec ? (frame * Hout * Wout) / p.rows_per_frame : -1, row_of,
                               table + (wm * BN + wn * WN) * 2);
     __syncthreads();
     pp_stats_flush<WGM, BN>(table, p.gn_part, (int64_t)tile_m, p.N, bn0, tid);
     return;
   }
-  pp_epilogue<MI, NI, false>(e, acc, lane, bn0 + wn * WN, row_of);
+  pp_epilogue<MI, NI, false, true>(e, acc, lane, bn0 + wn * WN, row_of);
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ struct PPEpi {
 
 // FEAT: the round-6 extras (stream low planes, folded LayerNorm, row statistics) are compiled in; callers branch ONCE per block on whether any of
 // them is set, so a plain launch runs the round-5 instruction stream (the GEGLU epilogue is VALU-bound: the dormant checks cost it 5 %)
-template <int MI, int NI, bool GEGLU, bool FEAT, typename RowFn>
+template <int MI, int NI, bool GEGLU, bool FEAT, bool RELU, typename RowFn>
 __device__ __forceinline__ void pp_epilogue_(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const RowFn row_of) {
   // n0: first output channel (packed weight row for GEGLU) of this wave; row_of(mi) = global output row of this lane in fragment mi, or -1
   const int q = lane >> 4;
@@ -137,7 +137,8 @@ __device__ __forceinline__ void pp_epilogue_(const PPEpi& e, f32x4 (&acc)[NI][MI
         if (e.act == MGLD_ACT_SILU) {
           const e2 s0 = silu2(pk(v[0], v[1])), s1 = silu2(pk(v[2], v[3]));
           v = f32x4{s0[0], s0[1], s1[0], s1[1]};
-        } else if (e.act == MGLD_ACT_RELU) {           // SPADE's shared convolution (openaimodel.py: mlp_shared = conv + ReLU)
+        } else if (RELU && e.act == MGLD_ACT_RELU) {   // SPADE's shared convolution (conv + ReLU); compiled into the convolution's copy only —
+                                                       // the runtime check alone put the 256 x 320 LINEAR tile (256 VGPRs) into scratch: 54 -> 70 us
           v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         }
         return v * alpha;
@@ -216,10 +217,10 @@ __device__ __forceinline__ void pp_epilogue_(const PPEpi& e, f32x4 (&acc)[NI][MI
   }
 }
 
-template <int MI, int NI, bool GEGLU, typename RowFn>
+template <int MI, int NI, bool GEGLU, bool RELU = false, typename RowFn>
 __device__ __forceinline__ void pp_epilogue(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const RowFn row_of) {
-  if (e.Rlo || e.Clo || e.ln_part || e.row_tab) pp_epilogue_<MI, NI, GEGLU, true>(e, acc, lane, n0, row_of);
-  else pp_epilogue_<MI, NI, GEGLU, false>(e, acc, lane, n0, row_of);
+  if (e.Rlo || e.Clo || e.ln_part || e.row_tab) pp_epilogue_<MI, NI, GEGLU, true, RELU>(e, acc, lane, n0, row_of);
+  else pp_epilogue_<MI, NI, GEGLU, false, RELU>(e, acc, lane, n0, row_of);
 }
 
 // ---- the same epilogue + per-channel (sum, sumsq) of the output values (GroupNorm statistics of the output, MgldIGemm.gn_part) ----
@@ -236,7 +237,7 @@ __device__ __forceinline__ float pp_row16_sum(float v) {
   return v;
 }
 
-template <int MI, int NI, typename RowFn>
+template <int MI, int NI, bool RELU = false, typename RowFn>
 __device__ __forceinline__ void pp_epilogue_stats(const PPEpi& e, f32x4 (&acc)[NI][MI], const int lane, const int n0, const int fr,
                                                   const RowFn row_of, float* __restrict__ wave_sums) {
   const int q = lane >> 4, l15 = lane & 15;
@@ -257,7 +258,7 @@ __device__ __forceinline__ void pp_epilogue_stats(const PPEpi& e, f32x4 (&acc)[N
     if (e.act == MGLD_ACT_SILU) {
       const e2 s0 = silu2(pk(v[0], v[1])), s1 = silu2(pk(v[2], v[3]));
       v = f32x4{s0[0], s0[1], s1[0], s1[1]};
-    } else if (e.act == MGLD_ACT_RELU) {
+    } else if (RELU && e.act == MGLD_ACT_RELU) {
       v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     }
     return v * alpha;

@@ -234,7 +234,7 @@ bool ppgemm_plan(const MgldIGemm* p, int* id) {
   if (!knob || p->mode != MGLD_MODE_LINEAR) return false;
   if (p->tune != 0 && (p->tune < 20 || p->tune > 20 + PP_NCFG)) return false;
   if (p->batch > 1 || p->W2 || p->out_f32 || p->bias_m || (p->K & 63) || p->K < 64) return false;
-  if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU || p->act == MGLD_ACT_RELU || p->act == MGLD_ACT_GEGLU)) return false;
+  if (!(p->act == MGLD_ACT_NONE || p->act == MGLD_ACT_SILU || p->act == MGLD_ACT_GEGLU)) return false;
   // operands go through unbounded buffer descriptors with 32-bit byte offsets relative to a tile's first row: a 256-row tile of either
   // operand must stay inside that range, and rows must hold K elements
   // (planner queries may leave the leading dimensions unset = 0: dense rows are assumed then)

@@ -286,6 +286,21 @@ def test_conv3p_tiled_weight_layout():
         assert float(tz[1, :, :, 2:].abs().max()) == 0
 
 
+def test_no_kernel_spills_to_scratch():
+    """Every kernel of the shipped library, from the code objects' own metadata: no private segment (scratch), no VGPR spill — the
+    256 x 320 LINEAR tile sits at 256 VGPRs, and one more runtime check in its epilogue (round 6: a ReLU branch) put it into scratch and cost
+    30 % of its time before this test existed."""
+    import codeobj
+    from mgld_vsr_amd import hip
+    hip.lib()
+    ks = codeobj.kernels(hip.lib_path())
+    assert len(ks) > 200, len(ks)
+    bad = [(k[".name"], k.get(".private_segment_fixed_size"), k.get(".vgpr_spill_count")) for k in ks
+           if k.get(".private_segment_fixed_size", 0) or k.get(".vgpr_spill_count", 0)]
+    assert not bad, bad
+    assert max(k[".vgpr_count"] for k in ks) <= 256 and all(k[".wavefront_size"] == 64 for k in ks)
+
+
 def test_conv3p_planner_routes_the_unet_convolutions():
     """mgld_igemm_config is host logic (no launch): which 3x3 convolutions take the patch-staged kernel, and with how many
     weight rows per block.  Code = 300000 + rows (+ splits * 1e6 once a split-K workspace is registered, which needs a GPU)."""

@@ -77,3 +77,32 @@ def test_workload_vs_reference(hip, case, S):
     assert got[f"work_{case}_S{S}_latent"] < lat_tol and got[f"work_{case}_S{S}_frames"] < MARGIN * TOL, got
     assert got[f"work_{case}_S{S}_frames_w05"] < MARGIN * TOL, got
     assert abs(float(out.double().norm()) / float(g["out_norm"][0]) - 1.0) < 1e-3
+
+
+def test_two_clips_of_one_pass_at_full_width_vs_reference(hip):
+    """bench.py's default scheduling batches TWO segments as clips of one pass (16 frames): every launch sees twice the rows and the planners
+    pick other tiles for them (round 6: the 32^2 convolutions on 16 x 32 x 80 tiles, the 8^2 level on frame-stacked tiles with a K split).
+    The guided workloads c2g and c2s as the two clips of ONE full-width pass, 4 steps: each clip against ITS recording of the reference, at the
+    bounds it is held to alone."""
+    names = [f"g_work_{c}_S4" for c in ("c2g", "c2s")]
+    if not all(_have(n) for n in names):
+        pytest.skip("workload fixtures not generated")
+    from mgld_vsr_amd.pipeline import VSRPipeline, model_configs
+    gs = [G(n) for n in names]
+    cs = [case_inputs(c, 4) for c in ("c2g", "c2s")]
+    Tn, H, st = cs[0]["T"], cs[0]["H"], cs[0]["stride"]
+    assert all(c["T"] == Tn and c["H"] == H and c["stride"] == st for c in cs)
+    pipe = VSRPipeline(num_frames=Tn, ddpm_steps=4, configs=model_configs(Tn))
+    x = torch.cat([c["x"] for c in cs])
+    noise = {"posterior": torch.cat([c["noise"]["posterior"] for c in cs]), "x_T": torch.cat([c["noise"]["x_T"] for c in cs]),
+             "steps": torch.cat([c["noise"]["steps"] for c in cs], 1)}
+    flows = tuple(torch.cat([c[k][None] for c in cs]) for k in ("ff", "fb"))
+    masks = tuple(torch.cat([g[k][None, :, None] for g in gs]) for k in ("focc", "bocc"))
+    out, lat = pipe.run_segment(x, flows=flows, masks=masks, guidance_scale=-10.0, noise=noise, return_latents=True)
+    assert out.shape == (2 * Tn, 3, H, H) and bool(torch.isfinite(out).all())
+    for i, (case, g) in enumerate(zip(("c2g", "c2s"), gs)):
+        sl = slice(i * Tn, (i + 1) * Tn)
+        e_lat, e_out = rel_l2(lat[sl], g["x0"]), rel_l2(out[sl, :, ::st, ::st], g["out_s"])
+        record(f"work_2clips_{case}_S4_latent", e_lat)
+        record(f"work_2clips_{case}_S4_frames", e_out)
+        assert e_lat < (1.65e-3 if case == "c2s" else MARGIN * TOL) and e_out < MARGIN * TOL, (case, e_lat, e_out)
