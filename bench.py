@@ -623,7 +623,7 @@ def main():
         "layernorm_folded_into_consumer": bool(eng_.LN_FOLD),
         "first_stage_encoder": "fp32 activations, split-fp16 contractions" if os.environ.get("MGLD_HP_ENCODER", "1") != "0" else "fp16",
         "weight_residual_pass": ",".join(sorted(eng_.w2_scopes)) or "off",
-        "price": "two-plane stream: -4.5 % frames/s for -18 % latent / -28 % frame error (MGLD_STREAM_LO=0 MGLD_LN_FOLD=0: 14.25 against 13.63 / 13.98 against 13.35 on two boxes); "
+        "price": "two-plane stream: -4 % frames/s for -18 % latent / -28 % frame error (MGLD_STREAM_LO=0 MGLD_LN_FOLD=0: 14.25 against 13.63 / 13.89 against 13.33 on two boxes); "
                  "high-precision first-stage encoder: +29 ms per 8-frame encode (-2.5 %)",
     }
     if one_at_a_time is not None:     # both schedulings in one line: `value` = the default (segments in flight), this = the reference's loop
