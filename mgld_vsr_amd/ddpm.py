@@ -408,8 +408,7 @@ class LatentDiffusionVSRTextWT(nn.Module):
                 src = st["sc_tables"][blk._sc_key]
                 fh, fw = st["sc_step"][blk._sc_key][1]
                 seg = Act(src[c0:c0 + k].view(k * n * fh * fw, src.shape[2]), k * n, fh, fw)
-                gb = blk.spade_modulation(eng, seg)
-                hip.copy2d(gb.v, tab[c0:c0 + k].view(gb.rows, gb.C))
+                blk.spade_modulation(eng, seg, out=Act(tab[c0:c0 + k].view(k * n * fh * fw, tab.shape[2]), k * n, fh, fw))   # straight into the table
         st["spade"] = {key: (tab, tab.shape[1] * tab.shape[2], st["win_idx"]) for key, (blk, tab) in tables.items()}
 
     def _structcond_of_step(self, eng, st, lat_act):

@@ -145,14 +145,15 @@ class ResBlockDual(ResBlock):
         gb = self.spade_modulation(eng, struct_cond[self._sc_key])
         return eng.spade_apply(h, stats, g, b, gb, skip, out=out, want_stats=True)   # the transformer's norm reads this next
 
-    def spade_modulation(self, eng, seg):
-        """[gamma | beta] = conv(relu(conv(seg))) (spade.py:93-104): a function of the struct-cond features only"""
+    def spade_modulation(self, eng, seg, out=None):
+        """[gamma | beta] = conv(relu(conv(seg))) (spade.py:93-104): a function of the struct-cond features only; out: Act to write into
+        (the hoisted tables: no copy)"""
         sp = self.spade
         actv = eng.conv3x3(seg, eng.weight("c3", (sp.mlp_shared[0].weight,), pack_conv3x3), eng.f32("b", sp.mlp_shared[0].bias),
                            128, act=hip.ACT_RELU)
         wgb = eng.weight("c3gb", (sp.mlp_gamma.weight, sp.mlp_beta.weight), lambda g, b: pack_conv3x3(torch.cat([g, b], 0)))
         bgb = eng.weight("bgb", (sp.mlp_gamma.bias, sp.mlp_beta.bias), lambda g, b: torch.cat([g, b], 0), torch.float32)
-        return eng.conv3x3(actv, wgb, bgb, 2 * self.out_channels)
+        return eng.conv3x3(actv, wgb, bgb, 2 * self.out_channels, out=out)
 
 
 class QKVAttentionLegacy(nn.Module):
